@@ -1,0 +1,198 @@
+"""Index-form hit graphs: the HBM layout the HIP kernels consume.
+
+The reference keeps the hit<->segment association as two dense one-hot matrices
+`Ri`, `Ro` of shape [B, N, E] (reference gnn/graph.py:28-35,
+gnn/trainSegmentClassifier.py:66-95) and uses `bmm` against them as gather and
+scatter-add (reference gnn/model.py:71-72,114-119).  Here the same association is
+stored once, in index form, for a *block-diagonal batch* of G graphs:
+
+    X        float32 [N, F]     hit features, graphs concatenated (global hit ids)
+    src,dst  int32   [E]        start / end hit of every segment; -1 = padded column
+    in_ptr   int32   [N+1]      CSR over segments ENDING at each hit   (rows of Ri)
+    in_eid   int32   [E_valid]  segment ids, grouped by end hit, ascending id
+    in_nbr   int32   [E_valid]  = src[in_eid]   (the hit at the other end)
+    out_ptr / out_eid / out_nbr the same for segments STARTING at each hit (rows of Ro),
+                                out_nbr = dst[out_eid]
+
+On disk the reference already stores exactly this ordering: `Ri.nonzero()` is
+row-major (reference gnn/graph.py:23-26), so `Ri_rows` is sorted by hit and
+`Ri_cols` is `in_eid`; `from_sparse_arrays` therefore needs a bincount, not a sort.
+
+Host-side numpy builds the plan once per batch; `to(device)` uploads it.
+"""
+import numpy as np
+import torch
+
+_I32 = np.int32
+
+
+def _csr_by(key, other, n_hits):
+    """Group valid segments by `key` hit; stable => ascending segment id per hit."""
+    valid = np.flatnonzero(key >= 0)
+    k = key[valid]
+    order = np.argsort(k, kind="stable")
+    eid = valid[order].astype(_I32)
+    ptr = np.zeros(n_hits + 1, dtype=np.int64)
+    np.cumsum(np.bincount(k, minlength=n_hits), out=ptr[1:])
+    if ptr[-1] >= 2 ** 31:
+        raise ValueError("segment count exceeds int32 index range")
+    return ptr.astype(_I32), eid, other[eid].astype(_I32)
+
+
+class HitGraphBatch:
+    """A block-diagonal batch of hit graphs in index form (see module docstring)."""
+
+    _TENSORS = ("X", "src", "dst", "in_ptr", "in_eid", "in_nbr",
+                "out_ptr", "out_eid", "out_nbr", "y")
+
+    def __init__(self, X, src, dst, y=None, hit_ptr=None, seg_ptr=None,
+                 dense_shape=None, csr=None):
+        X = np.ascontiguousarray(X, dtype=np.float32)
+        src = np.ascontiguousarray(src, dtype=_I32)
+        dst = np.ascontiguousarray(dst, dtype=_I32)
+        if X.ndim != 2 or src.ndim != 1 or src.shape != dst.shape:
+            raise ValueError("expected X [N,F], src [E], dst [E]")
+        n = X.shape[0]
+        pad = src < 0
+        if np.any(pad != (dst < 0)):
+            raise ValueError("a padded segment must have src = dst = -1")
+        if src.size and (src.max(initial=-1) >= n or dst.max(initial=-1) >= n):
+            raise ValueError("segment endpoint out of range")
+        self.n_hits, self.n_features = n, X.shape[1]
+        self.n_segments = src.shape[0]
+        self.hit_ptr = np.asarray([0, n] if hit_ptr is None else hit_ptr, dtype=np.int64)
+        self.seg_ptr = np.asarray([0, self.n_segments] if seg_ptr is None else seg_ptr,
+                                  dtype=np.int64)
+        self.n_graphs = len(self.hit_ptr) - 1
+        self.dense_shape = dense_shape  # (B, N_max, E_max) when built from a padded batch
+        if csr is None:
+            in_ptr, in_eid, in_nbr = _csr_by(dst, src, n)
+            out_ptr, out_eid, out_nbr = _csr_by(src, dst, n)
+        else:
+            in_ptr, in_eid, in_nbr, out_ptr, out_eid, out_nbr = csr
+        t = torch.from_numpy
+        self.X, self.src, self.dst = t(X), t(src), t(dst)
+        self.in_ptr, self.in_eid, self.in_nbr = t(in_ptr), t(in_eid), t(in_nbr)
+        self.out_ptr, self.out_eid, self.out_nbr = t(out_ptr), t(out_eid), t(out_nbr)
+        self.y = None if y is None else t(np.ascontiguousarray(y, dtype=np.float32))
+
+    # -- constructors ------------------------------------------------------------------
+    @classmethod
+    def from_graphs(cls, graphs):
+        """Index-form batcher: block-diagonal concatenation, no padding.
+
+        Replaces the zero-padding `merge_graphs` (reference
+        gnn/trainSegmentClassifier.py:66-95): batch composition order is the list
+        order (`graphs[j:j+batch_size]`, :103-104), features cast to float32 (:38-44).
+        """
+        hit_ptr = np.zeros(len(graphs) + 1, dtype=np.int64)
+        seg_ptr = np.zeros(len(graphs) + 1, dtype=np.int64)
+        for i, g in enumerate(graphs):
+            hit_ptr[i + 1] = hit_ptr[i] + g.X.shape[0]
+            seg_ptr[i + 1] = seg_ptr[i] + g.src.shape[0]
+        X = np.concatenate([np.asarray(g.X, dtype=np.float32) for g in graphs])
+        src = np.concatenate([np.asarray(g.src, dtype=np.int64) + hit_ptr[i]
+                              for i, g in enumerate(graphs)])
+        dst = np.concatenate([np.asarray(g.dst, dtype=np.int64) + hit_ptr[i]
+                              for i, g in enumerate(graphs)])
+        ys = [getattr(g, "y", None) for g in graphs]
+        y = None if any(v is None for v in ys) else np.concatenate(ys)
+        return cls(X, src, dst, y=y, hit_ptr=hit_ptr, seg_ptr=seg_ptr)
+
+    @classmethod
+    def from_sparse_arrays(cls, X, Ri_rows, Ri_cols, Ro_rows, Ro_cols, y=None):
+        """From the reference's on-disk `SparseGraph` arrays (gnn/graph.py:20-26,179-194).
+
+        `Ri_rows` (end hits) and `Ro_rows` (start hits) are sorted ascending because
+        `nonzero()` is row-major, so they are CSR order already: rowptr is a bincount.
+        Unsorted input (hand-made files) is handled by a stable sort.
+        """
+        X = np.asarray(X, dtype=np.float32)
+        n = X.shape[0]
+        e = int(np.asarray(Ri_rows).shape[0])
+        if np.asarray(Ro_rows).shape[0] != e:
+            raise ValueError("Ri and Ro must describe the same segments")
+
+        def one(rows, cols):
+            rows = np.asarray(rows, dtype=np.int64)
+            cols = np.asarray(cols, dtype=np.int64)
+            if rows.size and np.any(np.diff(rows) < 0):
+                o = np.lexsort((cols, rows))
+                rows, cols = rows[o], cols[o]
+            ptr = np.zeros(n + 1, dtype=np.int64)
+            np.cumsum(np.bincount(rows, minlength=n), out=ptr[1:])
+            end = np.full(e, -1, dtype=np.int64)
+            end[cols] = rows
+            return ptr.astype(_I32), cols.astype(_I32), end
+
+        in_ptr, in_eid, dst = one(Ri_rows, Ri_cols)
+        out_ptr, out_eid, src = one(Ro_rows, Ro_cols)
+        if np.any(src < 0) or np.any(dst < 0):
+            raise ValueError("every segment needs exactly one start and one end hit")
+        csr = (in_ptr, in_eid, src[in_eid].astype(_I32),
+               out_ptr, out_eid, dst[out_eid].astype(_I32))
+        return cls(X, src, dst, y=y, csr=csr)
+
+    @classmethod
+    def from_npz(cls, filename):
+        """Read one graph file written by the reference's `save_graph` (gnn/graph.py:179-194)."""
+        with np.load(filename) as f:  # allow_pickle stays False
+            return cls.from_sparse_arrays(f["X"], f["Ri_rows"], f["Ri_cols"],
+                                          f["Ro_rows"], f["Ro_cols"],
+                                          y=f["y"] if "y" in f.files else None)
+
+    @classmethod
+    def from_dense(cls, X, Ri, Ro, y=None):
+        """Compatibility adapter for the reference's dense inputs [B,N,F], [B,N,E], [B,N,E].
+
+        Column j of Ri/Ro holds a single 1 at the end/start hit (gnn/graph.py:132-135);
+        an all-zero column is a padded segment (gnn/trainSegmentClassifier.py:83-93)
+        and becomes src = dst = -1.  O(B*N*E) reads: kept off the benchmarked path.
+        """
+        Xn = X.detach().cpu().numpy() if torch.is_tensor(X) else np.asarray(X)
+        Rin = Ri.detach().cpu().numpy() if torch.is_tensor(Ri) else np.asarray(Ri)
+        Ron = Ro.detach().cpu().numpy() if torch.is_tensor(Ro) else np.asarray(Ro)
+        if Xn.ndim == 2:
+            Xn, Rin, Ron = Xn[None], Rin[None], Ron[None]
+        B, N, _ = Xn.shape
+        E = Rin.shape[2]
+        if Rin.shape != (B, N, E) or Ron.shape != (B, N, E):
+            raise ValueError("expected X [B,N,F], Ri [B,N,E], Ro [B,N,E]")
+        off = (np.arange(B, dtype=np.int64) * N)[:, None]
+
+        def ends(R):
+            nz = R != 0
+            cnt = nz.sum(axis=1)
+            if np.any(cnt > 1):
+                raise ValueError("incidence matrix column with more than one hit")
+            idx = nz.argmax(axis=1).astype(np.int64) + off
+            return np.where(cnt == 1, idx, -1).reshape(-1)
+
+        dst, src = ends(Rin), ends(Ron)
+        if np.any((src < 0) != (dst < 0)):
+            raise ValueError("a segment column must be set in both Ri and Ro or in neither")
+        yy = None if y is None else (y.detach().cpu().numpy() if torch.is_tensor(y) else
+                                     np.asarray(y)).reshape(-1)
+        return cls(Xn.reshape(B * N, -1), src, dst, y=yy,
+                   hit_ptr=np.arange(B + 1) * N, seg_ptr=np.arange(B + 1) * E,
+                   dense_shape=(B, N, E))
+
+    # -- device movement -----------------------------------------------------------------
+    def to(self, device):
+        for k in self._TENSORS:
+            v = getattr(self, k)
+            if v is not None:
+                setattr(self, k, v.to(device))
+        return self
+
+    def cuda(self, device=None):
+        return self.to(torch.device("cuda", torch.cuda.current_device() if device is None
+                                    else device))
+
+    @property
+    def device(self):
+        return self.X.device
+
+    def split_scores(self, e):
+        """Per-graph views of a flat score vector [E]."""
+        return [e[self.seg_ptr[i]:self.seg_ptr[i + 1]] for i in range(self.n_graphs)]
