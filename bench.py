@@ -1,0 +1,174 @@
+"""bench.py - edges/s of the SegmentClassifier forward on synthetic TrackML-shaped graphs.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (input network, T x (edge pass, node pass), final
+edge pass; reference gnn/model.py:140-156) over one batch of G synthetic graphs already
+resident in HBM, in index form.  Workload = BASELINE.json configs[2] ("c3"): 10k hits /
+100k segments per graph, F=3, D=8, T=3, G graphs per launch per GPU (SURVEY.md 8(d):
+one 100k-segment graph is cache-resident and launch-bound, so the roofline number is
+taken on a batch).  Multi-GPU: independent graphs sharded over ranks, no data-path
+collective (weak scaling); barrier + synchronize on both sides, max over ranks.
+
+Rank 0 prints ONE JSON line with `roofline` (dominant kernel, HIP-event timed inside the
+library on the launch stream) and `cpu_baseline` (the oracle's dense-bmm port of the
+reference algorithm, timed on this host's cores, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+
+N_HITS, N_SEG, F, D, T = 10000, 100000, 3, 8, 3
+C = F + D
+
+
+def algorithmic_bytes(n, e):
+    """compulsory HBM bytes per kernel launch, fp32 values / int32 indices."""
+    b_in = 4 * n * F + 4 * n * D
+    b_edge = 8 * e + 4 * n * C + 4 * e
+    b_node = 8 * e + 4 * e + 4 * n * C + 4 * n * D
+    return {"k_input": b_in, "k_edge": b_edge, "k_node": b_node,
+            "forward": b_in + (T + 1) * b_edge + T * b_node}
+
+
+def cpu_baseline(model, graph):
+    """Oracle timed on this host: (a) the dense-bmm port of reference gnn/model.py (the
+    algorithm the reference runs), one c3 graph; (b) the index-form C oracle, all cores."""
+    from oracle import dense_torch, index_c
+    from gnn_fpga_amd import synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    params = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    X, Ri, Ro = (torch.from_numpy(a)[None] for a in synth.to_dense(graph))
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        dense_torch.segment_classifier(X, Ri, Ro, params, T)
+    t_dense = time.perf_counter() - t0
+    del Ri, Ro
+    pn = {k: v.numpy() for k, v in params.items()}
+    index_c.segment_classifier(graph.X, graph.src, graph.dst, pn, T)     # warm
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        index_c.segment_classifier(graph.X, graph.src, graph.dst, pn, T)
+    t_index = (time.perf_counter() - t0) / reps
+    return {"value": N_SEG / t_dense, "unit": "edges/s", "cores": cores, "kind": "port",
+            "sample": "1 graph of the workload (10k hits, 100k segments), dense [N,E] bmm "
+                      "formulation of gnn/model.py restated in oracle/dense_torch.py, "
+                      "torch CPU %d threads, 1 run (%.1f s)" % (cores, t_dense),
+            "index_form_value": N_SEG / t_index,
+            "index_form_sample": "same graph, oracle/index_c (OpenMP, %d threads), mean of %d runs"
+                                 % (index_c.max_threads(), reps)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--graphs", type=int, default=256, help="graphs per launch per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pmc-traffic-bytes", type=float, default=None,
+                    help="HBM bytes per launch of the dominant kernel from a separate "
+                         "rocprofv3 --pmc pass (profiles/), corrected per MI355X_MICROARCH.md")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run "
+                         "--nproc-per-node %d" % (args.gpus, world, args.gpus))
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from gnn_fpga_amd import HitGraphBatch, _lib, synth
+    from gnn_fpga_amd.model import SegmentClassifier
+
+    G = args.graphs
+    graphs = [synth.layered_graph(N_HITS, N_SEG, F, seed=rank * G + i) for i in range(G)]
+    batch = HitGraphBatch.from_graphs(graphs).to(dev)
+    torch.manual_seed(0)
+    model = SegmentClassifier(input_dim=F, hidden_dim=D, n_iters=T).to(dev).eval()
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            model(batch)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            model(batch)
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        # per-kernel durations: HIP events recorded by the library around every launch,
+        # on the launch stream, in a separate pass (events perturb the timed region)
+        with _lib.profile(capacity=16 * args.steps) as prof:
+            for _ in range(args.steps):
+                model(batch)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        per = {}
+        for name, ms in prof.records:
+            per.setdefault(name, []).append(ms)
+        tot = {k: sum(v) for k, v in per.items()}
+        dom = max(tot, key=tot.get)
+        avg_ms = {k: sum(v) / len(v) for k, v in per.items()}
+        n_tot, e_tot = batch.n_hits, batch.n_segments
+        ab = algorithmic_bytes(n_tot, e_tot)
+        achieved = ab[dom] / (avg_ms[dom] * 1e-3) / 1e9
+        ms_step = elapsed / args.steps * 1e3
+        value = world * e_tot * args.steps / elapsed
+        out = {
+            "metric": "edges/sec (EdgeNet+NodeNet fwd) on 100k-edge TrackML graphs; % HBM roofline",
+            "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "c3 synthetic TrackML ACTS graphs: %d graphs/launch/GPU x "
+                                   "(10k hits, 100k segments), F=3, D=8, 3 MP iterations + final "
+                                   "edge pass, index form resident in HBM" % G,
+                       "graphs_per_gpu": G, "hits_per_graph": N_HITS,
+                       "segments_per_graph": N_SEG, "sharding": "independent graphs per rank, "
+                       "no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": args.pmc_traffic_bytes,
+                         "algorithmic_bytes_per_launch": ab[dom],
+                         "avg_launch_ms": avg_ms[dom],
+                         "kernel_ms": {k: round(v, 4) for k, v in avg_ms.items()},
+                         "launches_per_step": {k: len(v) // args.steps for k, v in per.items()},
+                         "forward_algorithmic_GBps": ab["forward"] / (ms_step * 1e-3) / 1e9,
+                         "forward_frac": ab["forward"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, graphs[0])
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,223 @@
+"""ctypes binding of libgnn_hip.so (C ABI in include/gnn_hip.h).
+
+This is the only compute path of the package: there is no CPU or eager-PyTorch
+fallback.  If the library is missing or a tensor is not on a ROCm device the call
+raises.  torch is used for device memory and the stream handle only.
+"""
+import ctypes
+import os
+
+import torch  # imported first: its bundled libamdhip64.so.7 is the one HIP runtime of the process
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgnn_hip.so")
+
+GNN_ABI_VERSION = 1
+GNN_ERR_UNSUPPORTED = -10001
+GNN_ERR_BADARG = -10002
+GNN_ERR_WORKSPACE = -10003
+
+_f = ctypes.c_void_p          # device pointers travel as integers
+_i32, _i64, _sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
+
+
+class GnnParams(ctypes.Structure):
+    _fields_ = [(n, _f) for n in ("Win", "bin", "W1", "b1", "W2", "b2", "W3", "b3", "W4", "b4")] + \
+               [("F", _i32), ("D", _i32)]
+
+
+class GnnGraph(ctypes.Structure):
+    _fields_ = [(n, _f) for n in ("X", "src", "dst", "in_ptr", "in_eid", "in_nbr",
+                                  "out_ptr", "out_eid", "out_nbr")] + \
+               [("n_hits", _i64), ("n_segments", _i64)]
+
+
+# name -> (restype, argtypes); must list every function include/gnn_hip.h declares
+SIGNATURES = {
+    "gnn_abi_version": (ctypes.c_int, []),
+    "gnn_last_error": (ctypes.c_char_p, []),
+    "gnn_shape_supported": (ctypes.c_int, [_i32, _i32]),
+    "gnn_h_stride": (_i32, [_i32, _i32]),
+    "gnn_input_fwd": (ctypes.c_int, [_f, _f, _f, _f, _i64, _i32, _i32, _i32, _f]),
+    "gnn_edge_fwd": (ctypes.c_int, [_f, _i32, _f, _f, _f, _f, _f, _f, _f, _f, _i64, _i64,
+                                    _i32, _i32, _f]),
+    "gnn_node_fwd": (ctypes.c_int, [_f, _i32, _f, ctypes.POINTER(GnnGraph), _f, _f, _f, _f, _f,
+                                    _i32, _i32, _f]),
+    "gnn_forward_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
+    "gnn_segclf_forward": (ctypes.c_int, [ctypes.POINTER(GnnGraph), ctypes.POINTER(GnnParams),
+                                          _i32, _f, _f, _f, _f, _sz, _f]),
+    "gnn_profile_begin": (ctypes.c_int, [_i32]),
+    "gnn_profile_end": (ctypes.c_int, [ctypes.POINTER(ctypes.c_char_p),
+                                       ctypes.POINTER(ctypes.c_float), _i32]),
+}
+
+_lib = None
+
+
+class GnnHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libgnn_hip.so once; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GnnHipError(
+            "HIP library %s is missing - build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C gnn-fpga_amd/csrc`; there is no CPU fallback" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)           # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    if lib.gnn_abi_version() != GNN_ABI_VERSION:
+        raise GnnHipError("libgnn_hip.so ABI %d != binding ABI %d"
+                          % (lib.gnn_abi_version(), GNN_ABI_VERSION))
+    with open("/proc/self/maps") as m:
+        runtimes = {ln.split()[-1] for ln in m if "libamdhip64" in ln}
+    if len(runtimes) > 1:
+        raise GnnHipError("two HIP runtimes mapped (%s): kernels and torch streams would not "
+                          "share a context" % ", ".join(sorted(runtimes)))
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise GnnHipError("libgnn_hip: %s (code %d)" % (load().gnn_last_error().decode(), rc))
+
+
+def _dev(t, dtype, what):
+    if not torch.is_tensor(t) or not t.is_cuda:
+        raise GnnHipError("%s must be a tensor on a ROCm device (no CPU path exists)" % what)
+    if t.dtype != dtype or not t.is_contiguous():
+        raise GnnHipError("%s must be contiguous %s" % (what, dtype))
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def shape_supported(F, D):
+    return bool(load().gnn_shape_supported(F, D))
+
+
+def h_stride(F, D):
+    s = load().gnn_h_stride(F, D)
+    if s == 0:
+        raise GnnHipError("no HIP kernel for input_dim=%d hidden_dim=%d" % (F, D))
+    return s
+
+
+def graph_struct(batch):
+    i32 = torch.int32
+    g = GnnGraph()
+    g.X = _dev(batch.X, torch.float32, "X")
+    for k in ("src", "dst", "in_ptr", "in_eid", "in_nbr", "out_ptr", "out_eid", "out_nbr"):
+        setattr(g, k, _dev(getattr(batch, k), i32, k))
+    g.n_hits, g.n_segments = batch.n_hits, batch.n_segments
+    return g
+
+
+def params_struct(weights, F, D):
+    """weights: the ten effective (masked) tensors in state_dict order."""
+    p = GnnParams()
+    for name, w in zip(("Win", "bin", "W1", "b1", "W2", "b2", "W3", "b3", "W4", "b4"), weights):
+        setattr(p, name, _dev(w, torch.float32, name))
+    p.F, p.D = F, D
+    return p
+
+
+def input_fwd(X, Win, bin_):
+    """[n_hits, F] -> H [n_hits, ldh] = [tanh(Win X + bin) | X | 0]."""
+    n, F = X.shape
+    D = Win.shape[0]
+    ldh = h_stride(F, D)
+    H = torch.empty((n, ldh), dtype=torch.float32, device=X.device)
+    _check(load().gnn_input_fwd(_dev(X, torch.float32, "X"), _dev(Win, torch.float32, "Win"),
+                                _dev(bin_, torch.float32, "bin"), H.data_ptr(), n, F, D, ldh,
+                                _stream()))
+    return H
+
+
+def edge_fwd(H, src, dst, W1, b1, W2, b2, F, D):
+    """H [n_hits, ldh] (ldh >= C), src/dst int32 [n_segments] -> e [n_segments]."""
+    n, ldh = H.shape
+    E = src.shape[0]
+    e = torch.empty(E, dtype=torch.float32, device=H.device)
+    pq = torch.empty((max(n, 1), 2 * D), dtype=torch.float32, device=H.device)
+    _check(load().gnn_edge_fwd(_dev(H, torch.float32, "H"), ldh, _dev(src, torch.int32, "src"),
+                               _dev(dst, torch.int32, "dst"), _dev(W1, torch.float32, "W1"),
+                               _dev(b1, torch.float32, "b1"), _dev(W2, torch.float32, "W2"),
+                               _dev(b2, torch.float32, "b2"), e.data_ptr(), pq.data_ptr(),
+                               n, E, F, D, _stream()))
+    return e
+
+
+def node_fwd(H, e, batch, W3, b3, W4, b4, F, D):
+    """H [n_hits, ldh], e [n_segments] -> Hnext [n_hits, ldh] = [H' | X | 0]."""
+    n, ldh = H.shape
+    Hn = torch.zeros_like(H)
+    g = graph_struct(batch)
+    _check(load().gnn_node_fwd(_dev(H, torch.float32, "H"), ldh, _dev(e, torch.float32, "e"),
+                               ctypes.byref(g), _dev(W3, torch.float32, "W3"),
+                               _dev(b3, torch.float32, "b3"), _dev(W4, torch.float32, "W4"),
+                               _dev(b4, torch.float32, "b4"), Hn.data_ptr(), F, D, _stream()))
+    return Hn
+
+
+def workspace_bytes(n_hits, n_segments, F, D):
+    return int(load().gnn_forward_workspace_bytes(n_hits, n_segments, F, D))
+
+
+def segclf_forward(batch, weights, F, D, n_iters, out=None, workspace=None, trace=False):
+    """Whole SegmentClassifier forward on an index-form batch.
+
+    Returns scores [n_segments] (and, with trace=True, e_trace [(T+1), E] and
+    H_trace [(T+1), N, C])."""
+    dev = batch.X.device
+    E, N = batch.n_segments, batch.n_hits
+    if not shape_supported(F, D):
+        raise GnnHipError("no HIP kernel for input_dim=%d hidden_dim=%d" % (F, D))
+    need = workspace_bytes(N, E, F, D)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+    if out is None:
+        out = torch.empty(E, dtype=torch.float32, device=dev)
+    et = Ht = None
+    if trace:
+        et = torch.empty((n_iters + 1, E), dtype=torch.float32, device=dev)
+        Ht = torch.empty((n_iters + 1, N, F + D), dtype=torch.float32, device=dev)
+    g = graph_struct(batch)
+    p = params_struct(weights, F, D)
+    _check(load().gnn_segclf_forward(ctypes.byref(g), ctypes.byref(p), n_iters,
+                                     _dev(out, torch.float32, "out"),
+                                     et.data_ptr() if trace else None,
+                                     Ht.data_ptr() if trace else None,
+                                     workspace.data_ptr(), workspace.numel(), _stream()))
+    return (out, et, Ht) if trace else out
+
+
+class profile:
+    """Context manager: per-kernel HIP-event timings of everything launched inside.
+
+    with _lib.profile(64) as prof: ...; prof.records -> [(kernel_name, ms), ...]"""
+
+    def __init__(self, capacity=256):
+        self.capacity = capacity
+        self.records = []
+
+    def __enter__(self):
+        _check(load().gnn_profile_begin(self.capacity))
+        return self
+
+    def __exit__(self, *exc):
+        names = (ctypes.c_char_p * self.capacity)()
+        ms = (ctypes.c_float * self.capacity)()
+        n = load().gnn_profile_end(names, ms, self.capacity)
+        if n < 0:
+            _check(n)
+        self.records = [(names[i].decode(), float(ms[i])) for i in range(min(n, self.capacity))]
+        return False

@@ -1,0 +1,557 @@
+// gnn_kernels.hip - SegmentClassifier message-passing forward for gfx950 (MI355X, CDNA4).
+//
+// What the reference does with dense one-hot incidence matrices and bmm
+// (gnn/model.py:69-81,113-125,140-156) is done here in index form, one lane per
+// segment (edge pass) or per hit (node pass), wave64, fp32 throughout:
+//
+//   k_input  H0[n] = [tanh(Win X[n] + bin) | X[n]]                       model.py:144-146
+//   k_edge   e[j]  = sigmoid(W2 tanh(P[src j] + Q[dst j]) + b2)          model.py:71-73,45-49
+//   k_node   mi/mo = CSR pull segment sums of e[j] * H[nbr]; H' = tanh(W4 tanh(W3 M + b3) + b4)
+//                                                                        model.py:114-125,154
+//
+// The first edge-MLP layer is linear in the concatenated pair [H_src | H_dst], so it is
+// split per hit:  W1 [H_s | H_d] + b1 = (W1[:, :C] H_s + b1) + W1[:, C:] H_d = P[s] + Q[d].
+// P and Q (D floats each) are produced by the kernel that produces H (k_input / k_node), which
+// turns the per-segment 2C x D contraction into a per-hit one (E/N ~ 10x fewer FMAs) and
+// shrinks the per-segment gather from 2 x C to 2 x D floats.
+//
+// Weights are tiny (569 floats at F=3, D=8): every weight address is wave-uniform, so the
+// compiler keeps them on the scalar path (s_load / SGPR operands) - no LDS, no VGPR copies.
+// No MFMA here by design: at D <= 16 the work is HBM/gather-bound integer-indexed traffic.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <vector>
+
+#include "gnn_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// error + profiling plumbing
+// ---------------------------------------------------------------------------------------------
+thread_local char g_err[320] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+struct Profiler {
+    bool on = false;
+    int cap = 0;
+    std::vector<hipEvent_t> ev;     // 2 per record
+    std::vector<const char *> name;
+    int n = 0;
+};
+Profiler g_prof;
+
+inline void prof_pre(const char *name, hipStream_t s)
+{
+    if (g_prof.on && g_prof.n < g_prof.cap) {
+        g_prof.name[g_prof.n] = name;
+        (void)hipEventRecord(g_prof.ev[2 * g_prof.n], s);
+    }
+}
+inline void prof_post(hipStream_t s)
+{
+    if (g_prof.on && g_prof.n < g_prof.cap) {
+        (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], s);
+        g_prof.n++;
+    }
+}
+
+#define GNN_LAUNCH(NAME, KERNEL, GRID, BLOCK, STREAM, ...)                                   \
+    do {                                                                                     \
+        prof_pre(NAME, STREAM);                                                              \
+        hipLaunchKernelGGL(KERNEL, dim3(GRID), dim3(BLOCK), 0, STREAM, __VA_ARGS__);         \
+        prof_post(STREAM);                                                                   \
+        hipError_t err_ = hipGetLastError();                                                 \
+        if (err_ != hipSuccess)                                                              \
+            return fail(-(int)err_, "%s launch failed: %s", NAME, hipGetErrorString(err_));  \
+    } while (0)
+
+constexpr int kBlock = 256;   // 4 waves of 64
+
+inline unsigned grid_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+// tanh(x) = 1 - 2 / (2^(2 log2(e) x) + 1): v_exp_f32 + v_rcp_f32 (1 ulp each), absolute error
+// ~1e-7 everywhere (the score tolerance is absolute, 1e-5).  Saturates correctly at +-inf.
+__device__ __forceinline__ float tanh_f(float x)
+{
+    float t = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
+}
+
+__device__ __forceinline__ float sigmoid_f(float x)
+{
+    float t = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);
+    return __builtin_amdgcn_rcpf(1.0f + t);
+}
+
+template <int F, int D>
+struct Shape {
+    static constexpr int C = F + D;
+    static constexpr int LDH = (C + 3) & ~3;
+};
+
+// P = W1[:, :C] h + b1, Q = W1[:, C:] h  -> PQ row [P(D) | Q(D)], stored as float4s.
+template <int F, int D>
+__device__ __forceinline__ void store_pq(const float *h, const float *__restrict__ W1,
+                                         const float *__restrict__ b1, float *__restrict__ pq_row)
+{
+    constexpr int C = F + D;
+    float pq[2 * D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        float p = b1[d], q = 0.0f;
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            p = fmaf(W1[d * 2 * C + k], h[k], p);
+            q = fmaf(W1[d * 2 * C + C + k], h[k], q);
+        }
+        pq[d] = p;
+        pq[D + d] = q;
+    }
+    float4 *o = reinterpret_cast<float4 *>(pq_row);
+#pragma unroll
+    for (int v = 0; v < 2 * D / 4; ++v)
+        o[v] = make_float4(pq[4 * v], pq[4 * v + 1], pq[4 * v + 2], pq[4 * v + 3]);
+}
+
+template <int N4>
+__device__ __forceinline__ void store_row4(float *__restrict__ row, const float *v)
+{
+    float4 *o = reinterpret_cast<float4 *>(row);
+#pragma unroll
+    for (int i = 0; i < N4; ++i) o[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+// input network + skip concat (+ P/Q of the first edge pass).  One hit per lane.
+template <int F, int D>
+__global__ __launch_bounds__(kBlock) void k_input(const float *__restrict__ X,
+                                                  const float *__restrict__ Win,
+                                                  const float *__restrict__ bin,
+                                                  const float *__restrict__ W1,
+                                                  const float *__restrict__ b1,
+                                                  float *__restrict__ H, int ldh,
+                                                  float *__restrict__ PQ, int64_t n_hits)
+{
+    constexpr int LDH = Shape<F, D>::LDH;
+    const int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (n >= n_hits) return;
+    float h[LDH];
+#pragma unroll
+    for (int k = 0; k < F; ++k) h[D + k] = X[n * F + k];
+#pragma unroll
+    for (int k = D + F; k < LDH; ++k) h[k] = 0.0f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        float acc = bin[d];
+#pragma unroll
+        for (int k = 0; k < F; ++k) acc = fmaf(Win[d * F + k], h[D + k], acc);
+        h[d] = tanh_f(acc);
+    }
+    store_row4<LDH / 4>(H + n * ldh, h);
+    if (PQ) store_pq<F, D>(h, W1, b1, PQ + n * 2 * D);
+}
+
+// P/Q from an existing H (stand-alone EdgeNetwork entry point).
+template <int F, int D>
+__global__ __launch_bounds__(kBlock) void k_pq(const float *__restrict__ H, int ldh,
+                                               const float *__restrict__ W1,
+                                               const float *__restrict__ b1,
+                                               float *__restrict__ PQ, int64_t n_hits)
+{
+    constexpr int C = F + D;
+    const int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (n >= n_hits) return;
+    float h[C];
+#pragma unroll
+    for (int k = 0; k < C; ++k) h[k] = H[n * ldh + k];
+    store_pq<F, D>(h, W1, b1, PQ + n * 2 * D);
+}
+
+// edge pass: one segment per lane; coalesced src/dst reads and e writes, two D-float gathers.
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_edge(const int32_t *__restrict__ src,
+                                                 const int32_t *__restrict__ dst,
+                                                 const float *__restrict__ PQ,
+                                                 const float *__restrict__ b1,
+                                                 const float *__restrict__ W2,
+                                                 const float *__restrict__ b2,
+                                                 float *__restrict__ e, int64_t n_segments)
+{
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n_segments) return;
+    const int s = src[j], d = dst[j];
+    float z[D];
+    if (s >= 0) {
+        const float4 *p = reinterpret_cast<const float4 *>(PQ + (int64_t)s * 2 * D);
+        const float4 *q = reinterpret_cast<const float4 *>(PQ + (int64_t)d * 2 * D + D);
+#pragma unroll
+        for (int v = 0; v < D / 4; ++v) {
+            const float4 a = p[v], b = q[v];
+            z[4 * v] = a.x + b.x;
+            z[4 * v + 1] = a.y + b.y;
+            z[4 * v + 2] = a.z + b.z;
+            z[4 * v + 3] = a.w + b.w;
+        }
+    } else {  // padded column: gathered rows are zero -> first layer output is b1
+#pragma unroll
+        for (int k = 0; k < D; ++k) z[k] = b1[k];
+    }
+    float acc = b2[0];
+#pragma unroll
+    for (int k = 0; k < D; ++k) acc = fmaf(W2[k], tanh_f(z[k]), acc);
+    e[j] = sigmoid_f(acc);
+}
+
+// node pass: one hit per lane; pull-mode segment sums over the two CSRs in ascending segment
+// id, fused 3C -> D -> D tanh MLP, skip concat, and P/Q for the next edge pass.
+template <int F, int D>
+__global__ __launch_bounds__(kBlock) void k_node(
+    const float *__restrict__ H, int ldh, const float *__restrict__ e,
+    const int32_t *__restrict__ in_ptr, const int32_t *__restrict__ in_eid,
+    const int32_t *__restrict__ in_nbr, const int32_t *__restrict__ out_ptr,
+    const int32_t *__restrict__ out_eid, const int32_t *__restrict__ out_nbr,
+    const float *__restrict__ W3, const float *__restrict__ b3, const float *__restrict__ W4,
+    const float *__restrict__ b4, const float *__restrict__ W1, const float *__restrict__ b1,
+    float *__restrict__ Hn, int ldhn, float *__restrict__ PQ, int64_t n_hits)
+{
+    constexpr int C = Shape<F, D>::C;
+    constexpr int LDH = Shape<F, D>::LDH;
+    const int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (n >= n_hits) return;
+
+    float M[3 * LDH];   // [mi | mo | h], each padded to LDH
+#pragma unroll
+    for (int k = 0; k < 2 * LDH; ++k) M[k] = 0.0f;
+    {
+        const float4 *hp = reinterpret_cast<const float4 *>(H + n * ldh);
+#pragma unroll
+        for (int v = 0; v < LDH / 4; ++v) {
+            const float4 a = hp[v];
+            M[2 * LDH + 4 * v] = a.x;
+            M[2 * LDH + 4 * v + 1] = a.y;
+            M[2 * LDH + 4 * v + 2] = a.z;
+            M[2 * LDH + 4 * v + 3] = a.w;
+        }
+    }
+    // segments ending here: weight e[j], features of the start hit      (model.py:117-118)
+    for (int k = in_ptr[n], k1 = in_ptr[n + 1]; k < k1; ++k) {
+        const float w = e[in_eid[k]];
+        const float4 *hp = reinterpret_cast<const float4 *>(H + (int64_t)in_nbr[k] * ldh);
+#pragma unroll
+        for (int v = 0; v < LDH / 4; ++v) {
+            const float4 a = hp[v];
+            M[4 * v] = fmaf(w, a.x, M[4 * v]);
+            M[4 * v + 1] = fmaf(w, a.y, M[4 * v + 1]);
+            M[4 * v + 2] = fmaf(w, a.z, M[4 * v + 2]);
+            M[4 * v + 3] = fmaf(w, a.w, M[4 * v + 3]);
+        }
+    }
+    // segments starting here: weight e[j], features of the end hit      (model.py:116,119)
+    for (int k = out_ptr[n], k1 = out_ptr[n + 1]; k < k1; ++k) {
+        const float w = e[out_eid[k]];
+        const float4 *hp = reinterpret_cast<const float4 *>(H + (int64_t)out_nbr[k] * ldh);
+#pragma unroll
+        for (int v = 0; v < LDH / 4; ++v) {
+            const float4 a = hp[v];
+            M[LDH + 4 * v] = fmaf(w, a.x, M[LDH + 4 * v]);
+            M[LDH + 4 * v + 1] = fmaf(w, a.y, M[LDH + 4 * v + 1]);
+            M[LDH + 4 * v + 2] = fmaf(w, a.z, M[LDH + 4 * v + 2]);
+            M[LDH + 4 * v + 3] = fmaf(w, a.w, M[LDH + 4 * v + 3]);
+        }
+    }
+    // MLP on M = [mi | mo | h]                                          (model.py:120,94-98)
+    float q[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        float acc = b3[d];
+#pragma unroll
+        for (int k = 0; k < C; ++k) acc = fmaf(W3[d * 3 * C + k], M[k], acc);
+#pragma unroll
+        for (int k = 0; k < C; ++k) acc = fmaf(W3[d * 3 * C + C + k], M[LDH + k], acc);
+#pragma unroll
+        for (int k = 0; k < C; ++k) acc = fmaf(W3[d * 3 * C + 2 * C + k], M[2 * LDH + k], acc);
+        q[d] = tanh_f(acc);
+    }
+    float hn[LDH];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        float acc = b4[d];
+#pragma unroll
+        for (int k = 0; k < D; ++k) acc = fmaf(W4[d * D + k], q[k], acc);
+        hn[d] = tanh_f(acc);
+    }
+#pragma unroll
+    for (int k = D; k < LDH; ++k) hn[k] = M[2 * LDH + k];   // skip concat of X (model.py:154)
+    store_row4<LDH / 4>(Hn + n * ldhn, hn);
+    if (PQ) store_pq<F, D>(hn, W1, b1, PQ + n * 2 * D);
+}
+
+// H (padded rows) -> unpadded [n_hits, C] trace rows (parity tests only).
+__global__ __launch_bounds__(kBlock) void k_unpad(const float *__restrict__ H, int ldh, int C,
+                                                  float *__restrict__ out, int64_t total)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= total) return;
+    out[i] = H[(i / C) * ldh + (i % C)];
+}
+
+// ---------------------------------------------------------------------------------------------
+// shape dispatch
+// ---------------------------------------------------------------------------------------------
+#define GNN_FOR_EACH_SHAPE(X_) \
+    X_(2, 4) X_(2, 8) X_(2, 16) X_(3, 4) X_(3, 8) X_(3, 16) X_(11, 4) X_(11, 8) X_(11, 16)
+
+template <int F, int D>
+int run_input(const float *X, const float *Win, const float *bin, const float *W1,
+              const float *b1, float *H, int ldh, float *PQ, int64_t n, hipStream_t s)
+{
+    if (n > 0)
+        GNN_LAUNCH("k_input", (k_input<F, D>), grid_for(n), kBlock, s, X, Win, bin, W1, b1, H, ldh,
+                   PQ, n);
+    return 0;
+}
+
+template <int F, int D>
+int run_pq(const float *H, int ldh, const float *W1, const float *b1, float *PQ, int64_t n,
+           hipStream_t s)
+{
+    if (n > 0) GNN_LAUNCH("k_pq", (k_pq<F, D>), grid_for(n), kBlock, s, H, ldh, W1, b1, PQ, n);
+    return 0;
+}
+
+template <int D>
+int run_edge(const int32_t *src, const int32_t *dst, const float *PQ, const float *b1,
+             const float *W2, const float *b2, float *e, int64_t n_seg, hipStream_t s)
+{
+    if (n_seg > 0)
+        GNN_LAUNCH("k_edge", (k_edge<D>), grid_for(n_seg), kBlock, s, src, dst, PQ, b1, W2, b2, e,
+                   n_seg);
+    return 0;
+}
+
+template <int F, int D>
+int run_node(const float *H, int ldh, const float *e, const gnn_graph_t *g, const float *W3,
+             const float *b3, const float *W4, const float *b4, const float *W1, const float *b1,
+             float *Hn, int ldhn, float *PQ, hipStream_t s)
+{
+    if (g->n_hits > 0)
+        GNN_LAUNCH("k_node", (k_node<F, D>), grid_for(g->n_hits), kBlock, s, H, ldh, e, g->in_ptr,
+                   g->in_eid, g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, W3, b3, W4, b4, W1, b1,
+                   Hn, ldhn, PQ, g->n_hits);
+    return 0;
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Workspace {
+    float *Ha, *Hb, *PQ, *e;
+    size_t bytes;
+};
+
+Workspace carve(void *base, int64_t n_hits, int64_t n_seg, int ldh, int D)
+{
+    Workspace w;
+    size_t off = 0;
+    char *b = static_cast<char *>(base);
+    const size_t hbytes = align256((size_t)n_hits * ldh * sizeof(float));
+    w.Ha = reinterpret_cast<float *>(b + off); off += hbytes;
+    w.Hb = reinterpret_cast<float *>(b + off); off += hbytes;
+    w.PQ = reinterpret_cast<float *>(b + off); off += align256((size_t)n_hits * 2 * D * sizeof(float));
+    w.e = reinterpret_cast<float *>(b + off);  off += align256((size_t)n_seg * sizeof(float));
+    w.bytes = off;
+    return w;
+}
+
+template <int F, int D>
+int forward_impl(const gnn_graph_t *g, const gnn_params_t *p, int n_iters, float *e_out,
+                 float *e_trace, float *H_trace, void *ws, hipStream_t s)
+{
+    constexpr int C = Shape<F, D>::C;
+    constexpr int LDH = Shape<F, D>::LDH;
+    const int64_t N = g->n_hits, E = g->n_segments;
+    Workspace w = carve(ws, N, E, LDH, D);
+    float *H = w.Ha, *Hn = w.Hb;
+    int rc = run_input<F, D>(g->X, p->Win, p->bin, p->W1, p->b1, H, LDH, w.PQ, N, s);
+    if (rc) return rc;
+    for (int t = 0; t <= n_iters; ++t) {
+        if (H_trace && N > 0)
+            GNN_LAUNCH("k_unpad", k_unpad, grid_for(N * C), kBlock, s, H, LDH, C,
+                       H_trace + (size_t)t * N * C, N * C);
+        const bool last = (t == n_iters);
+        float *e_t = e_trace ? e_trace + (size_t)t * E : (last ? e_out : w.e);
+        rc = run_edge<D>(g->src, g->dst, w.PQ, p->b1, p->W2, p->b2, e_t, E, s);
+        if (rc) return rc;
+        if (last) {
+            if (e_trace && E > 0) {
+                hipError_t err = hipMemcpyAsync(e_out, e_t, (size_t)E * sizeof(float),
+                                                hipMemcpyDeviceToDevice, s);
+                if (err != hipSuccess) return fail(-(int)err, "copy of final scores failed");
+            }
+            break;
+        }
+        rc = run_node<F, D>(H, LDH, e_t, g, p->W3, p->b3, p->W4, p->b4, p->W1, p->b1, Hn, LDH,
+                            w.PQ, s);
+        if (rc) return rc;
+        float *tmp = H; H = Hn; Hn = tmp;
+    }
+    return 0;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int gnn_abi_version(void) { return GNN_ABI_VERSION; }
+
+const char *gnn_last_error(void) { return g_err; }
+
+int gnn_shape_supported(int32_t F, int32_t D)
+{
+#define X_(F_, D_) if (F == F_ && D == D_) return 1;
+    GNN_FOR_EACH_SHAPE(X_)
+#undef X_
+    return 0;
+}
+
+int32_t gnn_h_stride(int32_t F, int32_t D)
+{
+    return gnn_shape_supported(F, D) ? ((F + D + 3) & ~3) : 0;
+}
+
+int gnn_input_fwd(const float *X, const float *Win, const float *bin, float *H, int64_t n_hits,
+                  int32_t F, int32_t D, int32_t ldh, void *stream)
+{
+    if (!X || !Win || !bin || !H || n_hits < 0) return fail(GNN_ERR_BADARG, "gnn_input_fwd: bad argument");
+    if (ldh < ((F + D + 3) & ~3) || (ldh & 3)) return fail(GNN_ERR_BADARG, "gnn_input_fwd: ldh must be a multiple of 4 >= C");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define X_(F_, D_) if (F == F_ && D == D_) return run_input<F_, D_>(X, Win, bin, nullptr, nullptr, H, ldh, nullptr, n_hits, s);
+    GNN_FOR_EACH_SHAPE(X_)
+#undef X_
+    return fail(GNN_ERR_UNSUPPORTED, "no kernel for input_dim=%d hidden_dim=%d", F, D);
+}
+
+int gnn_edge_fwd(const float *H, int32_t ldh, const int32_t *src, const int32_t *dst,
+                 const float *W1, const float *b1, const float *W2, const float *b2, float *e,
+                 float *pq_ws, int64_t n_hits, int64_t n_segments, int32_t F, int32_t D,
+                 void *stream)
+{
+    if (!H || !src || !dst || !W1 || !b1 || !W2 || !b2 || !e || !pq_ws || n_hits < 0 || n_segments < 0)
+        return fail(GNN_ERR_BADARG, "gnn_edge_fwd: bad argument");
+    if (ldh < F + D) return fail(GNN_ERR_BADARG, "gnn_edge_fwd: ldh < C");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define X_(F_, D_)                                                              \
+    if (F == F_ && D == D_) {                                                   \
+        int rc = run_pq<F_, D_>(H, ldh, W1, b1, pq_ws, n_hits, s);              \
+        if (rc) return rc;                                                      \
+        return run_edge<D_>(src, dst, pq_ws, b1, W2, b2, e, n_segments, s);     \
+    }
+    GNN_FOR_EACH_SHAPE(X_)
+#undef X_
+    return fail(GNN_ERR_UNSUPPORTED, "no kernel for input_dim=%d hidden_dim=%d", F, D);
+}
+
+int gnn_node_fwd(const float *H, int32_t ldh, const float *e, const gnn_graph_t *g,
+                 const float *W3, const float *b3, const float *W4, const float *b4, float *Hnext,
+                 int32_t F, int32_t D, void *stream)
+{
+    if (!H || !e || !g || !W3 || !b3 || !W4 || !b4 || !Hnext || g->n_hits < 0)
+        return fail(GNN_ERR_BADARG, "gnn_node_fwd: bad argument");
+    if (g->n_hits > 0 && (!g->in_ptr || !g->out_ptr)) return fail(GNN_ERR_BADARG, "gnn_node_fwd: CSR missing");
+    if (ldh < ((F + D + 3) & ~3) || (ldh & 3)) return fail(GNN_ERR_BADARG, "gnn_node_fwd: ldh must be a multiple of 4 >= C");
+    if (Hnext == H) return fail(GNN_ERR_BADARG, "gnn_node_fwd: Hnext must not alias H");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define X_(F_, D_) if (F == F_ && D == D_) return run_node<F_, D_>(H, ldh, e, g, W3, b3, W4, b4, nullptr, nullptr, Hnext, ldh, nullptr, s);
+    GNN_FOR_EACH_SHAPE(X_)
+#undef X_
+    return fail(GNN_ERR_UNSUPPORTED, "no kernel for input_dim=%d hidden_dim=%d", F, D);
+}
+
+size_t gnn_forward_workspace_bytes(int64_t n_hits, int64_t n_segments, int32_t F, int32_t D)
+{
+    if (n_hits < 0 || n_segments < 0 || F <= 0 || D <= 0) return 0;
+    return carve(nullptr, n_hits, n_segments, (F + D + 3) & ~3, D).bytes + 256;
+}
+
+int gnn_segclf_forward(const gnn_graph_t *g, const gnn_params_t *p, int32_t n_iters, float *e_out,
+                       float *e_trace, float *H_trace, void *workspace, size_t workspace_bytes,
+                       void *stream)
+{
+    if (!g || !p || n_iters < 0 || g->n_hits < 0 || g->n_segments < 0)
+        return fail(GNN_ERR_BADARG, "gnn_segclf_forward: bad argument");
+    if (g->n_segments > 0 && (!e_out || !g->src || !g->dst))
+        return fail(GNN_ERR_BADARG, "gnn_segclf_forward: segment arrays missing");
+    if (g->n_hits > 0 && (!g->X || !g->in_ptr || !g->out_ptr))
+        return fail(GNN_ERR_BADARG, "gnn_segclf_forward: hit arrays missing");
+    if (!p->Win || !p->bin || !p->W1 || !p->b1 || !p->W2 || !p->b2 || !p->W3 || !p->b3 || !p->W4 || !p->b4)
+        return fail(GNN_ERR_BADARG, "gnn_segclf_forward: weight pointer missing");
+    if (!gnn_shape_supported(p->F, p->D))
+        return fail(GNN_ERR_UNSUPPORTED, "no kernel for input_dim=%d hidden_dim=%d", p->F, p->D);
+    if (!workspace || workspace_bytes < gnn_forward_workspace_bytes(g->n_hits, g->n_segments, p->F, p->D))
+        return fail(GNN_ERR_WORKSPACE, "workspace too small: need %zu bytes",
+                    gnn_forward_workspace_bytes(g->n_hits, g->n_segments, p->F, p->D));
+    // 256-byte align the carve base
+    void *ws = reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define X_(F_, D_) if (p->F == F_ && p->D == D_) return forward_impl<F_, D_>(g, p, n_iters, e_out, e_trace, H_trace, ws, s);
+    GNN_FOR_EACH_SHAPE(X_)
+#undef X_
+    return fail(GNN_ERR_UNSUPPORTED, "unreachable");
+}
+
+int gnn_profile_begin(int32_t capacity)
+{
+    if (capacity <= 0) return fail(GNN_ERR_BADARG, "gnn_profile_begin: capacity must be positive");
+    for (hipEvent_t ev : g_prof.ev) (void)hipEventDestroy(ev);
+    g_prof.ev.assign(2 * (size_t)capacity, nullptr);
+    g_prof.name.assign((size_t)capacity, nullptr);
+    for (auto &ev : g_prof.ev) {
+        hipError_t err = hipEventCreate(&ev);
+        if (err != hipSuccess) return fail(-(int)err, "hipEventCreate failed");
+    }
+    g_prof.cap = capacity;
+    g_prof.n = 0;
+    g_prof.on = true;
+    return 0;
+}
+
+int gnn_profile_end(const char **names, float *ms, int32_t capacity_out)
+{
+    g_prof.on = false;
+    const int n = g_prof.n;
+    for (int i = 0; i < n; ++i) {
+        hipError_t err = hipEventSynchronize(g_prof.ev[2 * i + 1]);
+        if (err != hipSuccess) return fail(-(int)err, "hipEventSynchronize failed");
+        if (i < capacity_out) {
+            float t = 0.0f;
+            (void)hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]);
+            if (ms) ms[i] = t;
+            if (names) names[i] = g_prof.name[i];
+        }
+    }
+    for (hipEvent_t ev : g_prof.ev) (void)hipEventDestroy(ev);
+    g_prof.ev.clear();
+    g_prof.n = 0;
+    g_prof.cap = 0;
+    return n;
+}
+
+}  // extern "C"

@@ -149,26 +149,26 @@ class HitGraphBatch:
         an all-zero column is a padded segment (gnn/trainSegmentClassifier.py:83-93)
         and becomes src = dst = -1.  O(B*N*E) reads: kept off the benchmarked path.
         """
-        Xn = X.detach().cpu().numpy() if torch.is_tensor(X) else np.asarray(X)
-        Rin = Ri.detach().cpu().numpy() if torch.is_tensor(Ri) else np.asarray(Ri)
-        Ron = Ro.detach().cpu().numpy() if torch.is_tensor(Ro) else np.asarray(Ro)
-        if Xn.ndim == 2:
-            Xn, Rin, Ron = Xn[None], Rin[None], Ron[None]
-        B, N, _ = Xn.shape
-        E = Rin.shape[2]
-        if Rin.shape != (B, N, E) or Ron.shape != (B, N, E):
+        as_t = lambda a: a.detach() if torch.is_tensor(a) else torch.from_numpy(np.asarray(a))
+        Xt, Rit, Rot = as_t(X), as_t(Ri), as_t(Ro)
+        if Xt.dim() == 2:
+            Xt, Rit, Rot = Xt[None], Rit[None], Rot[None]
+        B, N, _ = Xt.shape
+        E = Rit.shape[2]
+        if tuple(Rit.shape) != (B, N, E) or tuple(Rot.shape) != (B, N, E):
             raise ValueError("expected X [B,N,F], Ri [B,N,E], Ro [B,N,E]")
+        Xn = Xt.cpu().numpy()
         off = (np.arange(B, dtype=np.int64) * N)[:, None]
 
-        def ends(R):
+        def ends(R):   # the O(B*N*E) reduction runs where the matrix lives; [B,E] comes back
             nz = R != 0
-            cnt = nz.sum(axis=1)
+            cnt = nz.sum(dim=1).cpu().numpy()
             if np.any(cnt > 1):
                 raise ValueError("incidence matrix column with more than one hit")
-            idx = nz.argmax(axis=1).astype(np.int64) + off
+            idx = nz.to(torch.uint8).argmax(dim=1).cpu().numpy().astype(np.int64) + off
             return np.where(cnt == 1, idx, -1).reshape(-1)
 
-        dst, src = ends(Rin), ends(Ron)
+        dst, src = ends(Rit), ends(Rot)
         if np.any((src < 0) != (dst < 0)):
             raise ValueError("a segment column must be set in both Ri and Ro or in neither")
         yy = None if y is None else (y.detach().cpu().numpy() if torch.is_tensor(y) else

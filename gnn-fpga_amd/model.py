@@ -1,0 +1,185 @@
+"""Drop-in module tree for the reference's segment classifier (reference gnn/model.py).
+
+Same class names, constructor signatures, sub-module attribute tree and the ten
+state_dict keys as the reference, so `gnn/estimator.py` can hold
+it unchanged: `model.edge_network.network[i].weight`, `.mask_flag`, `.set_mask()`,
+`.cuda()`, `.train()/.eval()`, `state_dict()/load_state_dict()`.
+
+What differs is where the arithmetic runs: `forward` hands device pointers to
+libgnn_hip.so (`_lib.py`), which executes the message-passing loop as HIP kernels
+in index form.  There is no CPU or eager fallback: CPU tensors raise.
+
+Accepted inputs
+  * the reference's `[X, Ri, Ro]` with dense float one-hot incidence matrices
+    [B,N,F], [B,N,E], [B,N,E] (gnn/model.py:142) - converted once per call with
+    `HitGraphBatch.from_dense`; returns scores [B, E] like the reference;
+  * a `HitGraphBatch` (index form, already on the device) - the fast path; returns
+    scores [E_total].
+
+Like gnn/model_maskedlinear.py:110-112 (and unlike gnn/model.py:100, which raises a
+TypeError), `masks_n=None` means "no mask".
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F_
+
+from . import _lib
+from .hitgraph import HitGraphBatch
+
+
+class MaskedLinear(nn.Linear):
+    """nn.Linear whose weight is multiplied by a fixed 0/1 mask (reference gnn/model.py:14-33)."""
+
+    def __init__(self, in_features, out_features, bias=True):
+        super(MaskedLinear, self).__init__(in_features, out_features, bias)
+        self.mask_flag = False
+        self.mask = None
+
+    def set_mask(self, mask):
+        # same side effects as reference gnn/model.py:19-22: keep the mask as a plain
+        # attribute (not a buffer: it is absent from state_dict) and zero the masked weights
+        self.mask = mask
+        self.weight.data = self.weight.data * self.mask.data.to(self.weight.device)
+        self.mask_flag = True
+
+    def get_mask(self):
+        print(self.mask_flag)
+        return self.mask
+
+    def effective_weight(self):
+        """W * mask when a mask is set (gnn/model.py:29-31), else W."""
+        if self.mask_flag:
+            return self.weight * self.mask.to(self.weight.device)
+        return self.weight
+
+    def forward(self, x):
+        return F_.linear(x, self.effective_weight(), self.bias)
+
+
+def _as_batch(X, Ri, Ro):
+    if isinstance(Ri, HitGraphBatch):
+        return Ri
+    return HitGraphBatch.from_dense(X, Ri, Ro).to(X.device)
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+class EdgeNetwork(nn.Module):
+    """Scores every segment from the features of its two hits (reference gnn/model.py:36-81)."""
+
+    def __init__(self, input_dim, hidden_dim=8, hidden_activation=nn.Tanh, mask=None):
+        super(EdgeNetwork, self).__init__()
+        _require_tanh(hidden_activation)
+        self.network = nn.Sequential(
+            MaskedLinear(input_dim * 2, hidden_dim),
+            hidden_activation(),
+            MaskedLinear(hidden_dim, 1),
+            nn.Sigmoid())
+        self.mask = mask
+        if self.mask is not None:
+            self.network[0].set_mask(self.mask[0])
+            self.network[2].set_mask(self.mask[1])
+        self._C, self._D = input_dim, hidden_dim
+
+    def weights(self):
+        n = self.network
+        return [_f32c(n[0].effective_weight()), _f32c(n[0].bias),
+                _f32c(n[2].effective_weight()), _f32c(n[2].bias)]
+
+    def forward(self, X, Ri, Ro=None):
+        """X = hit features H [B,N,C]; (Ri, Ro) dense, or Ri a HitGraphBatch.  -> e [B,E]."""
+        batch = _as_batch(X, Ri, Ro)
+        H = _f32c(X).reshape(-1, X.shape[-1])
+        D = self._D
+        e = _lib.edge_fwd(H, batch.src, batch.dst, *self.weights(), self._C - D, D)
+        return e.view(batch.dense_shape[0], batch.dense_shape[2]) if batch.dense_shape else e
+
+
+class NodeNetwork(nn.Module):
+    """New hit features from score-weighted neighbour sums (reference gnn/model.py:84-125)."""
+
+    def __init__(self, input_dim, output_dim, hidden_activation=nn.Tanh, mask=None):
+        super(NodeNetwork, self).__init__()
+        _require_tanh(hidden_activation)
+        self.network = nn.Sequential(
+            MaskedLinear(input_dim * 3, output_dim),
+            hidden_activation(),
+            MaskedLinear(output_dim, output_dim),
+            hidden_activation())
+        self.mask = mask
+        if self.mask is not None:       # gnn/model_maskedlinear.py:110-112
+            self.network[0].set_mask(self.mask[0])
+            self.network[2].set_mask(self.mask[1])
+        self._C, self._D = input_dim, output_dim
+
+    def weights(self):
+        n = self.network
+        return [_f32c(n[0].effective_weight()), _f32c(n[0].bias),
+                _f32c(n[2].effective_weight()), _f32c(n[2].bias)]
+
+    def forward(self, X, e, Ri, Ro=None):
+        """X = H [B,N,C], e [B,E] -> H' [B,N,D] (without the skip concat, like the reference)."""
+        batch = _as_batch(X, Ri, Ro)
+        C, D = self._C, self._D
+        ldh = _lib.h_stride(C - D, D)
+        H2 = _f32c(X).reshape(-1, C)
+        Hp = torch.zeros((H2.shape[0], ldh), dtype=torch.float32, device=H2.device)
+        Hp[:, :C] = H2
+        Hn = _lib.node_fwd(Hp, _f32c(e).reshape(-1), batch, *self.weights(), C - D, D)
+        return Hn[:, :D].reshape(*X.shape[:-1], D)
+
+
+def _require_tanh(act):
+    if act is not nn.Tanh:
+        raise NotImplementedError(
+            "the HIP kernels implement hidden_activation=nn.Tanh only (every caller in the "
+            "reference uses Tanh); got %r" % (act,))
+
+
+class SegmentClassifier(nn.Module):
+    """Segment classification GNN (reference gnn/model.py:127-156), HIP forward."""
+
+    def __init__(self, input_dim=2, hidden_dim=8, n_iters=3, hidden_activation=nn.Tanh,
+                 masks_e=None, masks_n=None):
+        super(SegmentClassifier, self).__init__()
+        self.n_iters = n_iters
+        self.input_dim, self.hidden_dim = input_dim, hidden_dim
+        _require_tanh(hidden_activation)
+        self.input_network = nn.Sequential(
+            nn.Linear(input_dim, hidden_dim),
+            hidden_activation())
+        self.edge_network = EdgeNetwork(input_dim + hidden_dim, hidden_dim,
+                                        hidden_activation, masks_e)
+        self.node_network = NodeNetwork(input_dim + hidden_dim, hidden_dim,
+                                        hidden_activation, masks_n)
+        self._workspace = None
+
+    def effective_weights(self):
+        """The ten tensors the kernels consume, in state_dict order, masks applied."""
+        lin = self.input_network[0]
+        return ([_f32c(lin.weight), _f32c(lin.bias)] + self.edge_network.weights() +
+                self.node_network.weights())
+
+    def forward(self, inputs, trace=False):
+        """Apply forward pass of the model: inputs = [X, Ri, Ro] or a HitGraphBatch."""
+        if isinstance(inputs, HitGraphBatch):
+            batch = inputs
+        else:
+            X, Ri, Ro = inputs
+            batch = _as_batch(X, Ri, Ro)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from .autograd import segclf_apply   # backward kernels live there
+            return segclf_apply(self, batch)
+        F, D = self.input_dim, self.hidden_dim
+        need = _lib.workspace_bytes(batch.n_hits, batch.n_segments, F, D)
+        if (self._workspace is None or self._workspace.numel() < need or
+                self._workspace.device != batch.X.device):
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=batch.X.device)
+        res = _lib.segclf_forward(batch, self.effective_weights(), F, D, self.n_iters,
+                                  workspace=self._workspace, trace=trace)
+        e = res[0] if trace else res
+        if batch.dense_shape:
+            e = e.view(batch.dense_shape[0], batch.dense_shape[2])
+        return (e, res[1], res[2]) if trace else e

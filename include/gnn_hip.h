@@ -1,0 +1,112 @@
+/* gnn_hip.h - C ABI of libgnn_hip.so: the SegmentClassifier message-passing forward
+ * of jmduarte/gnn-fpga (gnn/model.py) as hand-written HIP kernels for gfx950 (MI355X).
+ *
+ * The reference has no native boundary: its "FFI" for this path is the set of ATen calls
+ * in gnn/model.py.  Each entry point below names the reference interface it replaces.
+ * A maintainer binds it with ctypes; no C++ or torch types cross.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into caller-owned memory (e.g. tensor.data_ptr());
+ *     the library never allocates, frees or retains caller buffers;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     all work is asynchronous on it, no implicit synchronisation;
+ *   - return value 0 = success; negative = -(hipError_t) or one of GNN_ERR_*;
+ *     gnn_last_error() returns a thread-local message for the last failing call;
+ *   - matrices are row-major float32; weights use torch's nn.Linear layout [out, in];
+ *   - F = input_dim, D = hidden_dim, C = D + F; hit-feature rows H[n] = [H'(D) | X(F) | 0-pad]
+ *     with row stride ldh = gnn_h_stride(F, D) floats (C rounded up to a multiple of 4);
+ *   - a padded segment has src = dst = -1 (the all-zero Ri/Ro column of
+ *     gnn/trainSegmentClassifier.py:83-93): it scores sigmoid(W2 tanh(b1) + b2) and
+ *     contributes nothing to any hit.
+ */
+#ifndef GNN_HIP_H
+#define GNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNN_ABI_VERSION 1
+
+#define GNN_ERR_UNSUPPORTED (-10001) /* (F, D) has no kernel instantiation            */
+#define GNN_ERR_BADARG      (-10002) /* null pointer, negative size, bad stride ...   */
+#define GNN_ERR_WORKSPACE   (-10003) /* workspace smaller than gnn_forward_workspace_bytes */
+
+/* Effective weights (mask already applied: W*mask, gnn/model.py:28-33), device pointers.
+ * Shapes follow the reference state_dict. */
+typedef struct gnn_params {
+    const float *Win, *bin; /* input_network.0           [D,F]  [D]   gnn/model.py:132-134 */
+    const float *W1, *b1;   /* edge_network.network.0    [D,2C] [D]   gnn/model.py:45-46   */
+    const float *W2, *b2;   /* edge_network.network.2    [1,D]  [1]   gnn/model.py:48      */
+    const float *W3, *b3;   /* node_network.network.0    [D,3C] [D]   gnn/model.py:94-95   */
+    const float *W4, *b4;   /* node_network.network.2    [D,D]  [D]   gnn/model.py:97      */
+    int32_t F, D;
+} gnn_params_t;
+
+/* One block-diagonal batch of hit graphs in index form (replaces the dense Ri/Ro of
+ * gnn/graph.py:28-35).  CSR arrays list, per hit, the segments ending (in_*) / starting
+ * (out_*) there in ascending segment id, and the hit at the other end of each. */
+typedef struct gnn_graph {
+    const float *X;                            /* [n_hits, F]                              */
+    const int32_t *src, *dst;                  /* [n_segments]  start / end hit, -1 = pad  */
+    const int32_t *in_ptr, *in_eid, *in_nbr;   /* [n_hits+1], [n_valid], [n_valid] (=src[in_eid])  */
+    const int32_t *out_ptr, *out_eid, *out_nbr;/* [n_hits+1], [n_valid], [n_valid] (=dst[out_eid]) */
+    int64_t n_hits, n_segments;
+} gnn_graph_t;
+
+int gnn_abi_version(void);
+const char *gnn_last_error(void);
+
+/* 1 if kernels exist for this (input_dim, hidden_dim), else 0. */
+int gnn_shape_supported(int32_t F, int32_t D);
+/* Row stride (floats) of H for this shape; 0 if unsupported. */
+int32_t gnn_h_stride(int32_t F, int32_t D);
+
+/* input_network + skip concat: H[n] = [tanh(Win X[n] + bin) | X[n]].
+ * Replaces gnn/model.py:144,146 (nn.Linear + Tanh + torch.cat). */
+int gnn_input_fwd(const float *X, const float *Win, const float *bin, float *H,
+                  int64_t n_hits, int32_t F, int32_t D, int32_t ldh, void *stream);
+
+/* EdgeNetwork.forward: e[j] = sigmoid(W2 tanh(W1 [H[src j] | H[dst j]] + b1) + b2).
+ * Replaces gnn/model.py:69-81 (two bmm gathers, cat, MaskedLinear, Tanh, MaskedLinear, Sigmoid).
+ * pq_ws: scratch of n_hits * 2 * D floats (per-hit halves of the first layer). */
+int gnn_edge_fwd(const float *H, int32_t ldh, const int32_t *src, const int32_t *dst,
+                 const float *W1, const float *b1, const float *W2, const float *b2,
+                 float *e, float *pq_ws, int64_t n_hits, int64_t n_segments,
+                 int32_t F, int32_t D, void *stream);
+
+/* NodeNetwork.forward + the following skip concat:
+ *   mi[n] = sum_{j: dst j = n} e[j] H[src j],  mo[n] = sum_{j: src j = n} e[j] H[dst j],
+ *   Hnext[n] = [tanh(W4 tanh(W3 [mi|mo|H[n]] + b3) + b4) | X[n]]   (X[n] = H[n][D:D+F]).
+ * Replaces gnn/model.py:113-125 (four bmm, two broadcast multiplies, cat, 2x MaskedLinear+Tanh)
+ * and :154.  Sums run in ascending segment id (fixed order: bit-reproducible).
+ * Only X, in_*, out_* and n_hits of `g` are read.  Hnext must not alias H. */
+int gnn_node_fwd(const float *H, int32_t ldh, const float *e, const gnn_graph_t *g,
+                 const float *W3, const float *b3, const float *W4, const float *b4,
+                 float *Hnext, int32_t F, int32_t D, void *stream);
+
+/* Bytes of device scratch gnn_segclf_forward needs for this problem. */
+size_t gnn_forward_workspace_bytes(int64_t n_hits, int64_t n_segments, int32_t F, int32_t D);
+
+/* SegmentClassifier.forward (gnn/model.py:140-156): input network, n_iters x (edge pass,
+ * node pass), final edge pass.  e_out [n_segments] receives the scores.
+ * Optional traces for parity tests (NULL to skip): e_trace [(n_iters+1), n_segments],
+ * H_trace [(n_iters+1), n_hits, C] (unpadded rows). */
+int gnn_segclf_forward(const gnn_graph_t *g, const gnn_params_t *p, int32_t n_iters,
+                       float *e_out, float *e_trace, float *H_trace,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+/* Per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).
+ * gnn_profile_begin(capacity) arms recording of up to `capacity` kernel launches;
+ * gnn_profile_end synchronises the recorded events and returns the number of records,
+ * filling names[i] (static strings) and ms[i] for i < min(count, capacity_out). */
+int gnn_profile_begin(int32_t capacity);
+int gnn_profile_end(const char **names, float *ms, int32_t capacity_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNN_HIP_H */

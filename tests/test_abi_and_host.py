@@ -1,0 +1,144 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/gnn_hip.h
+declares; host logic (index-form batch, dense adapter, npz loader, module tree)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import Fixture
+from gnn_fpga_amd import HitGraphBatch, synth
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(REPO, "include", "gnn_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gnn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from gnn_fpga_amd import _lib
+    names = _declared_functions()
+    assert len(names) >= 10
+    assert sorted(_lib.SIGNATURES) == names          # binding covers the whole header
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), n
+    loaded = _lib.load()                              # no GPU needed for these calls
+    assert loaded.gnn_abi_version() == _lib.GNN_ABI_VERSION
+    assert loaded.gnn_shape_supported(3, 8) == 1
+    assert loaded.gnn_shape_supported(5, 7) == 0
+    assert loaded.gnn_h_stride(3, 8) == 12
+    assert loaded.gnn_forward_workspace_bytes(10, 20, 3, 8) > 0
+
+
+def test_no_cpu_fallback_in_product():
+    """The product path must not import the oracle or run on CPU tensors."""
+    pkg = os.path.join(REPO, "gnn-fpga_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "import oracle" not in src and "from oracle" not in src, fn
+    from gnn_fpga_amd.model import SegmentClassifier
+    m = SegmentClassifier(input_dim=3, hidden_dim=8, n_iters=1).eval()
+    g = synth.layered_graph(30, 50, 3, seed=0)
+    with torch.no_grad(), pytest.raises(RuntimeError):
+        m(HitGraphBatch.from_graphs([g]))
+
+
+def test_module_tree_matches_reference_state_dict():
+    from gnn_fpga_amd.model import SegmentClassifier
+    fx = Fixture("sector_s0")
+    m = SegmentClassifier(input_dim=3, hidden_dim=8, n_iters=4)
+    assert list(m.state_dict().keys()) == list(fx.params.keys())
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == fx.params[k].shape
+    assert sum(p.numel() for p in m.parameters()) == 569
+    assert list(m.named_buffers()) == []
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in fx.params.items()})
+    # what gnn/estimator.py:54-55 iterates
+    assert len([l.weight for l in m.node_network.network if hasattr(l, "weight")]) == 2
+    assert len([l.weight for l in m.edge_network.network if hasattr(l, "weight")]) == 2
+
+
+def test_masked_linear_semantics():
+    from gnn_fpga_amd.model import MaskedLinear
+    torch.manual_seed(0)
+    l = MaskedLinear(6, 4)
+    assert l.mask_flag is False
+    w0 = l.weight.detach().clone()
+    mask = (torch.rand(4, 6) < 0.5).float()
+    l.set_mask(mask)
+    assert l.mask_flag is True
+    assert torch.equal(l.weight.detach(), w0 * mask)          # gnn/model.py:21
+    x = torch.randn(3, 6)
+    assert torch.allclose(l(x), torch.nn.functional.linear(x, w0 * mask, l.bias))
+    assert "mask" not in l.state_dict()
+
+
+def test_csr_layout_and_on_disk_order():
+    g = synth.layered_graph(200, 900, 3, seed=4)
+    b = HitGraphBatch.from_graphs([g])
+    in_ptr, in_eid, in_nbr = b.in_ptr.numpy(), b.in_eid.numpy(), b.in_nbr.numpy()
+    out_ptr, out_eid, out_nbr = b.out_ptr.numpy(), b.out_eid.numpy(), b.out_nbr.numpy()
+    for n in range(200):
+        seg = in_eid[in_ptr[n]:in_ptr[n + 1]]
+        assert np.all(g.dst[seg] == n) and np.all(np.diff(seg) > 0)
+        assert np.all(in_nbr[in_ptr[n]:in_ptr[n + 1]] == g.src[seg])
+        seg = out_eid[out_ptr[n]:out_ptr[n + 1]]
+        assert np.all(g.src[seg] == n) and np.all(np.diff(seg) > 0)
+        assert np.all(out_nbr[out_ptr[n]:out_ptr[n + 1]] == g.dst[seg])
+    # the reference's on-disk SparseGraph arrays (nonzero() of the dense matrices,
+    # gnn/graph.py:23-26) are this CSR order already
+    X, Ri, Ro = synth.to_dense(g)
+    Ri_rows, Ri_cols = Ri.nonzero()
+    Ro_rows, Ro_cols = Ro.nonzero()
+    assert np.array_equal(Ri_cols, in_eid) and np.array_equal(Ro_cols, out_eid)
+    b2 = HitGraphBatch.from_sparse_arrays(X, Ri_rows, Ri_cols, Ro_rows, Ro_cols)
+    for k in ("src", "dst", "in_ptr", "in_eid", "in_nbr", "out_ptr", "out_eid", "out_nbr"):
+        assert torch.equal(getattr(b, k), getattr(b2, k)), k
+
+
+def test_dense_round_trip_and_padding(tmp_path):
+    """Dense <-> index round trip (gnn/GraphConstructionDev_mu200.ipynb cell 41-44) and the
+    zero-padded batch of gnn/trainSegmentClassifier.py:66-95."""
+    gs = [synth.muon_graph(s) for s in range(3)]
+    Nmax = max(g.X.shape[0] for g in gs)
+    Emax = max(g.src.shape[0] for g in gs)
+    dense = [synth.to_dense(g, Nmax, Emax) for g in gs]
+    X, Ri, Ro = (torch.from_numpy(np.stack([d[i] for d in dense])) for i in range(3))
+    b = HitGraphBatch.from_dense(X, Ri, Ro)
+    assert b.dense_shape == (3, Nmax, Emax)
+    src = b.src.numpy().reshape(3, Emax)
+    dst = b.dst.numpy().reshape(3, Emax)
+    for i, g in enumerate(gs):
+        E = g.src.shape[0]
+        assert np.array_equal(src[i, :E], g.src + i * Nmax)
+        assert np.array_equal(dst[i, :E], g.dst + i * Nmax)
+        assert np.all(src[i, E:] == -1) and np.all(dst[i, E:] == -1)
+    assert int(b.in_ptr[-1]) == sum(g.src.shape[0] for g in gs)
+    # npz written with the reference's key schema (gnn/graph.py:179-181)
+    g = gs[0]
+    Xd, Rid, Rod = synth.to_dense(g)
+    rr, rc = Rid.nonzero()
+    orr, oc = Rod.nonzero()
+    fn = str(tmp_path / "event000000.npz")
+    np.savez(fn, X=Xd, Ri_rows=rr, Ri_cols=rc, Ro_rows=orr, Ro_cols=oc, y=g.y)
+    bl = HitGraphBatch.from_npz(fn)
+    assert np.array_equal(bl.src.numpy(), g.src) and np.array_equal(bl.dst.numpy(), g.dst)
+
+
+def test_bad_inputs_raise():
+    g = synth.layered_graph(30, 50, 3, seed=0)
+    with pytest.raises(ValueError):
+        HitGraphBatch(g.X, g.src + 100, g.dst)
+    with pytest.raises(ValueError):
+        HitGraphBatch(g.X, np.where(np.arange(50) == 0, -1, g.src), g.dst)
+    X, Ri, Ro = synth.to_dense(g)
+    Ri[0, 0] = Ri[1, 0] = 1
+    with pytest.raises(ValueError):
+        HitGraphBatch.from_dense(X, Ri, Ro)
