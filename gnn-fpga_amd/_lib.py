@@ -32,6 +32,11 @@ class GnnGraph(ctypes.Structure):
                [("n_hits", _i64), ("n_segments", _i64)]
 
 
+class GnnPlan(ctypes.Structure):
+    _fields_ = [(n, _f) for n in ("X", "src", "dst", "in_off", "in_nbr", "out_off", "out_nbr")] + \
+               [("n_hits", _i64), ("n_segments", _i64), ("n_slices", _i64)]
+
+
 # name -> (restype, argtypes); must list every function include/gnn_hip.h declares
 SIGNATURES = {
     "gnn_abi_version": (ctypes.c_int, []),
@@ -46,6 +51,10 @@ SIGNATURES = {
     "gnn_forward_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
     "gnn_segclf_forward": (ctypes.c_int, [ctypes.POINTER(GnnGraph), ctypes.POINTER(GnnParams),
                                           _i32, _f, _f, _f, _f, _sz, _f]),
+    "gnn_plan_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
+    "gnn_segclf_forward_plan": (ctypes.c_int, [ctypes.POINTER(GnnPlan), ctypes.POINTER(GnnParams),
+                                               _i32, _f, _f, _sz, _f]),
+    "gnn_plan_shape_supported": (ctypes.c_int, [_i32, _i32]),
     "gnn_profile_begin": (ctypes.c_int, [_i32]),
     "gnn_profile_end": (ctypes.c_int, [ctypes.POINTER(ctypes.c_char_p),
                                        ctypes.POINTER(ctypes.c_float), _i32]),
@@ -198,6 +207,41 @@ def segclf_forward(batch, weights, F, D, n_iters, out=None, workspace=None, trac
                                      Ht.data_ptr() if trace else None,
                                      workspace.data_ptr(), workspace.numel(), _stream()))
     return (out, et, Ht) if trace else out
+
+
+def plan_shape_supported(F, D):
+    return bool(load().gnn_plan_shape_supported(F, D))
+
+
+def plan_struct(plan):
+    g = GnnPlan()
+    g.X = _dev(plan.X, torch.float32, "plan.X")
+    for k in ("src", "dst", "in_off", "in_nbr", "out_off", "out_nbr"):
+        setattr(g, k, _dev(getattr(plan, k), torch.int32, "plan." + k))
+    g.n_hits, g.n_segments, g.n_slices = plan.n_hits, plan.n_segments, plan.n_slices
+    return g
+
+
+def plan_workspace_bytes(n_hits, n_segments, F, D):
+    return int(load().gnn_plan_workspace_bytes(n_hits, n_segments, F, D))
+
+
+def segclf_forward_plan(plan, weights, F, D, n_iters, out=None, workspace=None):
+    """Whole SegmentClassifier forward on a planned batch (fused pipeline) -> scores [E]."""
+    dev = plan.X.device
+    if not plan_shape_supported(F, D):
+        raise GnnHipError("no fused HIP kernel for input_dim=%d hidden_dim=%d" % (F, D))
+    need = plan_workspace_bytes(plan.n_hits, plan.n_segments, F, D)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+    if out is None:
+        out = torch.empty(plan.n_segments, dtype=torch.float32, device=dev)
+    g = plan_struct(plan)
+    p = params_struct(weights, F, D)
+    _check(load().gnn_segclf_forward_plan(ctypes.byref(g), ctypes.byref(p), n_iters,
+                                          _dev(out, torch.float32, "out"),
+                                          workspace.data_ptr(), workspace.numel(), _stream()))
+    return out
 
 
 class profile:

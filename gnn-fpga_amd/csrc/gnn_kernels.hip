@@ -18,19 +18,10 @@
 // Weights are tiny (569 floats at F=3, D=8): every weight address is wave-uniform, so the
 // compiler keeps them on the scalar path (s_load / SGPR operands) - no LDS, no VGPR copies.
 // No MFMA here by design: at D <= 16 the work is HBM/gather-bound integer-indexed traffic.
-#include <hip/hip_runtime.h>
+#include "common.h"
 
-#include <cstdarg>
-#include <cstdio>
-#include <vector>
+namespace gnn {
 
-#include "gnn_hip.h"
-
-namespace {
-
-// ---------------------------------------------------------------------------------------------
-// error + profiling plumbing
-// ---------------------------------------------------------------------------------------------
 thread_local char g_err[320] = "";
 
 int fail(int code, const char *fmt, ...)
@@ -51,14 +42,14 @@ struct Profiler {
 };
 Profiler g_prof;
 
-inline void prof_pre(const char *name, hipStream_t s)
+void prof_pre(const char *name, hipStream_t s)
 {
     if (g_prof.on && g_prof.n < g_prof.cap) {
         g_prof.name[g_prof.n] = name;
         (void)hipEventRecord(g_prof.ev[2 * g_prof.n], s);
     }
 }
-inline void prof_post(hipStream_t s)
+void prof_post(hipStream_t s)
 {
     if (g_prof.on && g_prof.n < g_prof.cap) {
         (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], s);
@@ -66,36 +57,10 @@ inline void prof_post(hipStream_t s)
     }
 }
 
-#define GNN_LAUNCH(NAME, KERNEL, GRID, BLOCK, STREAM, ...)                                   \
-    do {                                                                                     \
-        prof_pre(NAME, STREAM);                                                              \
-        hipLaunchKernelGGL(KERNEL, dim3(GRID), dim3(BLOCK), 0, STREAM, __VA_ARGS__);         \
-        prof_post(STREAM);                                                                   \
-        hipError_t err_ = hipGetLastError();                                                 \
-        if (err_ != hipSuccess)                                                              \
-            return fail(-(int)err_, "%s launch failed: %s", NAME, hipGetErrorString(err_));  \
-    } while (0)
+}  // namespace gnn
 
-constexpr int kBlock = 256;   // 4 waves of 64
-
-inline unsigned grid_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
-
-// ---------------------------------------------------------------------------------------------
-// device helpers
-// ---------------------------------------------------------------------------------------------
-// tanh(x) = 1 - 2 / (2^(2 log2(e) x) + 1): v_exp_f32 + v_rcp_f32 (1 ulp each), absolute error
-// ~1e-7 everywhere (the score tolerance is absolute, 1e-5).  Saturates correctly at +-inf.
-__device__ __forceinline__ float tanh_f(float x)
-{
-    float t = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
-}
-
-__device__ __forceinline__ float sigmoid_f(float x)
-{
-    float t = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);
-    return __builtin_amdgcn_rcpf(1.0f + t);
-}
+namespace {
+using namespace gnn;
 
 template <int F, int D>
 struct Shape {
@@ -357,8 +322,6 @@ int run_node(const float *H, int ldh, const float *e, const gnn_graph_t *g, cons
     return 0;
 }
 
-inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-
 struct Workspace {
     float *Ha, *Hb, *PQ, *e;
     size_t bytes;
@@ -414,6 +377,8 @@ int forward_impl(const gnn_graph_t *g, const gnn_params_t *p, int n_iters, float
 }
 
 }  // namespace
+
+using namespace gnn;
 
 // ---------------------------------------------------------------------------------------------
 // C ABI
@@ -515,6 +480,28 @@ int gnn_segclf_forward(const gnn_graph_t *g, const gnn_params_t *p, int32_t n_it
     GNN_FOR_EACH_SHAPE(X_)
 #undef X_
     return fail(GNN_ERR_UNSUPPORTED, "unreachable");
+}
+
+size_t gnn_plan_workspace_bytes(int64_t n_hits, int64_t n_segments, int32_t F, int32_t D)
+{
+    if (n_hits < 0 || n_segments < 0) return 0;
+    return sell_workspace_bytes(n_hits, n_segments, F, D);
+}
+
+int gnn_plan_shape_supported(int32_t F, int32_t D) { return sell_shape_supported(F, D); }
+
+int gnn_segclf_forward_plan(const gnn_plan_t *pl, const gnn_params_t *p, int32_t n_iters,
+                            float *e_out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!pl || !p || n_iters < 0 || pl->n_hits < 0 || pl->n_segments < 0 || pl->n_slices < 0)
+        return fail(GNN_ERR_BADARG, "gnn_segclf_forward_plan: bad argument");
+    if (pl->n_slices != (pl->n_hits + 15) / 16)
+        return fail(GNN_ERR_BADARG, "gnn_segclf_forward_plan: n_slices must be ceil(n_hits/16)");
+    if (!pl->X || !pl->in_off || !pl->out_off || (pl->n_segments > 0 && (!pl->src || !pl->dst || !e_out)))
+        return fail(GNN_ERR_BADARG, "gnn_segclf_forward_plan: plan array missing");
+    if (!p->Win || !p->bin || !p->W1 || !p->b1 || !p->W2 || !p->b2 || !p->W3 || !p->b3 || !p->W4 || !p->b4)
+        return fail(GNN_ERR_BADARG, "gnn_segclf_forward_plan: weight pointer missing");
+    return sell_forward(pl, p, n_iters, e_out, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
 int gnn_profile_begin(int32_t capacity)

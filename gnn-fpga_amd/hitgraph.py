@@ -75,6 +75,15 @@ class HitGraphBatch:
         self.in_ptr, self.in_eid, self.in_nbr = t(in_ptr), t(in_eid), t(in_nbr)
         self.out_ptr, self.out_eid, self.out_nbr = t(out_ptr), t(out_eid), t(out_nbr)
         self.y = None if y is None else t(np.ascontiguousarray(y, dtype=np.float32))
+        self.plan = None
+
+    def build_plan(self):
+        """Relabel + SELL-16 execution plan of the fused kernels (plan.py); built once, on the
+        host, from the host copy of the index arrays, then moved to this batch's device."""
+        if self.plan is None:
+            from .plan import SellPlan
+            self.plan = SellPlan(self).to(self.X.device)
+        return self.plan
 
     # -- constructors ------------------------------------------------------------------
     @classmethod
@@ -183,6 +192,8 @@ class HitGraphBatch:
             v = getattr(self, k)
             if v is not None:
                 setattr(self, k, v.to(device))
+        if self.plan is not None:
+            self.plan.to(device)
         return self
 
     def cuda(self, device=None):

@@ -155,6 +155,7 @@ class SegmentClassifier(nn.Module):
         self.node_network = NodeNetwork(input_dim + hidden_dim, hidden_dim,
                                         hidden_activation, masks_n)
         self._workspace = None
+        self.use_plan = True      # False: per-module CSR kernels instead of the fused pipeline
 
     def effective_weights(self):
         """The ten tensors the kernels consume, in state_dict order, masks applied."""
@@ -173,12 +174,21 @@ class SegmentClassifier(nn.Module):
             from .autograd import segclf_apply   # backward kernels live there
             return segclf_apply(self, batch)
         F, D = self.input_dim, self.hidden_dim
-        need = _lib.workspace_bytes(batch.n_hits, batch.n_segments, F, D)
+        if not batch.X.is_cuda:
+            raise _lib.GnnHipError("SegmentClassifier.forward needs tensors on a ROCm device; "
+                                   "there is no CPU path")
+        fused = not trace and self.use_plan and _lib.plan_shape_supported(F, D)
+        need = (_lib.plan_workspace_bytes if fused else _lib.workspace_bytes)(
+            batch.n_hits, batch.n_segments, F, D)
         if (self._workspace is None or self._workspace.numel() < need or
                 self._workspace.device != batch.X.device):
             self._workspace = torch.empty(need, dtype=torch.uint8, device=batch.X.device)
-        res = _lib.segclf_forward(batch, self.effective_weights(), F, D, self.n_iters,
-                                  workspace=self._workspace, trace=trace)
+        if fused:     # relabel + SELL-16 plan, fused iteration kernels (csrc/sell_pipeline.hip)
+            res = _lib.segclf_forward_plan(batch.build_plan(), self.effective_weights(), F, D,
+                                           self.n_iters, workspace=self._workspace)
+        else:         # CSR kernels, one per reference module (csrc/gnn_kernels.hip); traces
+            res = _lib.segclf_forward(batch, self.effective_weights(), F, D, self.n_iters,
+                                      workspace=self._workspace, trace=trace)
         e = res[0] if trace else res
         if batch.dense_shape:
             e = e.view(batch.dense_shape[0], batch.dense_shape[2])

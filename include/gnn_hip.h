@@ -57,6 +57,18 @@ typedef struct gnn_graph {
     int64_t n_hits, n_segments;
 } gnn_graph_t;
 
+/* Execution plan of the fused pipeline (built once per batch by the host; see
+ * gnn-fpga_amd/plan.py): hits relabelled by degree inside each graph, neighbour lists in
+ * SELL-16 layout (entry k of hit i of 16-hit slice s at off[s] + 16*k + i), padded with the
+ * NULL hit id n_hits.  Scores are still per segment in the caller's segment order. */
+typedef struct gnn_plan {
+    const float *X;                      /* [n_hits+1, F] relabelled features, last row zero */
+    const int32_t *src, *dst;            /* [n_segments] relabelled endpoints, n_hits = padded */
+    const int32_t *in_off, *in_nbr;      /* [n_slices+1], [in_off[n_slices]]  segments ending at a hit -> start hit */
+    const int32_t *out_off, *out_nbr;    /* [n_slices+1], [out_off[n_slices]] segments starting at a hit -> end hit */
+    int64_t n_hits, n_segments, n_slices;
+} gnn_plan_t;
+
 int gnn_abi_version(void);
 const char *gnn_last_error(void);
 
@@ -98,6 +110,16 @@ size_t gnn_forward_workspace_bytes(int64_t n_hits, int64_t n_segments, int32_t F
 int gnn_segclf_forward(const gnn_graph_t *g, const gnn_params_t *p, int32_t n_iters,
                        float *e_out, float *e_trace, float *H_trace,
                        void *workspace, size_t workspace_bytes, void *stream);
+
+/* SegmentClassifier.forward (gnn/model.py:140-156) on a planned batch: the fast path.
+ * One fused kernel per message-passing iteration (edge scores are recomputed at both
+ * endpoints from per-hit partial products instead of being stored), one final edge kernel.
+ * e_out [n_segments].  Workspace size from gnn_plan_workspace_bytes. */
+size_t gnn_plan_workspace_bytes(int64_t n_hits, int64_t n_segments, int32_t F, int32_t D);
+int gnn_segclf_forward_plan(const gnn_plan_t *plan, const gnn_params_t *p, int32_t n_iters,
+                            float *e_out, void *workspace, size_t workspace_bytes, void *stream);
+/* 1 if the fused pipeline has kernels for this (input_dim, hidden_dim). */
+int gnn_plan_shape_supported(int32_t F, int32_t D);
 
 /* Per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).
  * gnn_profile_begin(capacity) arms recording of up to `capacity` kernel launches;

@@ -43,6 +43,24 @@ def test_forward_matches_reference_golden(hip, name):
     assert torch.equal(e, e2)
 
 
+@pytest.mark.parametrize("name", SINGLE + ["c3_full_s0"])
+def test_fused_plan_forward_matches_reference_golden(hip, name):
+    """The fast path: relabel + SELL-16 plan, one fused kernel per iteration."""
+    fx = Fixture(name)
+    if not hip.plan_shape_supported(fx.F, fx.D):
+        pytest.skip("no fused kernel for F=%d D=%d" % (fx.F, fx.D))
+    dev = torch.device("cuda:0")
+    batch = HitGraphBatch.from_graphs([fx.graph]).to(dev)
+    plan = batch.build_plan()
+    e = hip.segclf_forward_plan(plan, _weights(fx, dev), fx.F, fx.D, fx.n_iters)
+    torch.cuda.synchronize()
+    assert np.abs(e.cpu().numpy() - fx.scores).max() < TOL
+    # n_iters = 0 (input network + one edge pass) against the first traced edge pass
+    if fx.e_trace is not None:
+        e0 = hip.segclf_forward_plan(plan, _weights(fx, dev), fx.F, fx.D, 0)
+        assert np.abs(e0.cpu().numpy() - fx.e_trace[0]).max() < TOL
+
+
 def test_c3_full_size_golden(hip):
     fx = Fixture("c3_full_s0")
     dev = torch.device("cuda:0")
@@ -71,7 +89,7 @@ def test_padded_batch_dense_dropin(hip, name):
     assert np.abs(out.cpu().numpy() - fx.scores).max() < TOL
 
 
-@pytest.mark.parametrize("F,D,T", [(3, 8, 3), (11, 8, 3), (2, 16, 2), (3, 4, 5)])
+@pytest.mark.parametrize("F,D,T", [(3, 8, 3), (11, 8, 3), (2, 16, 2), (3, 4, 5), (3, 16, 1)])
 def test_megabatch_against_oracle(hip, F, D, T):
     """Block-diagonal batch of ragged graphs, incl. an empty-segment graph, vs the C oracle."""
     rng = np.random.default_rng(5)
@@ -85,13 +103,15 @@ def test_megabatch_against_oracle(hip, F, D, T):
     m = SegmentClassifier(input_dim=F, hidden_dim=D, n_iters=T).cuda().eval()
     params = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
     batch = HitGraphBatch.from_graphs(graphs).cuda()
-    with torch.no_grad():
-        e = m(batch).cpu().numpy()
-    for g, eg in zip(graphs, batch.split_scores(e)):
-        ref = index_c.segment_classifier(g.X, g.src, g.dst, params, T)
-        assert eg.shape == ref.shape
-        if ref.size:
-            assert np.abs(eg - ref).max() < TOL
+    for use_plan in (True, False):       # fused pipeline, then per-module CSR kernels
+        m.use_plan = use_plan
+        with torch.no_grad():
+            e = m(batch).cpu().numpy()
+        for g, eg in zip(graphs, batch.split_scores(e)):
+            ref = index_c.segment_classifier(g.X, g.src, g.dst, params, T)
+            assert eg.shape == ref.shape
+            if ref.size:
+                assert np.abs(eg - ref).max() < TOL
 
 
 def test_submodules_like_the_notebooks(hip):
