@@ -105,7 +105,7 @@ def main():
     graphs = [synth.layered_graph(N_HITS, N_SEG, F, seed=rank * G + i) for i in range(G)]
     batch = HitGraphBatch.from_graphs(graphs).to(dev)
     t_plan = time.perf_counter()
-    plan = batch.build_plan()     # relabel + SELL-16 lists: once per batch, like the CSR build
+    plan = batch.build_plan(D)     # relabel + SELL-16 lists: once per batch, like the CSR build
     t_plan = time.perf_counter() - t_plan
     torch.manual_seed(0)
     model = SegmentClassifier(input_dim=F, hidden_dim=D, n_iters=T).to(dev).eval()

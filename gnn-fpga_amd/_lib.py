@@ -33,8 +33,9 @@ class GnnGraph(ctypes.Structure):
 
 
 class GnnPlan(ctypes.Structure):
-    _fields_ = [(n, _f) for n in ("X", "src", "dst", "in_off", "in_nbr", "out_off", "out_nbr")] + \
-               [("n_hits", _i64), ("n_segments", _i64), ("n_slices", _i64)]
+    _fields_ = [(n, _f) for n in ("X", "src", "dst", "in_off", "in_nbr", "out_off", "out_nbr",
+                                  "tiles", "chunks")] + \
+               [("n_pad", _i64), ("n_segments", _i64), ("n_tiles", _i64), ("n_chunks", _i64)]
 
 
 # name -> (restype, argtypes); must list every function include/gnn_hip.h declares
@@ -55,6 +56,7 @@ SIGNATURES = {
     "gnn_segclf_forward_plan": (ctypes.c_int, [ctypes.POINTER(GnnPlan), ctypes.POINTER(GnnParams),
                                                _i32, _f, _f, _sz, _f]),
     "gnn_plan_shape_supported": (ctypes.c_int, [_i32, _i32]),
+    "gnn_plan_limits": (ctypes.c_int, [_i32, _i32, ctypes.POINTER(_i32)]),
     "gnn_profile_begin": (ctypes.c_int, [_i32]),
     "gnn_profile_end": (ctypes.c_int, [ctypes.POINTER(ctypes.c_char_p),
                                        ctypes.POINTER(ctypes.c_float), _i32]),
@@ -213,12 +215,21 @@ def plan_shape_supported(F, D):
     return bool(load().gnn_plan_shape_supported(F, D))
 
 
+def plan_limits(F, D):
+    """Tile / chunk sizes and LDS window budgets the plan builder must respect (no GPU needed)."""
+    out = (_i32 * 4)()
+    _check(load().gnn_plan_limits(F, D, out))
+    return {"tile_hits": out[0], "iter_records": out[1], "chunk_segments": out[2],
+            "edge_records": out[3]}
+
+
 def plan_struct(plan):
     g = GnnPlan()
     g.X = _dev(plan.X, torch.float32, "plan.X")
-    for k in ("src", "dst", "in_off", "in_nbr", "out_off", "out_nbr"):
+    for k in ("src", "dst", "in_off", "in_nbr", "out_off", "out_nbr", "tiles", "chunks"):
         setattr(g, k, _dev(getattr(plan, k), torch.int32, "plan." + k))
-    g.n_hits, g.n_segments, g.n_slices = plan.n_hits, plan.n_segments, plan.n_slices
+    g.n_pad, g.n_segments = plan.n_pad, plan.n_segments
+    g.n_tiles, g.n_chunks = plan.n_tiles, plan.n_chunks
     return g
 
 
@@ -231,7 +242,7 @@ def segclf_forward_plan(plan, weights, F, D, n_iters, out=None, workspace=None):
     dev = plan.X.device
     if not plan_shape_supported(F, D):
         raise GnnHipError("no fused HIP kernel for input_dim=%d hidden_dim=%d" % (F, D))
-    need = plan_workspace_bytes(plan.n_hits, plan.n_segments, F, D)
+    need = plan_workspace_bytes(plan.n_pad, plan.n_segments, F, D)
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(need, dtype=torch.uint8, device=dev)
     if out is None:

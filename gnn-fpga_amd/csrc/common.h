@@ -49,5 +49,6 @@ int sell_forward(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float
                  size_t ws_bytes, hipStream_t s);
 size_t sell_workspace_bytes(int64_t n_hits, int64_t n_segments, int F, int D);
 int sell_shape_supported(int F, int D);
+int sell_limits(int F, int D, int32_t *out4);
 
 }  // namespace gnn

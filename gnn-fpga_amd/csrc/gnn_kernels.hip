@@ -482,22 +482,28 @@ int gnn_segclf_forward(const gnn_graph_t *g, const gnn_params_t *p, int32_t n_it
     return fail(GNN_ERR_UNSUPPORTED, "unreachable");
 }
 
-size_t gnn_plan_workspace_bytes(int64_t n_hits, int64_t n_segments, int32_t F, int32_t D)
+size_t gnn_plan_workspace_bytes(int64_t n_pad, int64_t n_segments, int32_t F, int32_t D)
 {
-    if (n_hits < 0 || n_segments < 0) return 0;
-    return sell_workspace_bytes(n_hits, n_segments, F, D);
+    if (n_pad < 0 || n_segments < 0) return 0;
+    return sell_workspace_bytes(n_pad, n_segments, F, D);
 }
 
 int gnn_plan_shape_supported(int32_t F, int32_t D) { return sell_shape_supported(F, D); }
 
+int gnn_plan_limits(int32_t F, int32_t D, int32_t *out4)
+{
+    if (!out4) return fail(GNN_ERR_BADARG, "gnn_plan_limits: null output");
+    return sell_limits(F, D, out4);
+}
+
 int gnn_segclf_forward_plan(const gnn_plan_t *pl, const gnn_params_t *p, int32_t n_iters,
                             float *e_out, void *workspace, size_t workspace_bytes, void *stream)
 {
-    if (!pl || !p || n_iters < 0 || pl->n_hits < 0 || pl->n_segments < 0 || pl->n_slices < 0)
+    if (!pl || !p || n_iters < 0 || pl->n_pad < 0 || pl->n_segments < 0 || pl->n_tiles < 0 ||
+        pl->n_chunks < 0 || (pl->n_pad & 15))
         return fail(GNN_ERR_BADARG, "gnn_segclf_forward_plan: bad argument");
-    if (pl->n_slices != (pl->n_hits + 15) / 16)
-        return fail(GNN_ERR_BADARG, "gnn_segclf_forward_plan: n_slices must be ceil(n_hits/16)");
-    if (!pl->X || !pl->in_off || !pl->out_off || (pl->n_segments > 0 && (!pl->src || !pl->dst || !e_out)))
+    if (!pl->X || !pl->in_off || !pl->out_off || (pl->n_tiles > 0 && !pl->tiles) ||
+        (pl->n_segments > 0 && (!pl->src || !pl->dst || !pl->chunks || !e_out)))
         return fail(GNN_ERR_BADARG, "gnn_segclf_forward_plan: plan array missing");
     if (!p->Win || !p->bin || !p->W1 || !p->b1 || !p->W2 || !p->b2 || !p->W3 || !p->b3 || !p->W4 || !p->b4)
         return fail(GNN_ERR_BADARG, "gnn_segclf_forward_plan: weight pointer missing");

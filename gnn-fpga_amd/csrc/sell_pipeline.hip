@@ -28,15 +28,23 @@
 // (2.4 KB at F=3, D=8) into LDS; the 4 roles read 4 distinct addresses per instruction
 // (broadcast, conflict-free).
 //
-// XCD affinity: workgroups are renumbered so that each of the 8 XCDs walks one contiguous
-// eighth of the slices, i.e. whole graphs: a graph's records (1.3 MB at 10k hits) are pulled
-// into exactly one XCD's 4 MB L2 and gathered from there.
+// LDS-staged windows: plan.py orders hits by (graph, topological level) and cuts them into
+// tiles of <= 1024 hits, one workgroup each.  All start hits of a tile's incoming segments lie
+// in one contiguous id window and all end hits of its outgoing segments in another, so the
+// workgroup copies the two windows of records (PR of the previous level, QS of the next: 64 KB
+// each at 1000 hits/level, D = 8) into LDS with fully coalesced reads and gathers from LDS
+// (window-relative indices).  Measured before this change: random 64-byte gathers from an
+// L2-resident table run at the L2 line rate (17 TB/s of 128-byte lines, half of each line
+// wasted) and bound the kernel.  Tiles whose windows exceed the LDS budget (irregular graphs)
+// gather from global memory instead, with workgroups renumbered so that each XCD walks a
+// contiguous range of tiles (whole graphs stay in one XCD's L2).
 #include "common.h"
 
 namespace {
 using namespace gnn;
 
 constexpr int SLICE = 16;
+constexpr int DESC = 8;   // ints per tile / chunk descriptor (plan.py)
 
 // ---------------------------------------------------------------------------------------------
 // per-lane-role weight table layout (floats)
@@ -51,10 +59,21 @@ struct TL {
     static constexpr int o_W4 = o_b4 + d4;          // [D][d4]      W4[r][k]
     static constexpr int o_m = o_W4 + D * d4;       // 5 x { [d4] bias, [C][d4] weights }
     static constexpr int m_sz = d4 + C * d4;
-    static constexpr int used = o_m + 5 * m_sz;
+    static constexpr int o_b2 = o_m + 5 * m_sz;     // [1]  scaled output bias (see k_pack)
+    static constexpr int used = o_b2 + 1;
     static constexpr int stride = ((used + 3) & ~3) + 4;
-    static constexpr int total = 4 * stride;
+    static constexpr int o_flat = 4 * stride;       // [D] scaled W2 in natural order, [1] scaled b2
+    static constexpr int total = o_flat + ((D + 1 + 3) & ~3);
 };
+
+// Scale folding.  tanh(z) = 1 - 2 r(z'), r(z') = 1 / (1 + 2^z'), z' = 2 log2(e) z, and
+// sigmoid(a) = 1 / (1 + 2^a''), a'' = -log2(e) a.  With a = b2 + sum_i w_i tanh(z_i):
+//     a'' = -log2(e) (b2 + sum_i w_i) + sum_i (2 log2(e) w_i) r(z'_i)
+// so the pack kernel stores P, Q (and their biases) pre-multiplied by 2 log2(e), W2 as
+// 2 log2(e) w_i and the bias as -log2(e) (b2 + sum w): per hidden unit the edge MLP costs
+// add, v_exp, add, v_rcp, fma - no multiplies by constants in the inner loop.
+constexpr float kTwoLog2e = 2.8853900817779268f;
+constexpr float kLog2e = 1.4426950408889634f;
 
 template <int F, int D>
 __global__ __launch_bounds__(256) void k_pack(gnn_params_t p, float *__restrict__ table,
@@ -66,8 +85,17 @@ __global__ __launch_bounds__(256) void k_pack(gnn_params_t p, float *__restrict_
     for (int idx = threadIdx.x; idx < L::total; idx += 256) {
         const int q = idx / L::stride, pos = idx % L::stride;
         float v = 0.0f;
-        if (pos < L::o_bin) {
-            v = p.W2[q * d4 + pos];
+        if (idx >= L::o_flat) {
+            const int t = idx - L::o_flat;
+            if (t < D) {
+                v = kTwoLog2e * p.W2[t];
+            } else if (t == D) {
+                float sw = p.b2[0];
+                for (int k = 0; k < D; ++k) sw += p.W2[k];
+                v = -kLog2e * sw;
+            }
+        } else if (pos < L::o_bin) {
+            v = kTwoLog2e * p.W2[q * d4 + pos];
         } else if (pos < L::o_Win) {
             v = p.bin[q * d4 + (pos - L::o_bin)];
         } else if (pos < L::o_b4) {
@@ -78,29 +106,33 @@ __global__ __launch_bounds__(256) void k_pack(gnn_params_t p, float *__restrict_
         } else if (pos < L::o_m) {
             const int t = pos - L::o_W4, k = t / d4, i = t % d4;
             v = p.W4[(q * d4 + i) * D + k];
-        } else if (pos < L::used) {
+        } else if (pos < L::o_b2) {
             const int t = pos - L::o_m, m = t / L::m_sz, u = t % L::m_sz;
             if (u < d4) {
                 const int r = q * d4 + u;
-                v = (m == 0) ? p.b1[r] : (m == 4) ? p.b3[r] : 0.0f;
+                v = (m == 0) ? kTwoLog2e * p.b1[r] : (m == 4) ? p.b3[r] : 0.0f;
             } else {
                 const int k = (u - d4) / d4, r = q * d4 + (u - d4) % d4;
                 switch (m) {
-                case 0: v = p.W1[r * 2 * C + k]; break;            // P
-                case 1: v = p.W3[r * 3 * C + k]; break;            // R
-                case 2: v = p.W1[r * 2 * C + C + k]; break;        // Q
-                case 3: v = p.W3[r * 3 * C + C + k]; break;        // S
-                default: v = p.W3[r * 3 * C + 2 * C + k]; break;   // U
+                case 0: v = kTwoLog2e * p.W1[r * 2 * C + k]; break;      // P (scaled)
+                case 1: v = p.W3[r * 3 * C + k]; break;                  // R
+                case 2: v = kTwoLog2e * p.W1[r * 2 * C + C + k]; break;  // Q (scaled)
+                case 3: v = p.W3[r * 3 * C + C + k]; break;              // S
+                default: v = p.W3[r * 3 * C + 2 * C + k]; break;         // U
                 }
             }
+        } else if (pos == L::o_b2) {
+            float sw = p.b2[0];
+            for (int k = 0; k < D; ++k) sw += p.W2[k];
+            v = -kLog2e * sw;
         }
         table[idx] = v;
     }
-    // NULL hit (id n_hits): P = b1, everything else 0.  A padded list entry adds e * 0; a
+    // NULL hit (id n_hits): P = (scaled) b1, everything else 0.  A padded list entry adds e * 0; a
     // padded segment scores sigmoid(W2 tanh(b1) + b2) (gnn/trainSegmentClassifier.py:83-93).
     for (int t = threadIdx.x; t < 2 * D; t += 256) {
         const int q = t / (2 * d4), w = t % (2 * d4);
-        const float pv = (w < d4) ? p.b1[q * d4 + w] : 0.0f;
+        const float pv = (w < d4) ? kTwoLog2e * p.b1[q * d4 + w] : 0.0f;
         PRa[n_hits * 2 * D + t] = pv;
         PRb[n_hits * 2 * D + t] = pv;
         QSa[n_hits * 2 * D + t] = 0.0f;
@@ -108,7 +140,7 @@ __global__ __launch_bounds__(256) void k_pack(gnn_params_t p, float *__restrict_
     }
     for (int t = threadIdx.x; t < D; t += 256) {
         U[n_hits * D + t] = 0.0f;
-        Pc[n_hits * D + t] = p.b1[t];
+        Pc[n_hits * D + t] = kTwoLog2e * p.b1[t];
         Qc[n_hits * D + t] = 0.0f;
     }
 }
@@ -178,15 +210,27 @@ __device__ __forceinline__ void store_vec(float *__restrict__ dst, const float *
     }
 }
 
-// copy the packed weight table global -> LDS (whole workgroup), then barrier
-template <int TOTAL>
-__device__ __forceinline__ void stage_table(const float *__restrict__ table, float *lds)
+// copy n4 float4s global -> LDS with the whole workgroup (no barrier)
+template <int NT>
+__device__ __forceinline__ void stage4(const float *__restrict__ g, float *lds, int n4)
 {
-    static_assert(TOTAL % 4 == 0, "table is float4 granular");
-    for (int i = threadIdx.x; i < TOTAL / 4; i += 256)
-        reinterpret_cast<float4 *>(lds)[i] = reinterpret_cast<const float4 *>(table)[i];
-    __syncthreads();
+    for (int i = threadIdx.x; i < n4; i += NT)
+        reinterpret_cast<float4 *>(lds)[i] = reinterpret_cast<const float4 *>(g)[i];
 }
+
+// per-shape launch configuration and LDS budgets (records), mirrored to plan.py through
+// gnn_plan_limits()
+template <int F, int D>
+struct Cfg {
+    static constexpr int NT = (D <= 16) ? 1024 : 256;       // threads per workgroup
+    static constexpr int lds_bytes = 160 * 1024;
+    static constexpr int table_bytes = TL<F, D>::total * 4;
+    // k_iter window: records of 2D floats ([P|R] or [Q|S]); k_edge window: rows of D floats
+    static constexpr int it_rec = (D <= 16) ? (lds_bytes - table_bytes - 2048) / (8 * D) : 0;
+    static constexpr int ed_rec = (D <= 16) ? (lds_bytes - 2048) / (4 * D) : 0;
+    static constexpr int tile_hits = 1024;
+    static constexpr int chunk_segments = 8192;
+};
 
 // out[i] = bias[i] + sum_k W[k][i] * in[k]  for this lane's d4 rows; weights from LDS
 template <int D4, int KD, int KF>
@@ -238,27 +282,27 @@ __device__ __forceinline__ void emit_records(const float *wl, const float *hn, c
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-// input network (model.py:144-146) + records of iteration 0.  4 lanes per hit.
+// input network (model.py:144-146) + records of iteration 0.  4 lanes per hit, over the padded
+// hit range (dummy hits have X = 0 and are never gathered).
 template <int F, int D, bool LAST>
 __global__ __launch_bounds__(256) void k_input4(const float *__restrict__ X,
                                                 const float *__restrict__ table,
                                                 float *__restrict__ PRn, float *__restrict__ QSn,
                                                 float *__restrict__ U, float *__restrict__ Pc,
-                                                float *__restrict__ Qc, int64_t n_hits)
+                                                float *__restrict__ Qc, int64_t n_pad)
 {
     using L = TL<F, D>;
     constexpr int d4 = L::d4;
     __shared__ __attribute__((aligned(16))) float lds[L::total];
-    stage_table<L::total>(table, lds);
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t n = gid >> 2;
+    stage4<256>(table, lds, L::total / 4);
+    __syncthreads();
+    const int64_t n = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 2;   // n_pad % 16 == 0
+    if (n >= n_pad) return;                                             // whole quads exit
     const int q = threadIdx.x & 3;
-    const bool live = n < n_hits;
-    const int64_t ne = live ? n : n_hits;          // NULL row is readable
     const float *wl = lds + q * L::stride;
     float x[F];
 #pragma unroll
-    for (int k = 0; k < F; ++k) x[k] = X[ne * F + k];
+    for (int k = 0; k < F; ++k) x[k] = X[n * F + k];
     float hl[d4];
 #pragma unroll
     for (int i = 0; i < d4; ++i) {
@@ -269,128 +313,232 @@ __global__ __launch_bounds__(256) void k_input4(const float *__restrict__ X,
     }
     float hn[D];
     quad_allgather<d4>(hl, hn);
-    if (live) emit_records<F, D, LAST>(wl, hn, x, n, q, PRn, QSn, U, Pc, Qc);
+    emit_records<F, D, LAST>(wl, hn, x, n, q, PRn, QSn, U, Pc, Qc);
 }
 
-// one message-passing iteration: edge scores + weighted aggregation + hit update (+ records).
-template <int F, int D, bool LAST>
-__global__ __launch_bounds__(256) void k_iter(
-    const float *__restrict__ X, const float *__restrict__ table, const float *__restrict__ b2p,
-    const int32_t *__restrict__ in_off, const int32_t *__restrict__ in_nbr,
-    const int32_t *__restrict__ out_off, const int32_t *__restrict__ out_nbr,
-    const float *__restrict__ PR, const float *__restrict__ QS, float *__restrict__ U,
-    float *__restrict__ PRn, float *__restrict__ QSn, float *__restrict__ Pc,
-    float *__restrict__ Qc, int64_t n_hits, int n_slices, int blocks_per_xcd)
+// r(z') = 1 / (1 + 2^z'): the only transcendental pair of the edge MLP (see scale folding)
+__device__ __forceinline__ float r_f(float zs)
 {
-    using L = TL<F, D>;
-    constexpr int d4 = L::d4;
-    __shared__ __attribute__((aligned(16))) float lds[L::total];
-    stage_table<L::total>(table, lds);
-
-    // XCD-affine renumbering: hardware deals blockIdx round-robin over the 8 XCDs, so
-    // blocks with equal (blockIdx & 7) share an L2; give each such group a contiguous range.
-    const int vblock = (blockIdx.x & 7) * blocks_per_xcd + (blockIdx.x >> 3);
-    const int slice = __builtin_amdgcn_readfirstlane(vblock * 4 + (int)(threadIdx.x >> 6));
-    if (slice >= n_slices) return;
-    const int lane = threadIdx.x & 63;
-    const int q = lane & 3, i16 = lane >> 2;
-    const int64_t n = (int64_t)slice * SLICE + i16;
-    const bool live = n < n_hits;
-    const int64_t ne = live ? n : n_hits;
-    const float *wl = lds + q * L::stride;
-    const float b2 = b2p[0];
-
-    float w2[d4], Pn[d4], Qn[d4], acc[d4];
-#pragma unroll
-    for (int i = 0; i < d4; ++i) w2[i] = wl[L::o_w2 + i];
-    load_vec<d4>(PR + ne * 2 * D + q * 2 * d4, Pn);       // own P chunk
-    load_vec<d4>(QS + ne * 2 * D + q * 2 * d4, Qn);       // own Q chunk
-    load_vec<d4>(U + ne * D + q * d4, acc);               // W3[:, 2C:] H_n + b3
-
-    // one neighbour record: score the segment, add its weighted half
-    auto pull = [&](const float *rec, const float *own) {
-        float part = 0.0f;
-#pragma unroll
-        for (int i = 0; i < d4; ++i) part = fmaf(w2[i], tanh_f(rec[i] + own[i]), part);
-        const float e = sigmoid_f(quad_sum(part) + b2);
-#pragma unroll
-        for (int i = 0; i < d4; ++i) acc[i] = fmaf(e, rec[d4 + i], acc[i]);
-    };
-    auto sweep = [&](const int32_t *__restrict__ off, const int32_t *__restrict__ nbr,
-                     const float *__restrict__ REC, const float *own) {
-        const int base = __builtin_amdgcn_readfirstlane(off[slice]);
-        const int len = (__builtin_amdgcn_readfirstlane(off[slice + 1]) - base) >> 4;
-        const int32_t *lst = nbr + base + i16;
-        // UN independent record gathers in flight per lane (fewer at large D: registers)
-        constexpr int UN = d4 <= 2 ? 4 : (d4 <= 4 ? 2 : 1);
-        int k = 0;
-        for (; k + UN <= len; k += UN) {
-            int nb[UN];
-            float rec[UN][2 * d4];
-#pragma unroll
-            for (int j = 0; j < UN; ++j) nb[j] = lst[(k + j) * SLICE];
-#pragma unroll
-            for (int j = 0; j < UN; ++j)
-                load_vec<2 * d4>(REC + (int64_t)nb[j] * 2 * D + q * 2 * d4, rec[j]);
-#pragma unroll
-            for (int j = 0; j < UN; ++j) pull(rec[j], own);
-        }
-        for (; k < len; ++k) {
-            float rec[2 * d4];
-            load_vec<2 * d4>(REC + (int64_t)lst[k * SLICE] * 2 * D + q * 2 * d4, rec);
-            pull(rec, own);
-        }
-    };
-    sweep(in_off, in_nbr, PR, Qn);     // segments ending here:   P[start] + Q[n], adds e * R[start]
-    sweep(out_off, out_nbr, QS, Pn);   // segments starting here: Q[end] + P[n],   adds e * S[end]
-
-    // hit update: H' = tanh(W4 tanh(acc) + b4)                      (model.py:94-98,125)
-    float ql[d4], qa[D];
-#pragma unroll
-    for (int i = 0; i < d4; ++i) ql[i] = tanh_f(acc[i]);
-    quad_allgather<d4>(ql, qa);
-    float hl[d4];
-#pragma unroll
-    for (int i = 0; i < d4; ++i) hl[i] = wl[L::o_b4 + i];
-#pragma unroll
-    for (int k = 0; k < D; ++k)
-#pragma unroll
-        for (int i = 0; i < d4; ++i) hl[i] = fmaf(wl[L::o_W4 + k * d4 + i], qa[k], hl[i]);
-#pragma unroll
-    for (int i = 0; i < d4; ++i) hl[i] = tanh_f(hl[i]);
-    float hn[D], x[F];
-    quad_allgather<d4>(hl, hn);
-#pragma unroll
-    for (int k = 0; k < F; ++k) x[k] = X[ne * F + k];               // skip concat (model.py:154)
-    if (live) emit_records<F, D, LAST>(wl, hn, x, n, q, PRn, QSn, U, Pc, Qc);
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(zs));
 }
 
-// final edge pass (model.py:156): caller's segment order, 4 lanes per segment.
-template <int F, int D>
-__global__ __launch_bounds__(256) void k_edge4(const int32_t *__restrict__ src,
-                                               const int32_t *__restrict__ dst,
-                                               const float *__restrict__ Pc,
-                                               const float *__restrict__ Qc,
-                                               const float *__restrict__ table,
-                                               const float *__restrict__ b2p,
-                                               float *__restrict__ e, int64_t n_segments,
-                                               int blocks_per_xcd)
+// one neighbour record: score the segment from (record P|Q half + own half), add its R|S half
+template <int D4>
+__device__ __forceinline__ void pull(const float *rec, const float *own, const float *w2, float b2,
+                                     float *acc)
 {
-    using L = TL<F, D>;
-    constexpr int d4 = L::d4;
-    const int64_t vblock = (int64_t)(blockIdx.x & 7) * blocks_per_xcd + (blockIdx.x >> 3);
-    const int64_t j = vblock * 64 + (threadIdx.x >> 2);
-    if (j >= n_segments) return;
-    const int q = threadIdx.x & 3;
-    float w2[d4], p[d4], qq[d4];
-    load_vec<d4>(table + q * L::stride + L::o_w2, w2);
-    load_vec<d4>(Pc + (int64_t)src[j] * D + q * d4, p);
-    load_vec<d4>(Qc + (int64_t)dst[j] * D + q * d4, qq);
     float part = 0.0f;
 #pragma unroll
-    for (int i = 0; i < d4; ++i) part = fmaf(w2[i], tanh_f(p[i] + qq[i]), part);
-    const float ev = sigmoid_f(quad_sum(part) + b2p[0]);
-    if (q == 0) e[j] = ev;
+    for (int i = 0; i < D4; ++i) part = fmaf(w2[i], r_f(rec[i] + own[i]), part);
+    const float e = r_f(quad_sum(part) + b2);
+#pragma unroll
+    for (int i = 0; i < D4; ++i) acc[i] = fmaf(e, rec[D4 + i], acc[i]);
+}
+
+// Stream of SELL-16 entries of one list of this wavefront's slice.  The 4 lanes of a quad
+// need the same entry at every step, so they load 4 DIFFERENT steps with one instruction
+// (lane q takes step 4c+q) and broadcast inside the quad with DPP; two chunks stay in flight.
+// Reads run up to 11 steps past the list end (plan.py pads the arrays).
+struct ListStream {
+    const int32_t *p;
+    int c0, c1;
+    __device__ __forceinline__ void init(const int32_t *lst)   // lst = nbr + base + 16*q + i16
+    {
+        c0 = lst[0];
+        c1 = lst[4 * SLICE];
+        p = lst + 8 * SLICE;
+    }
+    __device__ __forceinline__ int next()
+    {
+        const int cur = c0;
+        c0 = c1;
+        c1 = p[0];
+        p += 4 * SLICE;
+        return cur;
+    }
+};
+
+template <int J>
+__device__ __forceinline__ int quad_bcast_i(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, J * 0x55, 0xF, 0xF, false);
+}
+
+// walk one list: REC is the record table (an LDS window or global memory)
+template <int D>
+__device__ __forceinline__ void sweep(ListStream &st, int len, const float *REC, int q,
+                                      const float *own, const float *w2, float b2, float *acc)
+{
+    constexpr int d4 = D / 4;
+    for (int k = 0; k < len; k += 4) {
+        const int cur = st.next();
+        const int nb[4] = {quad_bcast_i<0>(cur), quad_bcast_i<1>(cur), quad_bcast_i<2>(cur),
+                           quad_bcast_i<3>(cur)};
+        const int rem = len - k;                     // wave-uniform
+        if (rem >= 4) {
+            if constexpr (d4 <= 2) {                 // 4 independent record reads in flight
+                float rec[4][2 * d4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    load_vec<2 * d4>(REC + (int64_t)nb[j] * 2 * D + q * 2 * d4, rec[j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pull<d4>(rec[j], own, w2, b2, acc);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float rec[2 * d4];
+                    load_vec<2 * d4>(REC + (int64_t)nb[j] * 2 * D + q * 2 * d4, rec);
+                    pull<d4>(rec, own, w2, b2, acc);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if (j < rem) {
+                    float rec[2 * d4];
+                    load_vec<2 * d4>(REC + (int64_t)nb[j] * 2 * D + q * 2 * d4, rec);
+                    pull<d4>(rec, own, w2, b2, acc);
+                }
+            }
+        }
+    }
+}
+
+// one message-passing iteration for one tile: edge scores + weighted aggregation + hit update
+// (+ records for the next pass).  One workgroup per tile; each wavefront takes 16-hit slices.
+template <int F, int D, bool LAST>
+__global__ __launch_bounds__((Cfg<F, D>::NT)) void k_iter(
+    const float *__restrict__ X, const float *__restrict__ table,
+    const int32_t *__restrict__ tiles, const int32_t *__restrict__ in_off,
+    const int32_t *__restrict__ in_nbr, const int32_t *__restrict__ out_off,
+    const int32_t *__restrict__ out_nbr, const float *__restrict__ PR,
+    const float *__restrict__ QS, float *__restrict__ U, float *__restrict__ PRn,
+    float *__restrict__ QSn, float *__restrict__ Pc, float *__restrict__ Qc, int64_t n_pad,
+    int tiles_per_xcd, int n_tiles)
+{
+    using L = TL<F, D>;
+    using G = Cfg<F, D>;
+    constexpr int d4 = L::d4, NT = G::NT;
+    constexpr int WIN = G::it_rec > 0 ? G::it_rec * 2 * D : 4;
+    __shared__ __attribute__((aligned(16))) float lds[L::total];
+    __shared__ __attribute__((aligned(16))) float win[WIN];
+    stage4<NT>(table, lds, L::total / 4);
+
+    // XCD-affine renumbering (matters for global-mode tiles only): blockIdx is dealt round-robin
+    // over the 8 XCDs, so give each residue class a contiguous range of tiles.
+    const int tile = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
+    if (tile >= n_tiles) return;
+    const int32_t *td = tiles + (int64_t)tile * DESC;
+    const int s_begin = td[0], s_end = td[1], in_lo = td[2], in_cnt = td[3], out_lo = td[4],
+              out_cnt = td[5], mode = td[6];
+    float *winA = win, *winB = win + (in_cnt + 1) * 2 * D;
+    if (G::it_rec > 0 && mode) {
+        stage4<NT>(PR + (int64_t)in_lo * 2 * D, winA, in_cnt * 2 * D / 4);
+        stage4<NT>(PR + n_pad * 2 * D, winA + in_cnt * 2 * D, 2 * D / 4);     // NULL record
+        stage4<NT>(QS + (int64_t)out_lo * 2 * D, winB, out_cnt * 2 * D / 4);
+        stage4<NT>(QS + n_pad * 2 * D, winB + out_cnt * 2 * D, 2 * D / 4);
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int q = lane & 3, i16 = lane >> 2;
+    float w2[d4];
+#pragma unroll
+    for (int i = 0; i < d4; ++i) w2[i] = lds[q * L::stride + L::o_w2 + i];
+    const float b2 = lds[L::o_b2];                      // scaled output bias
+
+    for (int slice = s_begin + (int)(threadIdx.x >> 6); slice < s_end; slice += NT / 64) {
+        // the weight-table offset is made opaque per iteration: otherwise the compiler hoists
+        // every (loop-invariant) LDS weight read out of the slice loop into ~150 VGPRs
+        int woff = q * L::stride;
+        asm volatile("" : "+v"(woff));
+        const float *wl = lds + woff;
+        const int64_t n = (int64_t)slice * SLICE + i16;
+        // start both index streams and the own-record loads before anything is consumed
+        const int ib = __builtin_amdgcn_readfirstlane(in_off[slice]);
+        const int il = (__builtin_amdgcn_readfirstlane(in_off[slice + 1]) - ib) >> 4;
+        const int ob = __builtin_amdgcn_readfirstlane(out_off[slice]);
+        const int ol = (__builtin_amdgcn_readfirstlane(out_off[slice + 1]) - ob) >> 4;
+        ListStream sin, sout;
+        sin.init(in_nbr + ib + q * SLICE + i16);
+        sout.init(out_nbr + ob + q * SLICE + i16);
+        float Pn[d4], Qn[d4], acc[d4];
+        load_vec<d4>(PR + n * 2 * D + q * 2 * d4, Pn);      // own P chunk
+        load_vec<d4>(QS + n * 2 * D + q * 2 * d4, Qn);      // own Q chunk
+        load_vec<d4>(U + n * D + q * d4, acc);              // W3[:, 2C:] H_n + b3
+        if (G::it_rec > 0 && mode) {
+            // segments ending here: P[start] + Q[n], adds e * R[start]; then starting here
+            sweep<D>(sin, il, winA, q, Qn, w2, b2, acc);
+            sweep<D>(sout, ol, winB, q, Pn, w2, b2, acc);
+        } else {
+            sweep<D>(sin, il, PR, q, Qn, w2, b2, acc);
+            sweep<D>(sout, ol, QS, q, Pn, w2, b2, acc);
+        }
+        // hit update: H' = tanh(W4 tanh(acc) + b4)                  (model.py:94-98,125)
+        float ql[d4], qa[D];
+#pragma unroll
+        for (int i = 0; i < d4; ++i) ql[i] = tanh_f(acc[i]);
+        quad_allgather<d4>(ql, qa);
+        float hl[d4];
+#pragma unroll
+        for (int i = 0; i < d4; ++i) hl[i] = wl[L::o_b4 + i];
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+#pragma unroll
+            for (int i = 0; i < d4; ++i) hl[i] = fmaf(wl[L::o_W4 + k * d4 + i], qa[k], hl[i]);
+#pragma unroll
+        for (int i = 0; i < d4; ++i) hl[i] = tanh_f(hl[i]);
+        float hn[D], x[F];
+        quad_allgather<d4>(hl, hn);
+#pragma unroll
+        for (int k = 0; k < F; ++k) x[k] = X[n * F + k];            // skip concat (model.py:154)
+        emit_records<F, D, LAST>(wl, hn, x, n, q, PRn, QSn, U, Pc, Qc);
+    }
+}
+
+// final edge pass (model.py:156) for one chunk of the caller's segment order; one lane per
+// segment, P rows of the start hits and Q rows of the end hits from LDS windows or global.
+template <int F, int D>
+__global__ __launch_bounds__((Cfg<F, D>::NT)) void k_edge(
+    const int32_t *__restrict__ chunks, const int32_t *__restrict__ src,
+    const int32_t *__restrict__ dst, const float *__restrict__ Pc, const float *__restrict__ Qc,
+    const float *__restrict__ table, float *__restrict__ e, int64_t n_pad, int chunks_per_xcd,
+    int n_chunks)
+{
+    using G = Cfg<F, D>;
+    const float *__restrict__ W2 = table + TL<F, D>::o_flat;   // wave-uniform: scalar loads
+    constexpr int NT = G::NT;
+    constexpr int WIN = G::ed_rec > 0 ? G::ed_rec * D : 4;
+    __shared__ __attribute__((aligned(16))) float win[WIN];
+    const int chunk = (blockIdx.x & 7) * chunks_per_xcd + (blockIdx.x >> 3);
+    if (chunk >= n_chunks) return;
+    const int32_t *cd = chunks + (int64_t)chunk * DESC;
+    const int e0 = cd[0], e1 = cd[1], s_lo = cd[2], s_cnt = cd[3], d_lo = cd[4], d_cnt = cd[5],
+              mode = cd[6];
+    float *winA = win, *winB = win + (s_cnt + 1) * D;
+    if (G::ed_rec > 0 && mode) {
+        stage4<NT>(Pc + (int64_t)s_lo * D, winA, s_cnt * D / 4);
+        stage4<NT>(Pc + n_pad * D, winA + s_cnt * D, D / 4);               // NULL row: P = b1
+        stage4<NT>(Qc + (int64_t)d_lo * D, winB, d_cnt * D / 4);
+        stage4<NT>(Qc + n_pad * D, winB + d_cnt * D, D / 4);               // NULL row: Q = 0
+        __syncthreads();
+    }
+    const float b2 = W2[D];
+    for (int j = e0 + (int)threadIdx.x; j < e1; j += NT) {
+        const int s = src[j], d = dst[j];
+        float p[D], qq[D];
+        if (G::ed_rec > 0 && mode) {
+            load_vec<D>(winA + s * D, p);
+            load_vec<D>(winB + d * D, qq);
+        } else {
+            load_vec<D>(Pc + (int64_t)s * D, p);
+            load_vec<D>(Qc + (int64_t)d * D, qq);
+        }
+        float acc = b2;
+#pragma unroll
+        for (int k = 0; k < D; ++k) acc = fmaf(W2[k], r_f(p[k] + qq[k]), acc);
+        e[j] = r_f(acc);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -401,7 +549,7 @@ struct Ws {
     size_t bytes;
 };
 
-Ws carve(char *b, int64_t n_hits, int table_floats, int D)
+Ws carve(char *b, int64_t n_pad, int table_floats, int D)
 {
     Ws w;
     size_t off = 0;
@@ -410,7 +558,7 @@ Ws carve(char *b, int64_t n_hits, int table_floats, int D)
         off += align256(nfloat * sizeof(float));
         return p;
     };
-    const size_t rec = (size_t)(n_hits + 1) * 2 * D, vec = (size_t)(n_hits + 1) * D;
+    const size_t rec = (size_t)(n_pad + 1) * 2 * D, vec = (size_t)(n_pad + 1) * D;
     w.table = take((size_t)table_floats);
     w.PRa = take(rec); w.PRb = take(rec); w.QSa = take(rec); w.QSb = take(rec);
     w.U = take(vec); w.Pc = take(vec); w.Qc = take(vec);
@@ -423,39 +571,40 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
               hipStream_t s)
 {
     using L = TL<F, D>;
-    const int64_t N = pl->n_hits, E = pl->n_segments;
-    Ws w = carve(ws, N, L::total, D);
+    using G = Cfg<F, D>;
+    const int64_t Np = pl->n_pad, E = pl->n_segments;
+    Ws w = carve(ws, Np, L::total, D);
     GNN_LAUNCH("k_pack", (k_pack<F, D>), 1, 256, s, *p, w.table, w.PRa, w.PRb, w.QSa, w.QSb, w.U,
-               w.Pc, w.Qc, N);
+               w.Pc, w.Qc, Np);
     float *PR = w.PRa, *PRn = w.PRb, *QS = w.QSa, *QSn = w.QSb;
-    if (N > 0) {
-        const unsigned g = (unsigned)((N * 4 + 255) / 256);
+    if (Np > 0) {
+        const unsigned g = (unsigned)((Np * 4 + 255) / 256);
         if (n_iters == 0)
             GNN_LAUNCH("k_input4", (k_input4<F, D, true>), g, 256, s, pl->X, w.table, PR, QS, w.U,
-                       w.Pc, w.Qc, N);
+                       w.Pc, w.Qc, Np);
         else
             GNN_LAUNCH("k_input4", (k_input4<F, D, false>), g, 256, s, pl->X, w.table, PR, QS, w.U,
-                       w.Pc, w.Qc, N);
-        const int n_slices = (int)pl->n_slices;
-        const int bpx = ((n_slices + 3) / 4 + 7) / 8;       // workgroups per XCD group
+                       w.Pc, w.Qc, Np);
+        const int nt = (int)pl->n_tiles;
+        const int tpx = (nt + 7) / 8;
         for (int t = 0; t < n_iters; ++t) {
             if (t + 1 == n_iters)
-                GNN_LAUNCH("k_iter", (k_iter<F, D, true>), 8 * bpx, 256, s, pl->X, w.table, p->b2,
-                           pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PR, QS, w.U, PRn, QSn,
-                           w.Pc, w.Qc, N, n_slices, bpx);
+                GNN_LAUNCH("k_iter", (k_iter<F, D, true>), 8 * tpx, G::NT, s, pl->X, w.table,
+                           pl->tiles, pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PR, QS, w.U,
+                           PRn, QSn, w.Pc, w.Qc, Np, tpx, nt);
             else
-                GNN_LAUNCH("k_iter", (k_iter<F, D, false>), 8 * bpx, 256, s, pl->X, w.table, p->b2,
-                           pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PR, QS, w.U, PRn, QSn,
-                           w.Pc, w.Qc, N, n_slices, bpx);
+                GNN_LAUNCH("k_iter", (k_iter<F, D, false>), 8 * tpx, G::NT, s, pl->X, w.table,
+                           pl->tiles, pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PR, QS, w.U,
+                           PRn, QSn, w.Pc, w.Qc, Np, tpx, nt);
             float *t1 = PR; PR = PRn; PRn = t1;
             float *t2 = QS; QS = QSn; QSn = t2;
         }
     }
     if (E > 0) {
-        const int64_t nblk = (E + 63) / 64;
-        const int bpx = (int)((nblk + 7) / 8);
-        GNN_LAUNCH("k_edge4", (k_edge4<F, D>), 8 * bpx, 256, s, pl->src, pl->dst, w.Pc, w.Qc,
-                   w.table, p->b2, e_out, E, bpx);
+        const int nc = (int)pl->n_chunks;
+        const int cpx = (nc + 7) / 8;
+        GNN_LAUNCH("k_edge", (k_edge<F, D>), 8 * cpx, G::NT, s, pl->chunks, pl->src, pl->dst, w.Pc,
+                   w.Qc, w.table, e_out, Np, cpx, nc);
     }
     return 0;
 }
@@ -476,10 +625,25 @@ int sell_shape_supported(int F, int D)
     return 0;
 }
 
-size_t sell_workspace_bytes(int64_t n_hits, int64_t n_segments, int F, int D)
+int sell_limits(int F, int D, int32_t *out4)
+{
+#define X_(F_, D_)                                               \
+    if (F == F_ && D == D_) {                                    \
+        out4[0] = Cfg<F_, D_>::tile_hits;                        \
+        out4[1] = Cfg<F_, D_>::it_rec;                           \
+        out4[2] = Cfg<F_, D_>::chunk_segments;                   \
+        out4[3] = Cfg<F_, D_>::ed_rec;                           \
+        return 0;                                                \
+    }
+    SELL_FOR_EACH_SHAPE(X_)
+#undef X_
+    return fail(GNN_ERR_UNSUPPORTED, "no fused kernel for input_dim=%d hidden_dim=%d", F, D);
+}
+
+size_t sell_workspace_bytes(int64_t n_pad, int64_t n_segments, int F, int D)
 {
     (void)n_segments;
-#define X_(F_, D_) if (F == F_ && D == D_) return carve(nullptr, n_hits, TL<F_, D_>::total, D).bytes + 256;
+#define X_(F_, D_) if (F == F_ && D == D_) return carve(nullptr, n_pad, TL<F_, D_>::total, D).bytes + 256;
     SELL_FOR_EACH_SHAPE(X_)
 #undef X_
     return 0;
@@ -488,7 +652,7 @@ size_t sell_workspace_bytes(int64_t n_hits, int64_t n_segments, int F, int D)
 int sell_forward(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e_out, void *ws,
                  size_t ws_bytes, hipStream_t s)
 {
-    const size_t need = sell_workspace_bytes(pl->n_hits, pl->n_segments, p->F, p->D);
+    const size_t need = sell_workspace_bytes(pl->n_pad, pl->n_segments, p->F, p->D);
     if (need == 0) return fail(GNN_ERR_UNSUPPORTED, "no fused kernel for input_dim=%d hidden_dim=%d", p->F, p->D);
     if (!ws || ws_bytes < need) return fail(GNN_ERR_WORKSPACE, "workspace too small: need %zu bytes", need);
     char *base = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);

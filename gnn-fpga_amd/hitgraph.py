@@ -77,12 +77,16 @@ class HitGraphBatch:
         self.y = None if y is None else t(np.ascontiguousarray(y, dtype=np.float32))
         self.plan = None
 
-    def build_plan(self):
-        """Relabel + SELL-16 execution plan of the fused kernels (plan.py); built once, on the
-        host, from the host copy of the index arrays, then moved to this batch's device."""
-        if self.plan is None:
+    def build_plan(self, hidden_dim):
+        """Tiles + windows + SELL-16 execution plan of the fused kernels (plan.py); built once,
+        on the host, for the kernel shape (input_dim = n_features, hidden_dim), then moved to
+        this batch's device."""
+        if self.plan is None or self.plan.hidden_dim != hidden_dim:
+            from . import _lib
             from .plan import SellPlan
-            self.plan = SellPlan(self).to(self.X.device)
+            self.plan = SellPlan(self, _lib.plan_limits(self.n_features, hidden_dim))
+            self.plan.hidden_dim = hidden_dim
+            self.plan.to(self.X.device)
         return self.plan
 
     # -- constructors ------------------------------------------------------------------

@@ -178,13 +178,16 @@ class SegmentClassifier(nn.Module):
             raise _lib.GnnHipError("SegmentClassifier.forward needs tensors on a ROCm device; "
                                    "there is no CPU path")
         fused = not trace and self.use_plan and _lib.plan_shape_supported(F, D)
-        need = (_lib.plan_workspace_bytes if fused else _lib.workspace_bytes)(
-            batch.n_hits, batch.n_segments, F, D)
+        if fused:
+            plan = batch.build_plan(D)
+            need = _lib.plan_workspace_bytes(plan.n_pad, plan.n_segments, F, D)
+        else:
+            need = _lib.workspace_bytes(batch.n_hits, batch.n_segments, F, D)
         if (self._workspace is None or self._workspace.numel() < need or
                 self._workspace.device != batch.X.device):
             self._workspace = torch.empty(need, dtype=torch.uint8, device=batch.X.device)
         if fused:     # relabel + SELL-16 plan, fused iteration kernels (csrc/sell_pipeline.hip)
-            res = _lib.segclf_forward_plan(batch.build_plan(), self.effective_weights(), F, D,
+            res = _lib.segclf_forward_plan(plan, self.effective_weights(), F, D,
                                            self.n_iters, workspace=self._workspace)
         else:         # CSR kernels, one per reference module (csrc/gnn_kernels.hip); traces
             res = _lib.segclf_forward(batch, self.effective_weights(), F, D, self.n_iters,

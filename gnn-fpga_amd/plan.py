@@ -1,94 +1,254 @@
-"""Execution plan for the fused message-passing kernels: relabelled hits + SELL-16 lists.
+"""Execution plan for the fused message-passing kernels: tiles, windows, SELL-16 lists.
 
 Built once per batch on the host (like the CSR of `hitgraph.py`), reused by every
-iteration and every epoch.  Nothing the caller sees changes: scores are per segment,
-in the caller's segment order; hit numbering is internal to the plan.
+iteration and every epoch.  Nothing the caller sees changes: scores are per segment, in
+the caller's segment order; hit numbering is internal to the plan.
 
-1. Relabel.  Inside each graph, hits are renumbered by (in-degree, out-degree)
-   descending.  A wavefront processes a *slice* of 16 consecutive hits (4 lanes per hit),
-   so after the sort all 16 hits of a slice have (nearly) the same number of segments:
-   no divergence in the neighbour loop and almost no padding.
-2. SELL-16 ("sliced ELLPACK", slice height 16).  For slice s the neighbour list is stored
-   column-major: entry k of hit i of the slice sits at `off[s] + 16*k + i`, so the 16
-   hits of a wavefront read 64 contiguous bytes per step.  Lists are padded to the
-   slice's longest list with the NULL hit id `n_hits`, whose stored record is
-   [P = b1, R = 0]: a padded step adds exactly 0.
-   Within a hit, neighbours keep ascending segment id (fixed summation order).
-3. `src`/`dst` of every segment in the new numbering (caller's segment order) for the
-   final edge pass; padded segments (-1) map to the NULL hit.
+1. Levels.  Every hit gets a topological level (longest path from a hit without incoming
+   segments; for a layered detector graph this recovers the detector layer).  Hits are
+   ordered by (graph, level): all segments then join hits of neighbouring id ranges.
+2. Tiles.  Consecutive (graph, level) units are merged greedily into tiles of at most
+   `tile_hits` hits (one workgroup each); a unit larger than that is split.  A tile's
+   neighbour records therefore lie in two contiguous id windows - the start hits of its
+   incoming segments (`in` window) and the end hits of its outgoing segments (`out`
+   window).  If both windows fit the LDS budget the tile runs in LDS mode: the kernel
+   stages the windows with coalesced reads and gathers from LDS; lists then hold
+   window-relative indices.  Otherwise (irregular graph) the tile gathers from global
+   memory and lists hold absolute ids.
+3. Inside a tile hits are sorted by (in-degree, out-degree) descending and the tile is
+   padded to a multiple of 16 hits, so each 16-hit slice (one wavefront, 4 lanes per hit)
+   has near-uniform list lengths: SELL-16 ("sliced ELLPACK") with ~3 % padding.  Entry k of
+   hit i of slice s sits at `off[s] + 16*k + i`; padded entries point at the window's NULL
+   record (R/S half zero: adds exactly 0).  Neighbours keep ascending segment id.
+4. Final edge pass: segments stay in the caller's order, cut into chunks of `chunk_segments`;
+   per chunk the src / dst windows are computed the same way (LDS or global mode).
 
-Arrays (all int32 / float32, `to(device)` uploads them):
-    X        [n_hits+1, F]  relabelled features, last row zero (NULL hit)
-    src,dst  [n_segments]   relabelled endpoints, NULL hit for padded segments
-    in_off   [n_slices+1]   SELL offsets of the lists of segments ENDING at a hit
-    in_nbr   [in_off[-1]]   start hit of each such segment (or NULL)
-    out_off / out_nbr       the same for segments STARTING at a hit (entries = end hits)
-    perm     [n_hits]       new id -> caller's hit id (tests / traces only)
+All arrays int32 / float32; `to(device)` uploads them.  `n_pad` = padded hit count; the
+NULL hit has id `n_pad`.
 """
 import numpy as np
 import torch
 
 SLICE = 16
+TILE_DESC = 8    # ints per tile:  slice_begin, slice_end, in_lo, in_cnt, out_lo, out_cnt, mode, 0
+CHUNK_DESC = 8   # ints per chunk: seg_begin, seg_end, src_lo, src_cnt, dst_lo, dst_cnt, mode, 0
 
 
-def _sell(key_new, other_new, n_hits, n_slices):
-    """SELL-16 lists: for every hit (new ids) the `other_new` endpoint of each valid segment
-    whose `key_new` endpoint is that hit, ascending segment id."""
-    valid = np.flatnonzero(key_new < n_hits)
-    k = key_new[valid]
-    order = np.argsort(k, kind="stable")
-    k = k[order]
-    oth = other_new[valid][order]
-    deg = np.bincount(k, minlength=n_slices * SLICE)
-    ptr = np.zeros(deg.shape[0] + 1, dtype=np.int64)
+def topological_levels(src, dst, n, max_iter=64):
+    """level[n] = longest path (in segments) from a hit with no incoming segment.
+    Graphs with cycles stop at `max_iter` (any labelling is valid, only locality suffers)."""
+    level = np.zeros(n, dtype=np.int32)
+    if src.size == 0:
+        return level
+    order = np.argsort(dst, kind="stable")
+    s, d = src[order], dst[order]
+    uniq, start = np.unique(d, return_index=True)
+    for _ in range(max_iter):
+        cand = np.maximum.reduceat(level[s] + 1, start)
+        new = level.copy()
+        new[uniq] = np.maximum(new[uniq], cand)
+        if np.array_equal(new, level):
+            break
+        level = new
+    return level
+
+
+def _node_minmax(key, other, n):
+    """Per hit: min / max of `other` over segments whose `key` endpoint is the hit."""
+    order = np.argsort(key, kind="stable")
+    k, o = key[order], other[order]
+    lo = np.full(n, np.iinfo(np.int64).max, dtype=np.int64)
+    hi = np.full(n, -1, dtype=np.int64)
+    if k.size:
+        uniq, start = np.unique(k, return_index=True)
+        lo[uniq] = np.minimum.reduceat(o, start)
+        hi[uniq] = np.maximum.reduceat(o, start)
+    return lo, hi
+
+
+def _range_minmax(lo, hi, bounds):
+    """min(lo) / max(hi) over consecutive ranges [bounds[i], bounds[i+1])."""
+    rl = np.minimum.reduceat(lo, bounds[:-1])
+    rh = np.maximum.reduceat(hi, bounds[:-1])
+    return rl, rh
+
+
+def _sell(key_new, other_rel, n_pad, null_of_slice):
+    """SELL-16 lists over padded hit ids; `other_rel` is the stored value per segment,
+    `null_of_slice[s]` the padding value of slice s."""
+    n_slices = n_pad // SLICE
+    order = np.argsort(key_new, kind="stable")
+    k = key_new[order]
+    oth = other_rel[order]
+    deg = np.bincount(k, minlength=n_pad)
+    ptr = np.zeros(n_pad + 1, dtype=np.int64)
     np.cumsum(deg, out=ptr[1:])
-    pos = np.arange(k.shape[0], dtype=np.int64) - ptr[k]          # rank inside the hit's list
-    slen = deg.reshape(n_slices, SLICE).max(axis=1).astype(np.int64)
+    pos = np.arange(k.shape[0], dtype=np.int64) - ptr[k]
+    slen = deg.reshape(n_slices, SLICE).max(axis=1).astype(np.int64) if n_slices else \
+        np.zeros(0, np.int64)
     off = np.zeros(n_slices + 1, dtype=np.int64)
     np.cumsum(slen * SLICE, out=off[1:])
     if off[-1] >= 2 ** 31:
         raise ValueError("SELL list exceeds int32 index range")
-    nbr = np.full(int(off[-1]), n_hits, dtype=np.int32)           # NULL-padded
+    nbr = np.repeat(null_of_slice.astype(np.int32), (slen * SLICE).astype(np.int64))
     nbr[off[k // SLICE] + pos * SLICE + (k % SLICE)] = oth
+    # the kernel's prefetching list stream reads up to 11 steps past a list's end
+    nbr = np.concatenate([nbr, np.zeros(12 * SLICE, dtype=np.int32)])
     return off.astype(np.int32), nbr
 
 
 class SellPlan:
-    def __init__(self, batch):
-        """batch: a HitGraphBatch (host tensors)."""
+    def __init__(self, batch, limits):
+        """batch: HitGraphBatch; limits: dict(tile_hits, iter_records, chunk_segments,
+        edge_records) from the library (`_lib.plan_limits(F, D)`): LDS budgets in records."""
         src = batch.src.cpu().numpy().astype(np.int64)
         dst = batch.dst.cpu().numpy().astype(np.int64)
         X = batch.X.cpu().numpy()
-        n = batch.n_hits
+        n, E = batch.n_hits, batch.n_segments
+        tile_hits = int(limits["tile_hits"])
         ok = src >= 0
-        deg_in = np.bincount(dst[ok], minlength=n)
-        deg_out = np.bincount(src[ok], minlength=n)
+        vs, vd = src[ok], dst[ok]
+        deg_in = np.bincount(vd, minlength=n)
+        deg_out = np.bincount(vs, minlength=n)
         gid = np.zeros(n, dtype=np.int64)
         if batch.n_graphs > 1:
-            gid[batch.hit_ptr[1:-1]] = 1
+            np.add.at(gid, batch.hit_ptr[1:-1][batch.hit_ptr[1:-1] < n], 1)
             gid = np.cumsum(gid)
-        perm = np.lexsort((-deg_out, -deg_in, gid))                # new id -> old id
-        inv = np.empty(n + 1, dtype=np.int64)
-        inv[perm] = np.arange(n)
-        inv[n] = n                                                 # -1 (padded) -> NULL
-        self.n_hits, self.n_segments = n, batch.n_segments
+        level = topological_levels(vs, vd, n)
+
+        # -- (graph, level) units -> tiles ------------------------------------------------
+        base = np.lexsort((level, gid))                       # position -> old id
+        ukey = gid[base] * (int(level.max(initial=0)) + 1) + level[base]
+        ustart = np.flatnonzero(np.r_[True, ukey[1:] != ukey[:-1]]) if n else np.zeros(0, np.int64)
+        usize = np.diff(np.r_[ustart, n])
+        tile_bounds = [0]                                     # in base positions
+        cur = 0
+        for st, sz in zip(ustart.tolist(), usize.tolist()):
+            if sz > tile_hits:                                # split a big unit
+                if cur:
+                    tile_bounds.append(st)
+                    cur = 0
+                for a in range(st + tile_hits, st + sz, tile_hits):
+                    tile_bounds.append(a)
+                tile_bounds.append(st + sz)
+                continue
+            if cur + sz > tile_hits:
+                tile_bounds.append(st)
+                cur = 0
+            cur += sz
+        if n and tile_bounds[-1] != n:
+            tile_bounds.append(n)
+        tile_bounds = np.asarray(tile_bounds, dtype=np.int64)
+        n_tiles = len(tile_bounds) - 1
+        tsize = np.diff(tile_bounds)
+        tile_of_pos = np.repeat(np.arange(n_tiles), tsize)
+        # degree sort inside each tile
+        order = np.lexsort((-deg_out[base], -deg_in[base], tile_of_pos))
+        old_of_rank = base[order]                             # tile-major, degree-sorted
+        tpad = (tsize + SLICE - 1) // SLICE * SLICE
+        tpad_off = np.zeros(n_tiles + 1, dtype=np.int64)
+        np.cumsum(tpad, out=tpad_off[1:])
+        n_pad = int(tpad_off[-1])
+        rank_in_tile = np.arange(n, dtype=np.int64) - np.repeat(tile_bounds[:-1], tsize)
+        new_of_rank = np.repeat(tpad_off[:-1], tsize) + rank_in_tile
+        inv = np.empty(n + 1, dtype=np.int64)                 # old id -> new (padded) id
+        inv[old_of_rank] = new_of_rank
+        inv[n] = n_pad                                        # padded segment -> NULL hit
+        perm = np.full(n_pad, -1, dtype=np.int64)             # new id -> old id (-1 = dummy)
+        perm[new_of_rank] = old_of_rank
+
+        self.n_hits, self.n_pad, self.n_segments = n, n_pad, E
         self.n_features = batch.n_features
-        self.n_slices = (n + SLICE - 1) // SLICE
+        self.n_slices = n_pad // SLICE
+        self.n_tiles = n_tiles
         src_new = inv[np.where(ok, src, n)]
         dst_new = inv[np.where(ok, dst, n)]
-        in_off, in_nbr = _sell(dst_new, src_new, n, self.n_slices)
-        out_off, out_nbr = _sell(src_new, dst_new, n, self.n_slices)
-        Xp = np.zeros((n + 1, X.shape[1]), dtype=np.float32)
-        Xp[:n] = X[perm]
+        vs_new, vd_new = src_new[ok], dst_new[ok]
+
+        # -- per-tile windows -------------------------------------------------------------
+        tb = tpad_off                                         # tile bounds in new ids
+        in_lo_n, in_hi_n = _node_minmax(vd_new, vs_new, n_pad)
+        out_lo_n, out_hi_n = _node_minmax(vs_new, vd_new, n_pad)
+        if n_tiles:
+            in_lo, in_hi = _range_minmax(in_lo_n, in_hi_n, tb)
+            out_lo, out_hi = _range_minmax(out_lo_n, out_hi_n, tb)
+        else:
+            in_lo = in_hi = out_lo = out_hi = np.zeros(0, np.int64)
+        in_cnt = np.where(in_hi >= 0, in_hi - in_lo + 1, 0)
+        out_cnt = np.where(out_hi >= 0, out_hi - out_lo + 1, 0)
+        in_lo = np.where(in_cnt > 0, in_lo, 0)
+        out_lo = np.where(out_cnt > 0, out_lo, 0)
+        lds_mode = (in_cnt + out_cnt + 2) <= int(limits["iter_records"])
+        tile_of_new = np.repeat(np.arange(n_tiles), tpad)
+        slice_tile = tile_of_new[::SLICE] if n_pad else np.zeros(0, np.int64)
+
+        def lists(key_new, other_new, lo, cnt):
+            t = tile_of_new[key_new]
+            rel = np.where(lds_mode[t], other_new - lo[t], other_new)
+            null = np.where(lds_mode[slice_tile], cnt[slice_tile], n_pad)
+            return _sell(key_new, rel.astype(np.int32), n_pad, null)
+
+        in_off, in_nbr = lists(vd_new, vs_new, in_lo, in_cnt)
+        out_off, out_nbr = lists(vs_new, vd_new, out_lo, out_cnt)
+        tiles = np.zeros((n_tiles, TILE_DESC), dtype=np.int32)
+        tiles[:, 0] = tb[:-1] // SLICE
+        tiles[:, 1] = tb[1:] // SLICE
+        tiles[:, 2], tiles[:, 3] = in_lo, in_cnt
+        tiles[:, 4], tiles[:, 5] = out_lo, out_cnt
+        tiles[:, 6] = lds_mode
+
+        # -- final edge pass: chunks of the caller's segment order --------------------------
+        CH = int(limits["chunk_segments"])
+        cb = np.arange(0, E + CH, CH, dtype=np.int64)
+        cb[-1] = E
+        if E == 0:
+            cb = np.zeros(1, np.int64)
+        n_chunks = len(cb) - 1
+        big = np.iinfo(np.int64).max
+        s_lo_e = np.where(ok, src_new, big)
+        s_hi_e = np.where(ok, src_new, -1)
+        d_lo_e = np.where(ok, dst_new, big)
+        d_hi_e = np.where(ok, dst_new, -1)
+        if n_chunks:
+            s_lo, s_hi = _range_minmax(s_lo_e, s_hi_e, cb)
+            d_lo, d_hi = _range_minmax(d_lo_e, d_hi_e, cb)
+        else:
+            s_lo = s_hi = d_lo = d_hi = np.zeros(0, np.int64)
+        s_cnt = np.where(s_hi >= 0, s_hi - s_lo + 1, 0)
+        d_cnt = np.where(d_hi >= 0, d_hi - d_lo + 1, 0)
+        s_lo = np.where(s_cnt > 0, s_lo, 0)
+        d_lo = np.where(d_cnt > 0, d_lo, 0)
+        c_lds = (s_cnt + d_cnt + 2) <= int(limits["edge_records"])
+        chunk_of_seg = np.repeat(np.arange(n_chunks), np.diff(cb))
+        c = chunk_of_seg
+        src_st = np.where(c_lds[c], np.where(ok, src_new - s_lo[c], s_cnt[c]), src_new)
+        dst_st = np.where(c_lds[c], np.where(ok, dst_new - d_lo[c], d_cnt[c]), dst_new)
+        chunks = np.zeros((n_chunks, CHUNK_DESC), dtype=np.int32)
+        chunks[:, 0], chunks[:, 1] = cb[:-1], cb[1:]
+        chunks[:, 2], chunks[:, 3] = s_lo, s_cnt
+        chunks[:, 4], chunks[:, 5] = d_lo, d_cnt
+        chunks[:, 6] = c_lds
+        self.n_chunks = n_chunks
+
+        Xp = np.zeros((n_pad + 1, X.shape[1]), dtype=np.float32)
+        Xp[new_of_rank] = X[old_of_rank]
         t = torch.from_numpy
         self.X = t(Xp)
-        self.src, self.dst = t(src_new.astype(np.int32)), t(dst_new.astype(np.int32))
+        self.src, self.dst = t(src_st.astype(np.int32)), t(dst_st.astype(np.int32))
         self.in_off, self.in_nbr = t(in_off), t(in_nbr)
         self.out_off, self.out_nbr = t(out_off), t(out_nbr)
+        self.tiles, self.chunks = t(tiles.reshape(-1)), t(chunks.reshape(-1))
         self.perm = t(perm.astype(np.int32))
-        self.padding = (int(in_off[-1]) + int(out_off[-1])) / max(1, 2 * int(ok.sum())) - 1.0
+        nv = max(1, int(ok.sum()))
+        self.padding = (int(in_off[-1]) + int(out_off[-1])) / (2 * nv) - 1.0
+        self.lds_tile_fraction = float(lds_mode.mean()) if n_tiles else 1.0
+        self.lds_chunk_fraction = float(c_lds.mean()) if n_chunks else 1.0
+        # host copies for tests
+        self.src_abs, self.dst_abs = src_new, dst_new
+        self.level = level
 
-    _TENSORS = ("X", "src", "dst", "in_off", "in_nbr", "out_off", "out_nbr", "perm")
+    _TENSORS = ("X", "src", "dst", "in_off", "in_nbr", "out_off", "out_nbr", "tiles", "chunks",
+                "perm")
 
     def to(self, device):
         for k in self._TENSORS:

@@ -58,15 +58,22 @@ typedef struct gnn_graph {
 } gnn_graph_t;
 
 /* Execution plan of the fused pipeline (built once per batch by the host; see
- * gnn-fpga_amd/plan.py): hits relabelled by degree inside each graph, neighbour lists in
- * SELL-16 layout (entry k of hit i of 16-hit slice s at off[s] + 16*k + i), padded with the
- * NULL hit id n_hits.  Scores are still per segment in the caller's segment order. */
+ * gnn-fpga_amd/plan.py).  Hits are renumbered by (graph, topological level), cut into tiles of
+ * <= tile_hits hits (one workgroup each), degree-sorted inside a tile and padded to 16-hit
+ * slices; n_pad = padded hit count, NULL hit id = n_pad.  Neighbour lists are SELL-16: entry k
+ * of hit i of slice s at off[s] + 16*k + i, padded with the NULL entry.  A tile / chunk whose
+ * neighbour id windows fit the LDS budget (gnn_plan_limits) runs in LDS mode (mode = 1): its
+ * list / endpoint entries are window-relative and NULL = window size; otherwise entries are
+ * absolute padded ids.  Scores stay per segment in the caller's segment order.
+ *   tile  descriptor, 8 ints: slice_begin, slice_end, in_lo, in_cnt, out_lo, out_cnt, mode, 0
+ *   chunk descriptor, 8 ints: seg_begin, seg_end, src_lo, src_cnt, dst_lo, dst_cnt, mode, 0 */
 typedef struct gnn_plan {
-    const float *X;                      /* [n_hits+1, F] relabelled features, last row zero */
-    const int32_t *src, *dst;            /* [n_segments] relabelled endpoints, n_hits = padded */
-    const int32_t *in_off, *in_nbr;      /* [n_slices+1], [in_off[n_slices]]  segments ending at a hit -> start hit */
-    const int32_t *out_off, *out_nbr;    /* [n_slices+1], [out_off[n_slices]] segments starting at a hit -> end hit */
-    int64_t n_hits, n_segments, n_slices;
+    const float *X;                      /* [n_pad+1, F] renumbered features, dummy/NULL rows zero */
+    const int32_t *src, *dst;            /* [n_segments] endpoints (window-relative or absolute)   */
+    const int32_t *in_off, *in_nbr;      /* [n_pad/16+1], [in_off[last]]  segments ending at a hit -> start hit */
+    const int32_t *out_off, *out_nbr;    /* [n_pad/16+1], [out_off[last]] segments starting at a hit -> end hit */
+    const int32_t *tiles, *chunks;       /* [n_tiles*8], [n_chunks*8] descriptors                  */
+    int64_t n_pad, n_segments, n_tiles, n_chunks;
 } gnn_plan_t;
 
 int gnn_abi_version(void);
@@ -115,11 +122,15 @@ int gnn_segclf_forward(const gnn_graph_t *g, const gnn_params_t *p, int32_t n_it
  * One fused kernel per message-passing iteration (edge scores are recomputed at both
  * endpoints from per-hit partial products instead of being stored), one final edge kernel.
  * e_out [n_segments].  Workspace size from gnn_plan_workspace_bytes. */
-size_t gnn_plan_workspace_bytes(int64_t n_hits, int64_t n_segments, int32_t F, int32_t D);
+size_t gnn_plan_workspace_bytes(int64_t n_pad, int64_t n_segments, int32_t F, int32_t D);
 int gnn_segclf_forward_plan(const gnn_plan_t *plan, const gnn_params_t *p, int32_t n_iters,
                             float *e_out, void *workspace, size_t workspace_bytes, void *stream);
 /* 1 if the fused pipeline has kernels for this (input_dim, hidden_dim). */
 int gnn_plan_shape_supported(int32_t F, int32_t D);
+/* Plan-building limits for a shape: out4 = { tile_hits, iter_records, chunk_segments,
+ * edge_records } - the tile / chunk sizes and the LDS window budgets (in records of 2D floats
+ * for the iteration kernel, rows of D floats for the edge kernel). */
+int gnn_plan_limits(int32_t F, int32_t D, int32_t *out4);
 
 /* Per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).
  * gnn_profile_begin(capacity) arms recording of up to `capacity` kernel launches;

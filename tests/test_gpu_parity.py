@@ -51,7 +51,7 @@ def test_fused_plan_forward_matches_reference_golden(hip, name):
         pytest.skip("no fused kernel for F=%d D=%d" % (fx.F, fx.D))
     dev = torch.device("cuda:0")
     batch = HitGraphBatch.from_graphs([fx.graph]).to(dev)
-    plan = batch.build_plan()
+    plan = batch.build_plan(fx.D)
     e = hip.segclf_forward_plan(plan, _weights(fx, dev), fx.F, fx.D, fx.n_iters)
     torch.cuda.synchronize()
     assert np.abs(e.cpu().numpy() - fx.scores).max() < TOL

@@ -1,0 +1,138 @@
+"""Host-side checks of the execution plan (gnn-fpga_amd/plan.py): a numpy emulation of what the
+fused kernels do with the plan arrays (tiles, windows, SELL-16 lists, chunks) must reproduce
+the oracle.  Runs without a GPU (the limits come from the library's host-side query)."""
+import numpy as np
+import pytest
+
+from golden_util import Fixture
+from gnn_fpga_amd import HitGraphBatch, _lib, synth
+from gnn_fpga_amd.plan import SLICE, SellPlan
+from oracle import index_c
+
+
+def emulate(plan, params, n_iters):
+    """float64 emulation of csrc/sell_pipeline.hip driven by the plan arrays only."""
+    p = {k: np.asarray(v, np.float64) for k, v in params.items()}
+    D, F = p["input_network.0.weight"].shape
+    C = D + F
+    W1, b1 = p["edge_network.network.0.weight"], p["edge_network.network.0.bias"]
+    W2, b2 = p["edge_network.network.2.weight"][0], p["edge_network.network.2.bias"][0]
+    W3, b3 = p["node_network.network.0.weight"], p["node_network.network.0.bias"]
+    W4, b4 = p["node_network.network.2.weight"], p["node_network.network.2.bias"]
+    X = plan.X.numpy().astype(np.float64)
+    Np = plan.n_pad
+    sig = lambda z: 1 / (1 + np.exp(-z))
+
+    def records(Hn):           # rows 0..Np-1 real/dummy, row Np = NULL
+        H = np.concatenate([Hn, X[:Np]], axis=1)
+        P = np.vstack([H @ W1[:, :C].T + b1, b1[None]])
+        R = np.vstack([H @ W3[:, :C].T, np.zeros((1, D))])
+        Q = np.vstack([H @ W1[:, C:].T, np.zeros((1, D))])
+        S = np.vstack([H @ W3[:, C:2 * C].T, np.zeros((1, D))])
+        U = H @ W3[:, 2 * C:].T + b3
+        return P, R, Q, S, U
+
+    P, R, Q, S, U = records(np.tanh(X[:Np] @ p["input_network.0.weight"].T +
+                                    p["input_network.0.bias"]))
+    tiles = plan.tiles.numpy().reshape(-1, 8)
+    in_off, in_nbr = plan.in_off.numpy(), plan.in_nbr.numpy()
+    out_off, out_nbr = plan.out_off.numpy(), plan.out_nbr.numpy()
+    for _ in range(n_iters):
+        acc = U.copy()
+        for (s0, s1, in_lo, in_cnt, out_lo, out_cnt, mode, _z) in tiles:
+            for sl in range(s0, s1):
+                for i in range(SLICE):
+                    n = sl * SLICE + i
+                    for off, nbr, A, B, own, lo, cnt in (
+                            (in_off, in_nbr, P, R, Q[n], in_lo, in_cnt),
+                            (out_off, out_nbr, Q, S, P[n], out_lo, out_cnt)):
+                        for k in range((off[sl + 1] - off[sl]) // SLICE):
+                            ent = nbr[off[sl] + k * SLICE + i]
+                            if mode:      # window-relative, NULL = cnt
+                                assert 0 <= ent <= cnt
+                                idx = Np if ent == cnt else lo + ent
+                            else:
+                                idx = ent
+                            e = sig(W2 @ np.tanh(A[idx] + own) + b2)
+                            acc[n] += e * B[idx]
+        Hn = np.tanh(np.tanh(acc) @ W4.T + b4)
+        P, R, Q, S, U = records(Hn)
+    chunks = plan.chunks.numpy().reshape(-1, 8)
+    src, dst = plan.src.numpy(), plan.dst.numpy()
+    out = np.zeros(plan.n_segments)
+    for (e0, e1, s_lo, s_cnt, d_lo, d_cnt, mode, _z) in chunks:
+        for j in range(e0, e1):
+            s, d = src[j], dst[j]
+            if mode:
+                s = Np if s == s_cnt else s_lo + s
+                d = Np if d == d_cnt else d_lo + d
+            out[j] = sig(W2 @ np.tanh(P[s] + Q[d]) + b2)
+    return out
+
+
+LIMITS = [None,                                                     # the library's real budgets
+          dict(tile_hits=64, iter_records=40, chunk_segments=50, edge_records=60),   # mixed modes
+          dict(tile_hits=32, iter_records=0, chunk_segments=64, edge_records=0)]     # all global
+
+
+@pytest.mark.parametrize("name", ["sector_s0", "muon_s1", "ragged_isolated_s7",
+                                  "ragged_one_segment", "toy2d_s0"])
+@pytest.mark.parametrize("lim", LIMITS)
+def test_plan_emulation_matches_golden(name, lim):
+    fx = Fixture(name)
+    batch = HitGraphBatch.from_graphs([fx.graph])
+    plan = SellPlan(batch, lim or _lib.plan_limits(fx.F, fx.D))
+    e = emulate(plan, fx.effective_params(), fx.n_iters)
+    assert np.abs(e - fx.scores).max() < 2e-6
+
+
+def test_plan_on_padded_ragged_batch():
+    rng = np.random.default_rng(3)
+    graphs = [synth.layered_graph(int(rng.integers(20, 90)), int(rng.integers(10, 300)), 3,
+                                  seed=50 + i) for i in range(5)]
+    fx = Fixture("sector_s0")
+    b = HitGraphBatch.from_graphs(graphs)
+    # append padded segments (src = dst = -1), as a dense zero-padded batch produces them
+    src = np.concatenate([b.src.numpy(), -np.ones(7, np.int32)])
+    dst = np.concatenate([b.dst.numpy(), -np.ones(7, np.int32)])
+    bp = HitGraphBatch(b.X.numpy(), src, dst, hit_ptr=b.hit_ptr)
+    for lim in LIMITS[:2]:
+        plan = SellPlan(bp, lim or _lib.plan_limits(3, 8))
+        e = emulate(plan, fx.params, 2)
+        ref = index_c.segment_classifier(b.X.numpy(), src, dst, fx.params, 2)
+        assert np.abs(e - ref).max() < 2e-6
+
+
+def test_plan_structure_at_c3_shape():
+    """Layered 10k-hit graphs: every tile and (almost) every chunk runs in LDS mode, list
+    padding stays small, levels recover the layers."""
+    graphs = [synth.layered_graph(10000, 100000, 3, seed=s) for s in range(3)]
+    b = HitGraphBatch.from_graphs(graphs)
+    plan = SellPlan(b, _lib.plan_limits(3, 8))
+    assert plan.n_pad % SLICE == 0 and plan.n_pad >= b.n_hits
+    assert plan.level.max() == 9
+    assert plan.lds_tile_fraction == 1.0
+    assert plan.lds_chunk_fraction > 0.85
+    assert plan.padding < 0.15
+    perm = plan.perm.numpy()
+    real = perm[perm >= 0]
+    assert np.array_equal(np.sort(real), np.arange(b.n_hits))
+    # endpoints in absolute padded ids reproduce the caller's segments
+    assert np.array_equal(perm[plan.src_abs], b.src.numpy())
+    assert np.array_equal(perm[plan.dst_abs], b.dst.numpy())
+
+
+def test_plan_handles_cycles_and_empty():
+    # a graph with a cycle: levels do not converge, plan must still be valid
+    X = np.random.default_rng(0).uniform(-1, 1, (6, 3)).astype(np.float32)
+    src = np.array([0, 1, 2, 3, 4, 0], np.int32)
+    dst = np.array([1, 2, 0, 4, 5, 3], np.int32)
+    fx = Fixture("sector_s0")
+    b = HitGraphBatch(X, src, dst)
+    plan = SellPlan(b, _lib.plan_limits(3, 8))
+    e = emulate(plan, fx.params, 3)
+    ref = index_c.segment_classifier(X, src, dst, fx.params, 3)
+    assert np.abs(e - ref).max() < 2e-6
+    empty = HitGraphBatch(X, np.zeros(0, np.int32), np.zeros(0, np.int32))
+    pe = SellPlan(empty, _lib.plan_limits(3, 8))
+    assert pe.n_segments == 0 and pe.n_chunks == 0 and emulate(pe, fx.params, 2).shape == (0,)
