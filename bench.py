@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--graphs", type=int, default=256, help="graphs per launch per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--global-gather", action="store_true",
+                    help="experiment: disable the LDS windows (gather records from global memory)")
     ap.add_argument("--pmc-traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate "
                          "rocprofv3 --pmc pass (profiles/), corrected per MI355X_MICROARCH.md")
@@ -105,7 +107,7 @@ def main():
     graphs = [synth.layered_graph(N_HITS, N_SEG, F, seed=rank * G + i) for i in range(G)]
     batch = HitGraphBatch.from_graphs(graphs).to(dev)
     t_plan = time.perf_counter()
-    plan = batch.build_plan(D)     # relabel + SELL-16 lists: once per batch, like the CSR build
+    plan = batch.build_plan(D, {"iter_records": 0, "edge_records": 0} if args.global_gather else None)     # relabel + SELL-16 lists: once per batch, like the CSR build
     t_plan = time.perf_counter() - t_plan
     torch.manual_seed(0)
     model = SegmentClassifier(input_dim=F, hidden_dim=D, n_iters=T).to(dev).eval()

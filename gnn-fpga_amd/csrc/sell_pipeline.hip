@@ -40,6 +40,8 @@
 // contiguous range of tiles (whole graphs stay in one XCD's L2).
 #include "common.h"
 
+#include <cstdlib>
+
 namespace {
 using namespace gnn;
 
@@ -52,16 +54,18 @@ constexpr int DESC = 8;   // ints per tile / chunk descriptor (plan.py)
 template <int F, int D>
 struct TL {
     static constexpr int d4 = D / 4, C = F + D;
-    static constexpr int o_w2 = 0;                  // [d4]         W2[r]
-    static constexpr int o_bin = o_w2 + d4;         // [d4]         bin[r]
-    static constexpr int o_Win = o_bin + d4;        // [F][d4]      Win[r][k]
-    static constexpr int o_b4 = o_Win + F * d4;     // [d4]         b4[r]
-    static constexpr int o_W4 = o_b4 + d4;          // [D][d4]      W4[r][k]
-    static constexpr int o_m = o_W4 + D * d4;       // 5 x { [d4] bias, [C][d4] weights }
+    static constexpr int a4(int x) { return (x + 3) & ~3; }   // segments start 16-byte aligned
+    static constexpr int o_w2 = 0;                       // [d4]            W2[r]
+    static constexpr int o_in = a4(o_w2 + d4);           // [d4] bin[r], [F][d4] Win[r][k]
+    static constexpr int in_sz = d4 + F * d4;
+    static constexpr int o_4 = a4(o_in + in_sz);         // [d4] b4[r],  [D][d4] W4[r][k]
+    static constexpr int w4_sz = d4 + D * d4;
+    static constexpr int o_m = a4(o_4 + w4_sz);          // 5 x { [d4] bias, [C][d4] weights }
     static constexpr int m_sz = d4 + C * d4;
-    static constexpr int o_b2 = o_m + 5 * m_sz;     // [1]  scaled output bias (see k_pack)
+    static constexpr int m_st = a4(m_sz);                // stride between the 5 blocks
+    static constexpr int o_b2 = o_m + 5 * m_st;          // [1]  scaled output bias (see k_pack)
     static constexpr int used = o_b2 + 1;
-    static constexpr int stride = ((used + 3) & ~3) + 4;
+    static constexpr int stride = a4(used) + 4;
     static constexpr int o_flat = 4 * stride;       // [D] scaled W2 in natural order, [1] scaled b2
     static constexpr int total = o_flat + ((D + 1 + 3) & ~3);
 };
@@ -94,20 +98,26 @@ __global__ __launch_bounds__(256) void k_pack(gnn_params_t p, float *__restrict_
                 for (int k = 0; k < D; ++k) sw += p.W2[k];
                 v = -kLog2e * sw;
             }
-        } else if (pos < L::o_bin) {
+        } else if (pos < d4) {
             v = kTwoLog2e * p.W2[q * d4 + pos];
-        } else if (pos < L::o_Win) {
-            v = p.bin[q * d4 + (pos - L::o_bin)];
-        } else if (pos < L::o_b4) {
-            const int t = pos - L::o_Win, k = t / d4, i = t % d4;
-            v = p.Win[(q * d4 + i) * F + k];
-        } else if (pos < L::o_W4) {
-            v = p.b4[q * d4 + (pos - L::o_b4)];
-        } else if (pos < L::o_m) {
-            const int t = pos - L::o_W4, k = t / d4, i = t % d4;
-            v = p.W4[(q * d4 + i) * D + k];
-        } else if (pos < L::o_b2) {
-            const int t = pos - L::o_m, m = t / L::m_sz, u = t % L::m_sz;
+        } else if (pos >= L::o_in && pos < L::o_in + L::in_sz) {
+            const int t = pos - L::o_in;
+            if (t < d4) {
+                v = p.bin[q * d4 + t];
+            } else {
+                const int k = (t - d4) / d4, i = (t - d4) % d4;
+                v = p.Win[(q * d4 + i) * F + k];
+            }
+        } else if (pos >= L::o_4 && pos < L::o_4 + L::w4_sz) {
+            const int t = pos - L::o_4;
+            if (t < d4) {
+                v = p.b4[q * d4 + t];
+            } else {
+                const int k = (t - d4) / d4, i = (t - d4) % d4;
+                v = p.W4[(q * d4 + i) * D + k];
+            }
+        } else if (pos >= L::o_m && pos < L::o_b2 && (pos - L::o_m) % L::m_st < L::m_sz) {
+            const int t = pos - L::o_m, m = t / L::m_st, u = t % L::m_st;
             if (u < d4) {
                 const int r = q * d4 + u;
                 v = (m == 0) ? kTwoLog2e * p.b1[r] : (m == 4) ? p.b3[r] : 0.0f;
@@ -210,12 +220,22 @@ __device__ __forceinline__ void store_vec(float *__restrict__ dst, const float *
     }
 }
 
-// copy n4 float4s global -> LDS with the whole workgroup (no barrier)
+// copy n4 float4s global -> LDS with the whole workgroup (no barrier); 8 loads in flight per
+// lane before the first LDS write (a plain copy loop waits on every load)
 template <int NT>
 __device__ __forceinline__ void stage4(const float *__restrict__ g, float *lds, int n4)
 {
-    for (int i = threadIdx.x; i < n4; i += NT)
-        reinterpret_cast<float4 *>(lds)[i] = reinterpret_cast<const float4 *>(g)[i];
+    const float4 *__restrict__ g4 = reinterpret_cast<const float4 *>(g);
+    float4 *l4 = reinterpret_cast<float4 *>(lds);
+    int i = threadIdx.x;
+    for (; i + 7 * NT < n4; i += 8 * NT) {
+        float4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = g4[i + j * NT];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) l4[i + j * NT] = v[j];
+    }
+    for (; i < n4; i += NT) l4[i] = g4[i];
 }
 
 // per-shape launch configuration and LDS budgets (records), mirrored to plan.py through
@@ -230,54 +250,87 @@ struct Cfg {
     static constexpr int ed_rec = (D <= 16) ? (lds_bytes - 2048) / (4 * D) : 0;
     static constexpr int tile_hits = 1024;
     static constexpr int chunk_segments = 8192;
+    // Cross-slice prefetch keeps ~25 asm-loaded registers in flight while a slice is processed.
+    // That is only legal if the register allocator never spills: a spill of an in-flight
+    // register would save garbage.  Enabled for the shapes whose k_iter builds with zero scratch
+    // and no AGPR copies (tests/test_abi_and_host.py checks this against the compiler's resource
+    // remarks); the others wait for the prefetch immediately (same code, no in-flight window).
+    // D >= 32 sits at the 256-register cap: the allocator parks values in AGPRs there.
+    static constexpr bool pipelined = (D <= 8 && F <= 3) || (D == 4);
 };
 
-// out[i] = bias[i] + sum_k W[k][i] * in[k]  for this lane's d4 rows; weights from LDS
+// out[i] = bias[i] + sum_k W[k][i] * in[k]  for this lane's d4 rows.  The block
+// { bias[d4], W[KD+KF][d4] } sits 16-byte aligned in LDS; it is fetched with ds_read_b128
+// into registers in chunks of up to 32 floats before the FMAs consume it (one wait per chunk
+// instead of one per pair of weights).
 template <int D4, int KD, int KF>
 __device__ __forceinline__ void role_gemv(const float *w, const float *hn, const float *x,
                                           float *out)
 {
+    constexpr int NW = D4 + (KD + KF) * D4;
+    constexpr int CH = 16;
+    const float4 *w4 = reinterpret_cast<const float4 *>(__builtin_assume_aligned(w, 16));
 #pragma unroll
-    for (int i = 0; i < D4; ++i) out[i] = w[i];
-    w += D4;
+    for (int c0 = 0; c0 < NW; c0 += CH) {
+        constexpr int dummy = 0; (void)dummy;
+        float wr[CH];
 #pragma unroll
-    for (int k = 0; k < KD; ++k)
+        for (int v = 0; v < CH / 4; ++v) {
+            if (c0 + 4 * v < NW) {
+                const float4 t = w4[c0 / 4 + v];
+                wr[4 * v] = t.x; wr[4 * v + 1] = t.y; wr[4 * v + 2] = t.z; wr[4 * v + 3] = t.w;
+            }
+        }
 #pragma unroll
-        for (int i = 0; i < D4; ++i) out[i] = fmaf(w[k * D4 + i], hn[k], out[i]);
-#pragma unroll
-    for (int k = 0; k < KF; ++k)
-#pragma unroll
-        for (int i = 0; i < D4; ++i) out[i] = fmaf(w[(KD + k) * D4 + i], x[k], out[i]);
-}
-
-// From the new hit features [hn (D) | x (F)] emit this lane's chunk of the records the next
-// pass gathers: PR = [P | R], QS = [Q | S], U; or, for the last iteration, compact P and Q.
-template <int F, int D, bool LAST>
-__device__ __forceinline__ void emit_records(const float *wl, const float *hn, const float *x,
-                                             int64_t n, int q, float *__restrict__ PRn,
-                                             float *__restrict__ QSn, float *__restrict__ U,
-                                             float *__restrict__ Pc, float *__restrict__ Qc)
-{
-    using L = TL<F, D>;
-    constexpr int d4 = L::d4;
-    if constexpr (LAST) {
-        float pv[d4], qv[d4];
-        role_gemv<d4, D, F>(wl + L::o_m + 0 * L::m_sz, hn, x, pv);
-        role_gemv<d4, D, F>(wl + L::o_m + 2 * L::m_sz, hn, x, qv);
-        store_vec<d4>(Pc + n * D + q * d4, pv);
-        store_vec<d4>(Qc + n * D + q * d4, qv);
-    } else {
-        float pr[2 * d4], qs[2 * d4], u[d4];
-        role_gemv<d4, D, F>(wl + L::o_m + 0 * L::m_sz, hn, x, pr);
-        role_gemv<d4, D, F>(wl + L::o_m + 1 * L::m_sz, hn, x, pr + d4);
-        role_gemv<d4, D, F>(wl + L::o_m + 2 * L::m_sz, hn, x, qs);
-        role_gemv<d4, D, F>(wl + L::o_m + 3 * L::m_sz, hn, x, qs + d4);
-        role_gemv<d4, D, F>(wl + L::o_m + 4 * L::m_sz, hn, x, u);
-        store_vec<2 * d4>(PRn + n * 2 * D + q * 2 * d4, pr);
-        store_vec<2 * d4>(QSn + n * 2 * D + q * 2 * d4, qs);
-        store_vec<d4>(U + n * D + q * d4, u);
+        for (int j = 0; j < CH; ++j) {
+            const int g = c0 + j;                 // position in the block
+            if (g < NW) {
+                if (g < D4) {
+                    out[g] = wr[j];
+                } else {
+                    const int k = (g - D4) / D4, i = (g - D4) % D4;
+                    out[i] = fmaf(wr[j], k < KD ? hn[k < KD ? k : 0] : x[k >= KD ? k - KD : 0], out[i]);
+                }
+            }
+        }
     }
 }
+
+// This lane's chunk of the records the next pass gathers, computed from the new hit features
+// [hn (D) | x (F)]: PR = [P | R], QS = [Q | S], U; for the last iteration compact P and Q only.
+template <int F, int D, bool LAST>
+struct Records {
+    static constexpr int d4 = D / 4;
+    float pr[LAST ? d4 : 2 * d4], qs[LAST ? d4 : 2 * d4], u[d4];
+
+    __device__ __forceinline__ void compute(const float *wl, const float *hn, const float *x)
+    {
+        using L = TL<F, D>;
+        if constexpr (LAST) {
+            role_gemv<d4, D, F>(wl + L::o_m + 0 * L::m_st, hn, x, pr);
+            role_gemv<d4, D, F>(wl + L::o_m + 2 * L::m_st, hn, x, qs);
+        } else {
+            role_gemv<d4, D, F>(wl + L::o_m + 0 * L::m_st, hn, x, pr);
+            role_gemv<d4, D, F>(wl + L::o_m + 1 * L::m_st, hn, x, pr + d4);
+            role_gemv<d4, D, F>(wl + L::o_m + 2 * L::m_st, hn, x, qs);
+            role_gemv<d4, D, F>(wl + L::o_m + 3 * L::m_st, hn, x, qs + d4);
+            role_gemv<d4, D, F>(wl + L::o_m + 4 * L::m_st, hn, x, u);
+        }
+    }
+    __device__ __forceinline__ void store(int64_t n, int q, float *__restrict__ PRn,
+                                          float *__restrict__ QSn, float *__restrict__ U,
+                                          float *__restrict__ Pc, float *__restrict__ Qc) const
+    {
+        if constexpr (LAST) {
+            store_vec<d4>(Pc + n * D + q * d4, pr);
+            store_vec<d4>(Qc + n * D + q * d4, qs);
+        } else {
+            store_vec<2 * d4>(PRn + n * 2 * D + q * 2 * d4, pr);
+            store_vec<2 * d4>(QSn + n * 2 * D + q * 2 * d4, qs);
+            store_vec<d4>(U + n * D + q * d4, u);
+        }
+    }
+};
 
 // ---------------------------------------------------------------------------------------------
 // kernels
@@ -304,16 +357,14 @@ __global__ __launch_bounds__(256) void k_input4(const float *__restrict__ X,
 #pragma unroll
     for (int k = 0; k < F; ++k) x[k] = X[n * F + k];
     float hl[d4];
+    role_gemv<d4, 0, F>(wl + L::o_in, x, x, hl);
 #pragma unroll
-    for (int i = 0; i < d4; ++i) {
-        float a = wl[L::o_bin + i];
-#pragma unroll
-        for (int k = 0; k < F; ++k) a = fmaf(wl[L::o_Win + k * d4 + i], x[k], a);
-        hl[i] = tanh_f(a);
-    }
+    for (int i = 0; i < d4; ++i) hl[i] = tanh_f(hl[i]);
     float hn[D];
     quad_allgather<d4>(hl, hn);
-    emit_records<F, D, LAST>(wl, hn, x, n, q, PRn, QSn, U, Pc, Qc);
+    Records<F, D, LAST> rec;
+    rec.compute(wl, hn, x);
+    rec.store(n, q, PRn, QSn, U, Pc, Qc);
 }
 
 // r(z') = 1 / (1 + 2^z'): the only transcendental pair of the edge MLP (see scale folding)
@@ -322,85 +373,169 @@ __device__ __forceinline__ float r_f(float zs)
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(zs));
 }
 
-// one neighbour record: score the segment from (record P|Q half + own half), add its R|S half
-template <int D4>
-__device__ __forceinline__ void pull(const float *rec, const float *own, const float *w2, float b2,
-                                     float *acc)
+// ---- untracked prefetch ------------------------------------------------------------------------
+// Loads issued through asm are invisible to the compiler's s_waitcnt insertion, which otherwise
+// (vmcnt is one in-order counter) waits for a just-issued prefetch whenever anything older is
+// consumed.  Contract kept by k_iter: the asm outputs are the final storage of the loaded
+// values, and nothing reads them until a_wait_all() has executed and they have passed a fence;
+// both are asm volatile, so they stay ordered after the loads.
+typedef float f2_t __attribute__((ext_vector_type(2)));
+typedef float f3_t __attribute__((ext_vector_type(3)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+
+template <int OFF>
+__device__ __forceinline__ void a_load_i32(int &dst, const int32_t *p)
 {
-    float part = 0.0f;
-#pragma unroll
-    for (int i = 0; i < D4; ++i) part = fmaf(w2[i], r_f(rec[i] + own[i]), part);
-    const float e = r_f(quad_sum(part) + b2);
-#pragma unroll
-    for (int i = 0; i < D4; ++i) acc[i] = fmaf(e, rec[D4 + i], acc[i]);
+    asm volatile("global_load_dword %0, %1, off offset:%2" : "=v"(dst) : "v"(p), "n"(OFF));
 }
 
-// Stream of SELL-16 entries of one list of this wavefront's slice.  The 4 lanes of a quad
-// need the same entry at every step, so they load 4 DIFFERENT steps with one instruction
-// (lane q takes step 4c+q) and broadcast inside the quad with DPP; two chunks stay in flight.
-// Reads run up to 11 steps past the list end (plan.py pads the arrays).
-struct ListStream {
-    const int32_t *p;
-    int c0, c1;
-    __device__ __forceinline__ void init(const int32_t *lst)   // lst = nbr + base + 16*q + i16
+// N floats loaded by asm: the asm outputs ARE the storage (no element is copied out before
+// arrive), as pieces of 4 / 3 / 2 / 1 dwords.
+template <int N>
+struct AVec {
+    static constexpr int N4 = N / 4, R = N % 4;
+    f4_t v4[N4 ? N4 : 1];
+    f3_t v3;
+    f2_t v2;
+    float v1;
+    template <int I>
+    __device__ __forceinline__ void load4(const float *p)
     {
-        c0 = lst[0];
-        c1 = lst[4 * SLICE];
-        p = lst + 8 * SLICE;
+        if constexpr (I < N4) {
+            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(v4[I]) : "v"(p), "n"(16 * I));
+            load4<I + 1>(p);
+        }
     }
-    __device__ __forceinline__ int next()
+    __device__ __forceinline__ void load(const float *p)
     {
-        const int cur = c0;
-        c0 = c1;
-        c1 = p[0];
-        p += 4 * SLICE;
-        return cur;
+        static_assert(N * 4 < 4096, "immediate offset range");
+        load4<0>(p);
+        if constexpr (R == 3)
+            asm volatile("global_load_dwordx3 %0, %1, off offset:%2" : "=v"(v3) : "v"(p), "n"(16 * N4));
+        if constexpr (R == 2)
+            asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(v2) : "v"(p), "n"(16 * N4));
+        if constexpr (R == 1)
+            asm volatile("global_load_dword %0, %1, off offset:%2" : "=v"(v1) : "v"(p), "n"(16 * N4));
+    }
+    __device__ __forceinline__ void fence()
+    {
+#pragma unroll
+        for (int i = 0; i < N4; ++i) asm volatile("" : "+v"(v4[i]));
+        if constexpr (R == 3) asm volatile("" : "+v"(v3));
+        if constexpr (R == 2) asm volatile("" : "+v"(v2));
+        if constexpr (R == 1) asm volatile("" : "+v"(v1));
+    }
+    __device__ __forceinline__ void get(float *dst) const     // only after arrive
+    {
+#pragma unroll
+        for (int i = 0; i < N4; ++i) {
+            dst[4 * i] = v4[i].x; dst[4 * i + 1] = v4[i].y; dst[4 * i + 2] = v4[i].z; dst[4 * i + 3] = v4[i].w;
+        }
+        if constexpr (R == 3) { dst[4 * N4] = v3.x; dst[4 * N4 + 1] = v3.y; dst[4 * N4 + 2] = v3.z; }
+        if constexpr (R == 2) { dst[4 * N4] = v2.x; dst[4 * N4 + 1] = v2.y; }
+        if constexpr (R == 1) dst[4 * N4] = v1;
     }
 };
 
+__device__ __forceinline__ void a_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <typename T, int N>
+__device__ __forceinline__ void a_fence(T (&r)[N])
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(r[i]));
+}
+
+// ---- list sweep ----------------------------------------------------------------------------------
+// SELL-16 entries of one list of a 16-hit slice.  The 4 lanes of a quad need the same entry at
+// every step, so they load 4 DIFFERENT steps with one instruction (lane q takes step 4c+q of
+// chunk c) and broadcast inside the quad with DPP.
 template <int J>
 __device__ __forceinline__ int quad_bcast_i(int v)
 {
     return __builtin_amdgcn_update_dpp(0, v, J * 0x55, 0xF, 0xF, false);
 }
-
-// walk one list: REC is the record table (an LDS window or global memory)
-template <int D>
-__device__ __forceinline__ void sweep(ListStream &st, int len, const float *REC, int q,
-                                      const float *own, const float *w2, float b2, float *acc)
+template <int J>
+__device__ __forceinline__ float quad_bcast_f(float v)
 {
-    constexpr int d4 = D / 4;
-    for (int k = 0; k < len; k += 4) {
-        const int cur = st.next();
+    return dpp<J * 0x55>(v);
+}
+
+constexpr int MAXC = 6;   // chunks (of 4 steps) of a list held in registers; longer lists stream
+
+// The 4 neighbour records of one chunk (this lane's 2*D/4-float piece of each).
+template <int D>
+struct Recs {
+    float r[4][2 * (D / 4)];
+    __device__ __forceinline__ void read(int cur, const float *REC, int q)
+    {
+        constexpr int d4 = D / 4;
         const int nb[4] = {quad_bcast_i<0>(cur), quad_bcast_i<1>(cur), quad_bcast_i<2>(cur),
                            quad_bcast_i<3>(cur)};
-        const int rem = len - k;                     // wave-uniform
-        if (rem >= 4) {
-            if constexpr (d4 <= 2) {                 // 4 independent record reads in flight
-                float rec[4][2 * d4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    load_vec<2 * d4>(REC + (int64_t)nb[j] * 2 * D + q * 2 * d4, rec[j]);
+        for (int j = 0; j < 4; ++j) load_vec<2 * d4>(REC + (int64_t)nb[j] * 2 * D + q * 2 * d4, r[j]);
+    }
+};
+
+// Score the 4 segments of a chunk and add their weighted R|S halves.
+//   part_j = sum over this lane's dims of w2'_i r(P_i + Q_i)       (4 partial sums per lane)
+//   a 4x4 transpose-add inside the quad leaves lane j with the full pre-activation of segment j,
+//   so each lane evaluates ONE sigmoid (not the same one four times); the scores come back with a
+//   DPP broadcast.  Steps past the list end (rem < 4) read the NULL record: they add e * 0.
+template <int D4>
+__device__ __forceinline__ void score4(const float (*rec)[2 * D4], const float *own,
+                                       const float *w2, float b2, int q, float *acc)
+{
+    float part[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) pull<d4>(rec[j], own, w2, b2, acc);
-            } else {
+    for (int j = 0; j < 4; ++j) {
+        part[j] = 0.0f;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float rec[2 * d4];
-                    load_vec<2 * d4>(REC + (int64_t)nb[j] * 2 * D + q * 2 * d4, rec);
-                    pull<d4>(rec, own, w2, b2, acc);
-                }
-            }
-        } else {
+        for (int i = 0; i < D4; ++i) part[j] = fmaf(w2[i], r_f(rec[j][i] + own[i]), part[j]);
+    }
+    // stage 1 (xor 1): even lanes keep segments {0,2}, odd lanes {1,3}
+    const bool odd = q & 1, hi = q & 2;
+    const float s0 = odd ? part[0] : part[1], s1 = odd ? part[2] : part[3];   // what I give away
+    const float k0 = odd ? part[1] : part[0], k1 = odd ? part[3] : part[2];   // what I keep
+    const float t0 = k0 + dpp<0xB1>(s0), t1 = k1 + dpp<0xB1>(s1);
+    // stage 2 (xor 2): lanes 0,1 keep the lower segment of their pair, lanes 2,3 the upper
+    const float give = hi ? t0 : t1, keep = hi ? t1 : t0;
+    const float mine = keep + dpp<0x4E>(give);         // full sum of segment q, in lane q
+    const float e = r_f(mine + b2);
+    const float e4[4] = {quad_bcast_f<0>(e), quad_bcast_f<1>(e), quad_bcast_f<2>(e),
+                         quad_bcast_f<3>(e)};
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                if (j < rem) {
-                    float rec[2 * d4];
-                    load_vec<2 * d4>(REC + (int64_t)nb[j] * 2 * D + q * 2 * d4, rec);
-                    pull<d4>(rec, own, w2, b2, acc);
-                }
-            }
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < D4; ++i) acc[i] = fmaf(e4[j], rec[j][D4 + i], acc[i]);
+}
+
+// walk one list: the first MAXC chunks were prefetched into `pre`, the rest (rare) streams from
+// `lst` (= nbr + base + 16*q + i16).  REC is the record table (LDS window or global memory);
+// `null_idx` is the NULL record's index in REC.
+template <int D>
+__device__ __forceinline__ void sweep(const int *pre, const int32_t *__restrict__ lst, int len,
+                                      int null_idx, const float *REC, int q, const float *own,
+                                      const float *w2, float b2, float *acc)
+{
+    constexpr int d4 = D / 4;
+    if (len <= 0) return;
+    auto fix = [&](int cur, int rem) {           // steps past the end -> NULL record
+        const int lim = rem < 4 ? rem : 4;
+        return (q < lim) ? cur : null_idx;
+    };
+    Recs<D> a;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        if (4 * c < len) {
+            a.read(fix(pre[c], len - 4 * c), REC, q);
+            score4<d4>(a.r, own, w2, b2, q, acc);
         }
+    }
+    // lists longer than 4*MAXC steps (rare): stream the remaining chunks
+    for (int k = 4 * MAXC; k < len; k += 4) {
+        a.read(fix(lst[k * SLICE], len - k), REC, q);
+        score4<d4>(a.r, own, w2, b2, q, acc);
     }
 }
 
@@ -414,7 +549,7 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_iter(
     const int32_t *__restrict__ out_nbr, const float *__restrict__ PR,
     const float *__restrict__ QS, float *__restrict__ U, float *__restrict__ PRn,
     float *__restrict__ QSn, float *__restrict__ Pc, float *__restrict__ Qc, int64_t n_pad,
-    int tiles_per_xcd, int n_tiles)
+    int tiles_per_xcd, int n_tiles, int ablate)
 {
     using L = TL<F, D>;
     using G = Cfg<F, D>;
@@ -432,7 +567,7 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_iter(
     const int s_begin = td[0], s_end = td[1], in_lo = td[2], in_cnt = td[3], out_lo = td[4],
               out_cnt = td[5], mode = td[6];
     float *winA = win, *winB = win + (in_cnt + 1) * 2 * D;
-    if (G::it_rec > 0 && mode) {
+    if (G::it_rec > 0 && mode && !(ablate & 1)) {
         stage4<NT>(PR + (int64_t)in_lo * 2 * D, winA, in_cnt * 2 * D / 4);
         stage4<NT>(PR + n_pad * 2 * D, winA + in_cnt * 2 * D, 2 * D / 4);     // NULL record
         stage4<NT>(QS + (int64_t)out_lo * 2 * D, winB, out_cnt * 2 * D / 4);
@@ -447,52 +582,106 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_iter(
     for (int i = 0; i < d4; ++i) w2[i] = lds[q * L::stride + L::o_w2 + i];
     const float b2 = lds[L::o_b2];                      // scaled output bias
 
-    for (int slice = s_begin + (int)(threadIdx.x >> 6); slice < s_end; slice += NT / 64) {
-        // the weight-table offset is made opaque per iteration: otherwise the compiler hoists
-        // every (loop-invariant) LDS weight read out of the slice loop into ~150 VGPRs
-        int woff = q * L::stride;
-        asm volatile("" : "+v"(woff));
-        const float *wl = lds + woff;
+    // Everything a slice needs from global memory (list offsets, index chunks, own records) is
+    // requested one slice ahead: index lists stream from HBM exactly once, and a wave has only
+    // 3 siblings on its SIMD (LDS-limited occupancy), so loads must be in flight for a whole
+    // slice (~10k cycles) rather than a chunk.
+    struct Pre {
+        int il, ol, ib, ob;          // list lengths and offsets: wave-uniform (SGPRs)
+        int cin[MAXC], cout[MAXC];
+        AVec<d4> Pn, Qn, acc;
+        AVec<F> x;
+    };
+    auto prefetch = [&](Pre &p, int slice) {
+        if (ablate & 8) { p.il = 12; p.ol = 12; p.ib = 0; p.ob = 0;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) { p.cin[c] = 0; p.cout[c] = 0; }
+            return; }
+        p.ib = __builtin_amdgcn_readfirstlane(in_off[slice]);
+        p.il = (__builtin_amdgcn_readfirstlane(in_off[slice + 1]) - p.ib) >> 4;
+        p.ob = __builtin_amdgcn_readfirstlane(out_off[slice]);
+        p.ol = (__builtin_amdgcn_readfirstlane(out_off[slice + 1]) - p.ob) >> 4;
+        const int32_t *li = in_nbr + p.ib + q * SLICE + i16;
+        const int32_t *lo = out_nbr + p.ob + q * SLICE + i16;
+        // chunk c holds list steps 4c..4c+3 (lane q: step 4c+q); only chunks that exist are read
+        // (the last one may over-read up to 3 steps into the next list: plan.py pads the arrays)
+#define GNN_PF(C_)                                                              \
+        if (4 * C_ < p.il) a_load_i32<C_ * 4 * SLICE * 4>(p.cin[C_], li);           \
+        if (4 * C_ < p.ol) a_load_i32<C_ * 4 * SLICE * 4>(p.cout[C_], lo);
+        GNN_PF(0) GNN_PF(1) GNN_PF(2) GNN_PF(3) GNN_PF(4) GNN_PF(5)
+#undef GNN_PF
+        static_assert(MAXC == 6, "prefetch is written out for 6 chunks");
         const int64_t n = (int64_t)slice * SLICE + i16;
-        // start both index streams and the own-record loads before anything is consumed
-        const int ib = __builtin_amdgcn_readfirstlane(in_off[slice]);
-        const int il = (__builtin_amdgcn_readfirstlane(in_off[slice + 1]) - ib) >> 4;
-        const int ob = __builtin_amdgcn_readfirstlane(out_off[slice]);
-        const int ol = (__builtin_amdgcn_readfirstlane(out_off[slice + 1]) - ob) >> 4;
-        ListStream sin, sout;
-        sin.init(in_nbr + ib + q * SLICE + i16);
-        sout.init(out_nbr + ob + q * SLICE + i16);
-        float Pn[d4], Qn[d4], acc[d4];
-        load_vec<d4>(PR + n * 2 * D + q * 2 * d4, Pn);      // own P chunk
-        load_vec<d4>(QS + n * 2 * D + q * 2 * d4, Qn);      // own Q chunk
-        load_vec<d4>(U + n * D + q * d4, acc);              // W3[:, 2C:] H_n + b3
-        if (G::it_rec > 0 && mode) {
-            // segments ending here: P[start] + Q[n], adds e * R[start]; then starting here
-            sweep<D>(sin, il, winA, q, Qn, w2, b2, acc);
-            sweep<D>(sout, ol, winB, q, Pn, w2, b2, acc);
-        } else {
-            sweep<D>(sin, il, PR, q, Qn, w2, b2, acc);
-            sweep<D>(sout, ol, QS, q, Pn, w2, b2, acc);
+        p.Pn.load(PR + n * 2 * D + q * 2 * d4);      // own P chunk
+        p.Qn.load(QS + n * 2 * D + q * 2 * d4);      // own Q chunk
+        p.acc.load(U + n * D + q * d4);              // W3[:, 2C:] H_n + b3
+        p.x.load(X + n * F);                         // skip concat input (model.py:154)
+    };
+    auto arrive = [&](Pre &p) {      // all prefetched registers of p become readable
+        a_wait_all();
+        a_fence(p.cin); a_fence(p.cout);
+        p.Pn.fence(); p.Qn.fence(); p.acc.fence(); p.x.fence();
+    };
+    // slices are degree-sorted (heaviest first): deal them to the wavefronts in zig-zag order
+    constexpr int NWV = NT / 64;
+    const int wv = threadIdx.x >> 6;
+    const int rounds = (s_end - s_begin + NWV - 1) / NWV;
+    auto slice_of = [&](int r) {
+        const int sl = s_begin + r * NWV + ((r & 1) ? NWV - 1 - wv : wv);
+        return (r < rounds && sl < s_end) ? sl : -1;
+    };
+    Pre cur, nxt;
+    int slice = slice_of(0);
+    if (slice >= 0) {
+        prefetch(cur, slice);
+        arrive(cur);
+    }
+    // While `cur` is processed (LDS-mode tiles issue no VMEM instruction there) the loads of
+    // `nxt` stay in flight; arrive(nxt) waits for them a whole slice after issue, and this slice's
+    // stores are issued after that wait so nothing ever waits on a store.
+    for (int r = 0; r < rounds; ++r) {
+        const int next = slice_of(r + 1);
+        if (next >= 0) {
+            prefetch(nxt, next);
+            if constexpr (!G::pipelined) arrive(nxt);
         }
-        // hit update: H' = tanh(W4 tanh(acc) + b4)                  (model.py:94-98,125)
-        float ql[d4], qa[D];
+        Records<F, D, LAST> rec;
+        const int64_t n = (int64_t)slice * SLICE + i16;
+        if (slice >= 0) {
+            // the weight-table offset is made opaque per iteration: otherwise the compiler hoists
+            // every (loop-invariant) LDS weight read out of the slice loop into ~150 VGPRs
+            int woff = q * L::stride;
+            asm volatile("" : "+v"(woff));
+            const float *wl = lds + woff;
+            float acc[d4], Pn[d4], Qn[d4], xv[F];
+            cur.acc.get(acc); cur.Pn.get(Pn); cur.Qn.get(Qn); cur.x.get(xv);
+            if (ablate & 2) {
+            } else if (G::it_rec > 0 && mode) {
+                // segments ending here: P[start] + Q[n], adds e * R[start]; then starting here
+                sweep<D>(cur.cin, in_nbr + cur.ib + q * SLICE + i16, cur.il, in_cnt, winA, q, Qn, w2, b2, acc);
+                sweep<D>(cur.cout, out_nbr + cur.ob + q * SLICE + i16, cur.ol, out_cnt, winB, q, Pn, w2, b2, acc);
+            } else {
+                sweep<D>(cur.cin, in_nbr + cur.ib + q * SLICE + i16, cur.il, (int)n_pad, PR, q, Qn, w2, b2, acc);
+                sweep<D>(cur.cout, out_nbr + cur.ob + q * SLICE + i16, cur.ol, (int)n_pad, QS, q, Pn, w2, b2, acc);
+            }
+            // hit update: H' = tanh(W4 tanh(acc) + b4)                  (model.py:94-98,125)
+            float ql[d4], qa[D];
 #pragma unroll
-        for (int i = 0; i < d4; ++i) ql[i] = tanh_f(acc[i]);
-        quad_allgather<d4>(ql, qa);
-        float hl[d4];
+            for (int i = 0; i < d4; ++i) ql[i] = tanh_f(acc[i]);
+            quad_allgather<d4>(ql, qa);
+            float hl[d4];
+            role_gemv<d4, D, 0>(wl + L::o_4, qa, qa, hl);
 #pragma unroll
-        for (int i = 0; i < d4; ++i) hl[i] = wl[L::o_b4 + i];
-#pragma unroll
-        for (int k = 0; k < D; ++k)
-#pragma unroll
-            for (int i = 0; i < d4; ++i) hl[i] = fmaf(wl[L::o_W4 + k * d4 + i], qa[k], hl[i]);
-#pragma unroll
-        for (int i = 0; i < d4; ++i) hl[i] = tanh_f(hl[i]);
-        float hn[D], x[F];
-        quad_allgather<d4>(hl, hn);
-#pragma unroll
-        for (int k = 0; k < F; ++k) x[k] = X[n * F + k];            // skip concat (model.py:154)
-        emit_records<F, D, LAST>(wl, hn, x, n, q, PRn, QSn, U, Pc, Qc);
+            for (int i = 0; i < d4; ++i) hl[i] = tanh_f(hl[i]);
+            float hn[D];
+            quad_allgather<d4>(hl, hn);
+            if (!(ablate & 4)) rec.compute(wl, hn, xv);
+        }
+        if constexpr (G::pipelined)
+            if (next >= 0) arrive(nxt);
+        cur = nxt;
+        if (slice >= 0 && !(ablate & 16)) rec.store(n, q, PRn, QSn, U, Pc, Qc);
+        slice = next;
     }
 }
 
@@ -587,15 +776,17 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
                        w.Pc, w.Qc, Np);
         const int nt = (int)pl->n_tiles;
         const int tpx = (nt + 7) / 8;
+        const char *ab = getenv("GNN_ABLATE");   // timing diagnostics only (results invalid)
+        const int ablate = ab ? atoi(ab) : 0;
         for (int t = 0; t < n_iters; ++t) {
             if (t + 1 == n_iters)
                 GNN_LAUNCH("k_iter", (k_iter<F, D, true>), 8 * tpx, G::NT, s, pl->X, w.table,
                            pl->tiles, pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PR, QS, w.U,
-                           PRn, QSn, w.Pc, w.Qc, Np, tpx, nt);
+                           PRn, QSn, w.Pc, w.Qc, Np, tpx, nt, ablate);
             else
                 GNN_LAUNCH("k_iter", (k_iter<F, D, false>), 8 * tpx, G::NT, s, pl->X, w.table,
                            pl->tiles, pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PR, QS, w.U,
-                           PRn, QSn, w.Pc, w.Qc, Np, tpx, nt);
+                           PRn, QSn, w.Pc, w.Qc, Np, tpx, nt, ablate);
             float *t1 = PR; PR = PRn; PRn = t1;
             float *t2 = QS; QS = QSn; QSn = t2;
         }

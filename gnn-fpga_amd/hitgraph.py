@@ -77,14 +77,16 @@ class HitGraphBatch:
         self.y = None if y is None else t(np.ascontiguousarray(y, dtype=np.float32))
         self.plan = None
 
-    def build_plan(self, hidden_dim):
+    def build_plan(self, hidden_dim, limits=None):
         """Tiles + windows + SELL-16 execution plan of the fused kernels (plan.py); built once,
         on the host, for the kernel shape (input_dim = n_features, hidden_dim), then moved to
         this batch's device."""
         if self.plan is None or self.plan.hidden_dim != hidden_dim:
             from . import _lib
             from .plan import SellPlan
-            self.plan = SellPlan(self, _lib.plan_limits(self.n_features, hidden_dim))
+            lim = _lib.plan_limits(self.n_features, hidden_dim)
+            lim.update(limits or {})       # tests / experiments: e.g. iter_records=0 -> global mode
+            self.plan = SellPlan(self, lim)
             self.plan.hidden_dim = hidden_dim
             self.plan.to(self.X.device)
         return self.plan

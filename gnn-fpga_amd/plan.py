@@ -92,8 +92,8 @@ def _sell(key_new, other_rel, n_pad, null_of_slice):
         raise ValueError("SELL list exceeds int32 index range")
     nbr = np.repeat(null_of_slice.astype(np.int32), (slen * SLICE).astype(np.int64))
     nbr[off[k // SLICE] + pos * SLICE + (k % SLICE)] = oth
-    # the kernel's prefetching list stream reads up to 11 steps past a list's end
-    nbr = np.concatenate([nbr, np.zeros(12 * SLICE, dtype=np.int32)])
+    # the kernel reads lists in chunks of 4 steps: up to 3 steps past the end of the last list
+    nbr = np.concatenate([nbr, np.zeros(4 * SLICE, dtype=np.int32)])
     return off.astype(np.int32), nbr
 
 

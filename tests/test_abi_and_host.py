@@ -142,3 +142,30 @@ def test_bad_inputs_raise():
     Ri[0, 0] = Ri[1, 0] = 1
     with pytest.raises(ValueError):
         HitGraphBatch.from_dense(X, Ri, Ro)
+
+
+def test_pipelined_kernels_never_spill():
+    """Cfg::pipelined shapes keep asm-loaded registers in flight across a slice; that is only
+    legal with zero scratch (a spill would save a register before its load has landed).  The
+    compiler's resource remarks of the real build are kept in build/sell_pipeline.remarks."""
+    import subprocess
+    path = os.path.join(REPO, "build", "sell_pipeline.remarks")
+    if not os.path.exists(path):
+        pytest.skip("no build remarks (library was built elsewhere)")
+    txt = open(path).read()
+    blocks = re.split(r"remark: Function Name: ", txt)[1:]
+    seen = 0
+    for b in blocks:
+        name = subprocess.run(["c++filt", b.split()[0]], capture_output=True, text=True).stdout
+        m = re.search(r"k_iter<(\d+), (\d+), (true|false)>", name)
+        if not m:
+            continue
+        F, D = int(m.group(1)), int(m.group(2))
+        pipelined = (D <= 8 and F <= 3) or D == 4                 # mirrors Cfg::pipelined
+        scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+        agprs = int(re.search(r"AGPRs: (\d+)", b).group(1))
+        if pipelined:
+            seen += 1
+            assert agprs == 0, "k_iter<%d,%d> is pipelined but parks values in AGPRs" % (F, D)
+            assert scratch == 0, "k_iter<%d,%d> is pipelined but spills %d bytes" % (F, D, scratch)
+    assert seen >= 8
