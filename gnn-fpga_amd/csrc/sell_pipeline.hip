@@ -566,21 +566,8 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_iter(
     const int32_t *td = tiles + (int64_t)tile * DESC;
     const int s_begin = td[0], s_end = td[1], in_lo = td[2], in_cnt = td[3], out_lo = td[4],
               out_cnt = td[5], mode = td[6];
-    float *winA = win, *winB = win + (in_cnt + 1) * 2 * D;
-    if (G::it_rec > 0 && mode && !(ablate & 1)) {
-        stage4<NT>(PR + (int64_t)in_lo * 2 * D, winA, in_cnt * 2 * D / 4);
-        stage4<NT>(PR + n_pad * 2 * D, winA + in_cnt * 2 * D, 2 * D / 4);     // NULL record
-        stage4<NT>(QS + (int64_t)out_lo * 2 * D, winB, out_cnt * 2 * D / 4);
-        stage4<NT>(QS + n_pad * 2 * D, winB + out_cnt * 2 * D, 2 * D / 4);
-    }
-    __syncthreads();
-
     const int lane = threadIdx.x & 63;
     const int q = lane & 3, i16 = lane >> 2;
-    float w2[d4];
-#pragma unroll
-    for (int i = 0; i < d4; ++i) w2[i] = lds[q * L::stride + L::o_w2 + i];
-    const float b2 = lds[L::o_b2];                      // scaled output bias
 
     // Everything a slice needs from global memory (list offsets, index chunks, own records) is
     // requested one slice ahead: index lists stream from HBM exactly once, and a wave has only
@@ -632,10 +619,21 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_iter(
     };
     Pre cur, nxt;
     int slice = slice_of(0);
-    if (slice >= 0) {
-        prefetch(cur, slice);
-        arrive(cur);
+    if (slice >= 0) prefetch(cur, slice);     // in flight while the windows are staged
+    float *winA = win, *winB = win + (in_cnt + 1) * 2 * D;
+    if (G::it_rec > 0 && mode && !(ablate & 1)) {
+        stage4<NT>(PR + (int64_t)in_lo * 2 * D, winA, in_cnt * 2 * D / 4);
+        stage4<NT>(PR + n_pad * 2 * D, winA + in_cnt * 2 * D, 2 * D / 4);     // NULL record
+        stage4<NT>(QS + (int64_t)out_lo * 2 * D, winB, out_cnt * 2 * D / 4);
+        stage4<NT>(QS + n_pad * 2 * D, winB + out_cnt * 2 * D, 2 * D / 4);
     }
+    __syncthreads();
+    if (slice >= 0) arrive(cur);
+    float w2[d4];
+#pragma unroll
+    for (int i = 0; i < d4; ++i) w2[i] = lds[q * L::stride + L::o_w2 + i];
+    const float b2 = lds[L::o_b2];                      // scaled output bias
+
     // While `cur` is processed (LDS-mode tiles issue no VMEM instruction there) the loads of
     // `nxt` stay in flight; arrive(nxt) waits for them a whole slice after issue, and this slice's
     // stores are issued after that wait so nothing ever waits on a store.
