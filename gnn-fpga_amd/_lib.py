@@ -32,6 +32,10 @@ class GnnGraph(ctypes.Structure):
                [("n_hits", _i64), ("n_segments", _i64)]
 
 
+class GnnGrads(ctypes.Structure):
+    _fields_ = [(n, _f) for n in ("Win", "bin", "W1", "b1", "W2", "b2", "W3", "b3", "W4", "b4")]
+
+
 class GnnPlan(ctypes.Structure):
     _fields_ = [(n, _f) for n in ("X", "src", "dst", "in_off", "in_nbr", "out_off", "out_nbr",
                                   "tiles", "chunks")] + \
@@ -52,6 +56,11 @@ SIGNATURES = {
     "gnn_forward_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
     "gnn_segclf_forward": (ctypes.c_int, [ctypes.POINTER(GnnGraph), ctypes.POINTER(GnnParams),
                                           _i32, _f, _f, _f, _f, _sz, _f]),
+    "gnn_segclf_forward_train": (ctypes.c_int, [ctypes.POINTER(GnnGraph),
+                                                ctypes.POINTER(GnnParams), _i32, _f, _f, _f, _sz, _f]),
+    "gnn_backward_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
+    "gnn_segclf_backward": (ctypes.c_int, [ctypes.POINTER(GnnGraph), ctypes.POINTER(GnnParams),
+                                           _i32, _f, _f, _f, ctypes.POINTER(GnnGrads), _f, _sz, _f]),
     "gnn_plan_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
     "gnn_segclf_forward_plan": (ctypes.c_int, [ctypes.POINTER(GnnPlan), ctypes.POINTER(GnnParams),
                                                _i32, _f, _f, _sz, _f]),
@@ -209,6 +218,41 @@ def segclf_forward(batch, weights, F, D, n_iters, out=None, workspace=None, trac
                                      Ht.data_ptr() if trace else None,
                                      workspace.data_ptr(), workspace.numel(), _stream()))
     return (out, et, Ht) if trace else out
+
+
+def segclf_forward_train(batch, weights, F, D, n_iters):
+    """Training forward: returns (e_all [(T+1), E], H_all [(T+1), N, ldh]); scores = e_all[-1]."""
+    dev = batch.X.device
+    E, N = batch.n_segments, batch.n_hits
+    ldh = h_stride(F, D)
+    e_all = torch.empty((n_iters + 1, E), dtype=torch.float32, device=dev)
+    H_all = torch.empty((n_iters + 1, N, ldh), dtype=torch.float32, device=dev)
+    ws = torch.empty(workspace_bytes(N, E, F, D), dtype=torch.uint8, device=dev)
+    g = graph_struct(batch)
+    p = params_struct(weights, F, D)
+    _check(load().gnn_segclf_forward_train(ctypes.byref(g), ctypes.byref(p), n_iters,
+                                           e_all.data_ptr(), H_all.data_ptr(), ws.data_ptr(),
+                                           ws.numel(), _stream()))
+    return e_all, H_all
+
+
+def segclf_backward(batch, weights, F, D, n_iters, e_all, H_all, grad_out):
+    """Gradients of the ten (effective) weight tensors, in state_dict order."""
+    dev = batch.X.device
+    grads = [torch.zeros_like(w) for w in weights]
+    gs = GnnGrads()
+    for name, t in zip(("Win", "bin", "W1", "b1", "W2", "b2", "W3", "b3", "W4", "b4"), grads):
+        setattr(gs, name, t.data_ptr())
+    need = int(load().gnn_backward_workspace_bytes(batch.n_hits, batch.n_segments, F, D))
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    g = graph_struct(batch)
+    p = params_struct(weights, F, D)
+    _check(load().gnn_segclf_backward(ctypes.byref(g), ctypes.byref(p), n_iters,
+                                      _dev(e_all, torch.float32, "e_all"),
+                                      _dev(H_all, torch.float32, "H_all"),
+                                      _dev(grad_out, torch.float32, "grad_out"),
+                                      ctypes.byref(gs), ws.data_ptr(), ws.numel(), _stream()))
+    return grads
 
 
 def plan_shape_supported(F, D):

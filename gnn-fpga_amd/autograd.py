@@ -1,0 +1,47 @@
+"""Autograd bridge: makes the HIP forward differentiable w.r.t. the module's parameters so that
+`loss.backward()` in the reference's training loop (gnn/estimator.py:57-58) works unchanged.
+
+The training forward keeps every iteration's hit features and edge scores; the backward is
+explicit HIP kernels (csrc/backward.hip).  Masks stay in autograd: the Function's inputs are the
+EFFECTIVE weights `W * mask` computed with torch ops, so d/dW picks up the mask exactly like
+gnn/model.py:30 does.  X gets no gradient (the reference never asks for one).
+"""
+import torch
+
+from . import _lib
+
+
+class _SegClf(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, batch, F, D, n_iters, *weights):
+        w = [t.detach().to(torch.float32).contiguous() for t in weights]
+        e_all, H_all = _lib.segclf_forward_train(batch, w, F, D, n_iters)
+        ctx.batch, ctx.F, ctx.D, ctx.n_iters = batch, F, D, n_iters
+        ctx.save_for_backward(e_all, H_all, *w)
+        return e_all[n_iters].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        e_all, H_all, *w = ctx.saved_tensors
+        grads = _lib.segclf_backward(ctx.batch, list(w), ctx.F, ctx.D, ctx.n_iters, e_all, H_all,
+                                     grad_out.to(torch.float32).contiguous())
+        return (None, None, None, None) + tuple(grads)
+
+
+def segclf_apply(model, batch):
+    """Differentiable forward of `model` (a gnn_fpga_amd SegmentClassifier) on `batch`."""
+    F, D = model.input_dim, model.hidden_dim
+    if not batch.X.is_cuda:
+        raise _lib.GnnHipError("SegmentClassifier.forward needs tensors on a ROCm device; "
+                               "there is no CPU path")
+    if not _lib.shape_supported(F, D):
+        raise _lib.GnnHipError("no HIP training kernels for input_dim=%d hidden_dim=%d" % (F, D))
+    lin = model.input_network[0]
+    en, nn_ = model.edge_network.network, model.node_network.network
+    weights = [lin.weight, lin.bias,
+               en[0].effective_weight(), en[0].bias, en[2].effective_weight(), en[2].bias,
+               nn_[0].effective_weight(), nn_[0].bias, nn_[2].effective_weight(), nn_[2].bias]
+    e = _SegClf.apply(batch, F, D, model.n_iters, *weights)
+    if batch.dense_shape:
+        e = e.view(batch.dense_shape[0], batch.dense_shape[2])
+    return e

@@ -1,0 +1,434 @@
+// backward.hip - gradient of the SegmentClassifier forward w.r.t. its ten parameter tensors.
+//
+// The reference gets this from autograd through gnn/model.py:140-156 when
+// gnn/estimator.py:58 calls loss.backward().  Here the training forward (gnn_kernels.hip) saves
+// the hit features H_t and edge scores e_t of every iteration and this file walks the iterations
+// backwards with explicit kernels (formulas: SURVEY.md appendix A, checked there against
+// autograd in fp64).  Index form, CSR pulls, fp32:
+//
+//   edge pass t   e = sigmoid(u), u = W2 a + b2, a = tanh(z), z = P[s] + Q[d]
+//       k_edge_bwd   per segment:  gu = ge e (1-e);  gz = gu W2 (1-a^2)  -> gz[E,D];  gW2, gb2
+//       k_pq_bwd     per hit:      gP = sum_out gz, gQ = sum_in gz (CSR pulls, fixed order)
+//                                  gH += W1[:, :C]^T gP + W1[:, C:]^T gQ;  gW1, gb1
+//   node pass t   H' = tanh(W4 q + b4), q = tanh(W3 M + b3), M = [mi | mo | H]
+//       k_node_bwd   per hit: recompute M, q; gr = gH' (1-H'^2); gp = W4^T gr (1-q^2);
+//                             gM = W3^T gp -> gmi, gmo stored, gH_prev = gHself;  gW3, gb3, gW4, gb4
+//       k_agg_bwd_e  per segment:  ge = <gmi[d], H[s]> + <gmo[s], H[d]>
+//       k_agg_bwd_n  per hit:      gH_prev += sum_out e gmi[d] + sum_in e gmo[s]
+//   input         k_input_bwd per hit: g = gH0[:D] (1-H0^2);  gWin, gbin
+//
+// Weight gradients are sums of per-item outer products: a workgroup parks its 256 items' factors
+// in LDS, each thread then owns output elements and sums over the 256 items (fixed order), and
+// one atomicAdd per element per workgroup goes to the (zero-initialised) gradient tensor.
+// Only the order of those cross-workgroup atomics is run-dependent (last-bit differences).
+#include "common.h"
+
+namespace {
+using namespace gnn;
+
+template <int F, int D>
+struct Shape {
+    static constexpr int C = F + D;
+    static constexpr int LDH = (C + 3) & ~3;
+};
+
+// sum over the workgroup's items of L (x) R, added into g[i * ldg + col0 + k]
+template <int NL, int NR>
+__device__ __forceinline__ void accum_outer(const float *L, const float *R, bool active, float *g,
+                                            int ldg, int col0, float *lds)
+{
+    constexpr int S = NL + NR;
+    float *mine = lds + threadIdx.x * S;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) mine[i] = active ? L[i] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) mine[NL + k] = active ? R[k] : 0.0f;
+    __syncthreads();
+    for (int o = threadIdx.x; o < NL * NR; o += kBlock) {
+        const int i = o / NR, k = o % NR;
+        float acc = 0.0f;
+        for (int t = 0; t < kBlock; ++t) acc = fmaf(lds[t * S + i], lds[t * S + NL + k], acc);
+        atomicAdd(&g[i * ldg + col0 + k], acc);
+    }
+    __syncthreads();
+}
+
+// P/Q rows from H (same as the forward's k_pq; kept local to this file)
+template <int F, int D>
+__global__ __launch_bounds__(kBlock) void kb_pq(const float *__restrict__ H, int ldh,
+                                                const float *__restrict__ W1,
+                                                const float *__restrict__ b1,
+                                                float *__restrict__ PQ, int64_t n_hits)
+{
+    constexpr int C = F + D;
+    const int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (n >= n_hits) return;
+    float h[C];
+#pragma unroll
+    for (int k = 0; k < C; ++k) h[k] = H[n * ldh + k];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        float p = b1[d], q = 0.0f;
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            p = fmaf(W1[d * 2 * C + k], h[k], p);
+            q = fmaf(W1[d * 2 * C + C + k], h[k], q);
+        }
+        PQ[n * 2 * D + d] = p;
+        PQ[n * 2 * D + D + d] = q;
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_edge_bwd(
+    const int32_t *__restrict__ src, const int32_t *__restrict__ dst,
+    const float *__restrict__ PQ, const float *__restrict__ b1, const float *__restrict__ W2,
+    const float *__restrict__ e, const float *__restrict__ ge, float *__restrict__ gz,
+    float *__restrict__ gW2, float *__restrict__ gb2, int64_t n_segments)
+{
+    __shared__ float lds[kBlock * (D + 2)];
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool active = j < n_segments;
+    float a[D], gu = 0.0f;
+#pragma unroll
+    for (int i = 0; i < D; ++i) a[i] = 0.0f;
+    if (active) {
+        const int s = src[j], d = dst[j];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const float z = s >= 0 ? PQ[(int64_t)s * 2 * D + i] + PQ[(int64_t)d * 2 * D + D + i] : b1[i];
+            a[i] = tanh_f(z);
+        }
+        const float ev = e[j];
+        gu = ge[j] * ev * (1.0f - ev);
+#pragma unroll
+        for (int i = 0; i < D; ++i) gz[j * D + i] = gu * W2[i] * (1.0f - a[i] * a[i]);
+    }
+    const float one = 1.0f;
+    accum_outer<1, D>(&gu, a, active, gW2, D, 0, lds);       // gW2[0][i] += gu a_i
+    accum_outer<1, 1>(&gu, &one, active, gb2, 1, 0, lds);
+}
+
+template <int F, int D>
+__global__ __launch_bounds__(kBlock) void k_pq_bwd(
+    const float *__restrict__ H, int ldh, const float *__restrict__ gz,
+    const int32_t *__restrict__ in_ptr, const int32_t *__restrict__ in_eid,
+    const int32_t *__restrict__ out_ptr, const int32_t *__restrict__ out_eid,
+    const float *__restrict__ W1, float *__restrict__ gH, float *__restrict__ gW1,
+    float *__restrict__ gb1, int64_t n_pad_edges_b1, int64_t n_hits)
+{
+    constexpr int C = F + D;
+    __shared__ float lds[kBlock * (D + C)];
+    const int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool active = n < n_hits;
+    float gP[D], gQ[D], h[C];
+#pragma unroll
+    for (int i = 0; i < D; ++i) gP[i] = gQ[i] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < C; ++k) h[k] = 0.0f;
+    if (active) {
+        for (int k = out_ptr[n], k1 = out_ptr[n + 1]; k < k1; ++k) {
+            const float *r = gz + (int64_t)out_eid[k] * D;
+#pragma unroll
+            for (int i = 0; i < D; ++i) gP[i] += r[i];
+        }
+        for (int k = in_ptr[n], k1 = in_ptr[n + 1]; k < k1; ++k) {
+            const float *r = gz + (int64_t)in_eid[k] * D;
+#pragma unroll
+            for (int i = 0; i < D; ++i) gQ[i] += r[i];
+        }
+#pragma unroll
+        for (int k = 0; k < C; ++k) h[k] = H[n * ldh + k];
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                acc = fmaf(W1[i * 2 * C + k], gP[i], acc);
+                acc = fmaf(W1[i * 2 * C + C + k], gQ[i], acc);
+            }
+            gH[n * ldh + k] += acc;
+        }
+    }
+    const float one = 1.0f;
+    accum_outer<D, C>(gP, h, active, gW1, 2 * C, 0, lds);
+    accum_outer<D, C>(gQ, h, active, gW1, 2 * C, C, lds);
+    accum_outer<D, 1>(gP, &one, active, gb1, 1, 0, lds);
+    (void)n_pad_edges_b1;
+}
+
+// padded segments (src = -1) score sigmoid(W2 tanh(b1) + b2): their gz flows into b1 only
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_pad_b1(const int32_t *__restrict__ src,
+                                                   const float *__restrict__ gz,
+                                                   float *__restrict__ gb1, int64_t n_segments)
+{
+    __shared__ float lds[kBlock * (D + 1)];
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool active = j < n_segments && src[j] < 0;
+    float g[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) g[i] = active ? gz[j * D + i] : 0.0f;
+    const float one = 1.0f;
+    accum_outer<D, 1>(g, &one, active, gb1, 1, 0, lds);
+}
+
+template <int F, int D>
+__global__ __launch_bounds__(kBlock) void k_node_bwd(
+    const float *__restrict__ H, const float *__restrict__ Hn, int ldh,
+    const float *__restrict__ e, const int32_t *__restrict__ in_ptr,
+    const int32_t *__restrict__ in_eid, const int32_t *__restrict__ in_nbr,
+    const int32_t *__restrict__ out_ptr, const int32_t *__restrict__ out_eid,
+    const int32_t *__restrict__ out_nbr, const float *__restrict__ W3,
+    const float *__restrict__ b3, const float *__restrict__ W4, const float *__restrict__ gHn,
+    float *__restrict__ gH, float *__restrict__ gmio, float *__restrict__ gW3,
+    float *__restrict__ gb3, float *__restrict__ gW4, float *__restrict__ gb4, int64_t n_hits)
+{
+    constexpr int C = Shape<F, D>::C;
+    __shared__ float lds[kBlock * (D + 3 * C)];
+    const int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool active = n < n_hits;
+    float M[3 * C], q[D], gr[D], gp[D];
+#pragma unroll
+    for (int k = 0; k < 3 * C; ++k) M[k] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < D; ++i) q[i] = gr[i] = gp[i] = 0.0f;
+    if (active) {
+        for (int k = in_ptr[n], k1 = in_ptr[n + 1]; k < k1; ++k) {
+            const float w = e[in_eid[k]];
+            const float *hp = H + (int64_t)in_nbr[k] * ldh;
+#pragma unroll
+            for (int c = 0; c < C; ++c) M[c] = fmaf(w, hp[c], M[c]);
+        }
+        for (int k = out_ptr[n], k1 = out_ptr[n + 1]; k < k1; ++k) {
+            const float w = e[out_eid[k]];
+            const float *hp = H + (int64_t)out_nbr[k] * ldh;
+#pragma unroll
+            for (int c = 0; c < C; ++c) M[C + c] = fmaf(w, hp[c], M[C + c]);
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) M[2 * C + c] = H[n * ldh + c];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            float acc = b3[i];
+#pragma unroll
+            for (int k = 0; k < 3 * C; ++k) acc = fmaf(W3[i * 3 * C + k], M[k], acc);
+            q[i] = tanh_f(acc);
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const float hp = Hn[n * ldh + i];
+            gr[i] = gHn[n * ldh + i] * (1.0f - hp * hp);
+        }
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < D; ++i) acc = fmaf(W4[i * D + k], gr[i], acc);
+            gp[k] = acc * (1.0f - q[k] * q[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 3 * C; ++k) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < D; ++i) acc = fmaf(W3[i * 3 * C + k], gp[i], acc);
+            if (k < 2 * C)
+                gmio[n * 2 * C + k] = acc;          // [gmi | gmo]
+            else
+                gH[n * ldh + (k - 2 * C)] = acc;    // gHself initialises gH_prev
+        }
+    }
+    const float one = 1.0f;
+    accum_outer<D, 3 * C>(gp, M, active, gW3, 3 * C, 0, lds);
+    accum_outer<D, 1>(gp, &one, active, gb3, 1, 0, lds);
+    accum_outer<D, D>(gr, q, active, gW4, D, 0, lds);
+    accum_outer<D, 1>(gr, &one, active, gb4, 1, 0, lds);
+}
+
+template <int F, int D>
+__global__ __launch_bounds__(kBlock) void k_agg_bwd_e(const int32_t *__restrict__ src,
+                                                      const int32_t *__restrict__ dst,
+                                                      const float *__restrict__ H, int ldh,
+                                                      const float *__restrict__ gmio,
+                                                      float *__restrict__ ge, int64_t n_segments)
+{
+    constexpr int C = F + D;
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n_segments) return;
+    const int s = src[j], d = dst[j];
+    float acc = 0.0f;
+    if (s >= 0) {
+        const float *hs = H + (int64_t)s * ldh, *hd = H + (int64_t)d * ldh;
+        const float *gmi_d = gmio + (int64_t)d * 2 * C, *gmo_s = gmio + (int64_t)s * 2 * C + C;
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc = fmaf(gmi_d[c], hs[c], acc);
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc = fmaf(gmo_s[c], hd[c], acc);
+    }
+    ge[j] = acc;
+}
+
+template <int F, int D>
+__global__ __launch_bounds__(kBlock) void k_agg_bwd_n(
+    const float *__restrict__ e, const float *__restrict__ gmio,
+    const int32_t *__restrict__ in_ptr, const int32_t *__restrict__ in_eid,
+    const int32_t *__restrict__ in_nbr, const int32_t *__restrict__ out_ptr,
+    const int32_t *__restrict__ out_eid, const int32_t *__restrict__ out_nbr,
+    float *__restrict__ gH, int ldh, int64_t n_hits)
+{
+    constexpr int C = F + D;
+    const int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (n >= n_hits) return;
+    float acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = 0.0f;
+    // n is the START of these segments: H[n] entered mi of the end hit d
+    for (int k = out_ptr[n], k1 = out_ptr[n + 1]; k < k1; ++k) {
+        const float w = e[out_eid[k]];
+        const float *g = gmio + (int64_t)out_nbr[k] * 2 * C;          // gmi[d]
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = fmaf(w, g[c], acc[c]);
+    }
+    // n is the END of these segments: H[n] entered mo of the start hit s
+    for (int k = in_ptr[n], k1 = in_ptr[n + 1]; k < k1; ++k) {
+        const float w = e[in_eid[k]];
+        const float *g = gmio + (int64_t)in_nbr[k] * 2 * C + C;       // gmo[s]
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = fmaf(w, g[c], acc[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) gH[n * ldh + c] += acc[c];
+}
+
+template <int F, int D>
+__global__ __launch_bounds__(kBlock) void k_input_bwd(const float *__restrict__ X,
+                                                      const float *__restrict__ H0, int ldh,
+                                                      const float *__restrict__ gH,
+                                                      float *__restrict__ gWin,
+                                                      float *__restrict__ gbin, int64_t n_hits)
+{
+    __shared__ float lds[kBlock * (D + F)];
+    const int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool active = n < n_hits;
+    float g[D], x[F];
+#pragma unroll
+    for (int i = 0; i < D; ++i) g[i] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < F; ++k) x[k] = 0.0f;
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const float h = H0[n * ldh + i];
+            g[i] = gH[n * ldh + i] * (1.0f - h * h);
+        }
+#pragma unroll
+        for (int k = 0; k < F; ++k) x[k] = X[n * F + k];
+    }
+    const float one = 1.0f;
+    accum_outer<D, F>(g, x, active, gWin, F, 0, lds);
+    accum_outer<D, 1>(g, &one, active, gbin, 1, 0, lds);
+}
+
+struct BwdWs {
+    float *PQ, *gz, *ge, *gHa, *gHb, *gmio;
+    size_t bytes;
+};
+
+BwdWs carve_bwd(char *b, int64_t N, int64_t E, int ldh, int C, int D)
+{
+    BwdWs w;
+    size_t off = 0;
+    auto take = [&](size_t nfloat) {
+        float *p = reinterpret_cast<float *>(b + off);
+        off += align256(nfloat * sizeof(float));
+        return p;
+    };
+    w.PQ = take((size_t)N * 2 * D);
+    w.gz = take((size_t)E * D);
+    w.ge = take((size_t)E);
+    w.gHa = take((size_t)N * ldh);
+    w.gHb = take((size_t)N * ldh);
+    w.gmio = take((size_t)N * 2 * C);
+    w.bytes = off;
+    return w;
+}
+
+template <int F, int D>
+int backward_t(const gnn_graph_t *g, const gnn_params_t *p, int T, const float *e_all,
+               const float *H_all, const float *grad_out, const gnn_grads_t *gr, char *ws,
+               hipStream_t s)
+{
+    constexpr int C = Shape<F, D>::C, LDH = Shape<F, D>::LDH;
+    const int64_t N = g->n_hits, E = g->n_segments;
+    BwdWs w = carve_bwd(ws, N, E, LDH, C, D);
+    float *gH = w.gHa, *gHprev = w.gHb;
+    if (N > 0) {
+        hipError_t err = hipMemsetAsync(gH, 0, (size_t)N * LDH * sizeof(float), s);
+        if (err != hipSuccess) return fail(-(int)err, "memset of the hit gradient failed");
+    }
+    const float *ge = grad_out;
+    for (int t = T; t >= 0; --t) {
+        const float *Ht = H_all + (size_t)t * N * LDH;
+        const float *et = e_all + (size_t)t * E;
+        // edge pass t backward: adds into gH (gradient w.r.t. H_t)
+        if (N > 0) GNN_LAUNCH("kb_pq", (kb_pq<F, D>), grid_for(N), kBlock, s, Ht, LDH, p->W1, p->b1, w.PQ, N);
+        if (E > 0) {
+            GNN_LAUNCH("k_edge_bwd", (k_edge_bwd<D>), grid_for(E), kBlock, s, g->src, g->dst, w.PQ,
+                       p->b1, p->W2, et, ge, w.gz, gr->W2, gr->b2, E);
+            GNN_LAUNCH("k_pad_b1", (k_pad_b1<D>), grid_for(E), kBlock, s, g->src, w.gz, gr->b1, E);
+        }
+        if (N > 0)
+            GNN_LAUNCH("k_pq_bwd", (k_pq_bwd<F, D>), grid_for(N), kBlock, s, Ht, LDH, w.gz, g->in_ptr,
+                       g->in_eid, g->out_ptr, g->out_eid, p->W1, gH, gr->W1, gr->b1, (int64_t)0, N);
+        if (t == 0) break;
+        // node pass t-1 backward: H_{t-1}, e_{t-1} -> H_t
+        const float *Hp = H_all + (size_t)(t - 1) * N * LDH;
+        const float *ep = e_all + (size_t)(t - 1) * E;
+        if (N > 0) {
+            GNN_LAUNCH("k_node_bwd", (k_node_bwd<F, D>), grid_for(N), kBlock, s, Hp, Ht, LDH, ep,
+                       g->in_ptr, g->in_eid, g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, p->W3,
+                       p->b3, p->W4, gH, gHprev, w.gmio, gr->W3, gr->b3, gr->W4, gr->b4, N);
+            if (E > 0)
+                GNN_LAUNCH("k_agg_bwd_e", (k_agg_bwd_e<F, D>), grid_for(E), kBlock, s, g->src, g->dst,
+                           Hp, LDH, w.gmio, w.ge, E);
+            GNN_LAUNCH("k_agg_bwd_n", (k_agg_bwd_n<F, D>), grid_for(N), kBlock, s, ep, w.gmio,
+                       g->in_ptr, g->in_eid, g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, gHprev,
+                       LDH, N);
+        }
+        float *tmp = gH; gH = gHprev; gHprev = tmp;
+        ge = w.ge;
+    }
+    if (N > 0)
+        GNN_LAUNCH("k_input_bwd", (k_input_bwd<F, D>), grid_for(N), kBlock, s, g->X, H_all, LDH, gH,
+                   gr->Win, gr->bin, N);
+    return 0;
+}
+
+#define BWD_FOR_EACH_SHAPE(X_) \
+    X_(2, 4) X_(2, 8) X_(2, 16) X_(3, 4) X_(3, 8) X_(3, 16) X_(11, 4) X_(11, 8) X_(11, 16)
+
+}  // namespace
+
+namespace gnn {
+
+size_t backward_workspace_bytes(int64_t N, int64_t E, int F, int D)
+{
+    const int C = F + D;
+    return carve_bwd(nullptr, N, E, (C + 3) & ~3, C, D).bytes + 256;
+}
+
+int backward(const gnn_graph_t *g, const gnn_params_t *p, int T, const float *e_all,
+             const float *H_all, const float *grad_out, const gnn_grads_t *gr, void *ws,
+             size_t ws_bytes, hipStream_t s)
+{
+    if (ws_bytes < backward_workspace_bytes(g->n_hits, g->n_segments, p->F, p->D))
+        return fail(GNN_ERR_WORKSPACE, "backward workspace too small: need %zu bytes",
+                    backward_workspace_bytes(g->n_hits, g->n_segments, p->F, p->D));
+    char *base = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
+#define X_(F_, D_) if (p->F == F_ && p->D == D_) return backward_t<F_, D_>(g, p, T, e_all, H_all, grad_out, gr, base, s);
+    BWD_FOR_EACH_SHAPE(X_)
+#undef X_
+    return fail(GNN_ERR_UNSUPPORTED, "no backward kernel for input_dim=%d hidden_dim=%d", p->F, p->D);
+}
+
+}  // namespace gnn

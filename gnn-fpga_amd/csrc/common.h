@@ -51,4 +51,10 @@ size_t sell_workspace_bytes(int64_t n_hits, int64_t n_segments, int F, int D);
 int sell_shape_supported(int F, int D);
 int sell_limits(int F, int D, int32_t *out4);
 
+// backward.hip
+size_t backward_workspace_bytes(int64_t n_hits, int64_t n_segments, int F, int D);
+int backward(const gnn_graph_t *g, const gnn_params_t *p, int T, const float *e_all,
+             const float *H_all, const float *grad_out, const gnn_grads_t *gr, void *ws,
+             size_t ws_bytes, hipStream_t s);
+
 }  // namespace gnn

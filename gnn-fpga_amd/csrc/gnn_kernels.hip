@@ -343,13 +343,14 @@ Workspace carve(void *base, int64_t n_hits, int64_t n_seg, int ldh, int D)
 
 template <int F, int D>
 int forward_impl(const gnn_graph_t *g, const gnn_params_t *p, int n_iters, float *e_out,
-                 float *e_trace, float *H_trace, void *ws, hipStream_t s)
+                 float *e_trace, float *H_trace, void *ws, hipStream_t s, float *H_all = nullptr)
 {
     constexpr int C = Shape<F, D>::C;
     constexpr int LDH = Shape<F, D>::LDH;
     const int64_t N = g->n_hits, E = g->n_segments;
     Workspace w = carve(ws, N, E, LDH, D);
-    float *H = w.Ha, *Hn = w.Hb;
+    // training forward: every iteration's H is kept (H_all), no ping-pong
+    float *H = H_all ? H_all : w.Ha, *Hn = H_all ? H_all + (size_t)N * LDH : w.Hb;
     int rc = run_input<F, D>(g->X, p->Win, p->bin, p->W1, p->b1, H, LDH, w.PQ, N, s);
     if (rc) return rc;
     for (int t = 0; t <= n_iters; ++t) {
@@ -361,7 +362,7 @@ int forward_impl(const gnn_graph_t *g, const gnn_params_t *p, int n_iters, float
         rc = run_edge<D>(g->src, g->dst, w.PQ, p->b1, p->W2, p->b2, e_t, E, s);
         if (rc) return rc;
         if (last) {
-            if (e_trace && E > 0) {
+            if (e_trace && E > 0 && e_out != e_t) {
                 hipError_t err = hipMemcpyAsync(e_out, e_t, (size_t)E * sizeof(float),
                                                 hipMemcpyDeviceToDevice, s);
                 if (err != hipSuccess) return fail(-(int)err, "copy of final scores failed");
@@ -371,7 +372,12 @@ int forward_impl(const gnn_graph_t *g, const gnn_params_t *p, int n_iters, float
         rc = run_node<F, D>(H, LDH, e_t, g, p->W3, p->b3, p->W4, p->b4, p->W1, p->b1, Hn, LDH,
                             w.PQ, s);
         if (rc) return rc;
-        float *tmp = H; H = Hn; Hn = tmp;
+        if (H_all) {
+            H = Hn;
+            Hn = H + (size_t)N * LDH;
+        } else {
+            float *tmp = H; H = Hn; Hn = tmp;
+        }
     }
     return 0;
 }
@@ -480,6 +486,50 @@ int gnn_segclf_forward(const gnn_graph_t *g, const gnn_params_t *p, int32_t n_it
     GNN_FOR_EACH_SHAPE(X_)
 #undef X_
     return fail(GNN_ERR_UNSUPPORTED, "unreachable");
+}
+
+int gnn_segclf_forward_train(const gnn_graph_t *g, const gnn_params_t *p, int32_t n_iters,
+                             float *e_all, float *H_all, void *workspace, size_t workspace_bytes,
+                             void *stream)
+{
+    if (!g || !p || n_iters < 0 || g->n_hits < 0 || g->n_segments < 0)
+        return fail(GNN_ERR_BADARG, "gnn_segclf_forward_train: bad argument");
+    if ((g->n_segments > 0 && (!e_all || !g->src || !g->dst)) || (g->n_hits > 0 && (!H_all || !g->X || !g->in_ptr || !g->out_ptr)))
+        return fail(GNN_ERR_BADARG, "gnn_segclf_forward_train: array missing");
+    if (!gnn_shape_supported(p->F, p->D))
+        return fail(GNN_ERR_UNSUPPORTED, "no kernel for input_dim=%d hidden_dim=%d", p->F, p->D);
+    if (!workspace || workspace_bytes < gnn_forward_workspace_bytes(g->n_hits, g->n_segments, p->F, p->D))
+        return fail(GNN_ERR_WORKSPACE, "workspace too small");
+    void *ws = reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // e_trace = e_all makes every edge pass land in its row; the "final scores" copy goes to the
+    // last row itself (no-op copy avoided by passing that row as e_out)
+    float *last = e_all ? e_all + (size_t)n_iters * g->n_segments : nullptr;
+#define X_(F_, D_) if (p->F == F_ && p->D == D_) return forward_impl<F_, D_>(g, p, n_iters, last, e_all, nullptr, ws, s, H_all);
+    GNN_FOR_EACH_SHAPE(X_)
+#undef X_
+    return fail(GNN_ERR_UNSUPPORTED, "unreachable");
+}
+
+size_t gnn_backward_workspace_bytes(int64_t n_hits, int64_t n_segments, int32_t F, int32_t D)
+{
+    if (n_hits < 0 || n_segments < 0 || F <= 0 || D <= 0) return 0;
+    return backward_workspace_bytes(n_hits, n_segments, F, D);
+}
+
+int gnn_segclf_backward(const gnn_graph_t *g, const gnn_params_t *p, int32_t n_iters,
+                        const float *e_all, const float *H_all, const float *grad_out,
+                        const gnn_grads_t *gr, void *workspace, size_t workspace_bytes,
+                        void *stream)
+{
+    if (!g || !p || !gr || n_iters < 0 || g->n_hits < 0 || g->n_segments < 0 || !workspace)
+        return fail(GNN_ERR_BADARG, "gnn_segclf_backward: bad argument");
+    if ((g->n_segments > 0 && (!e_all || !grad_out)) || (g->n_hits > 0 && !H_all))
+        return fail(GNN_ERR_BADARG, "gnn_segclf_backward: saved tensors missing");
+    if (!gr->Win || !gr->bin || !gr->W1 || !gr->b1 || !gr->W2 || !gr->b2 || !gr->W3 || !gr->b3 || !gr->W4 || !gr->b4)
+        return fail(GNN_ERR_BADARG, "gnn_segclf_backward: gradient pointer missing");
+    return backward(g, p, n_iters, e_all, H_all, grad_out, gr, workspace, workspace_bytes,
+                    static_cast<hipStream_t>(stream));
 }
 
 size_t gnn_plan_workspace_bytes(int64_t n_pad, int64_t n_segments, int32_t F, int32_t D)

@@ -57,6 +57,12 @@ typedef struct gnn_graph {
     int64_t n_hits, n_segments;
 } gnn_graph_t;
 
+/* Gradient outputs, same shapes as gnn_params_t; the caller zero-initialises them and the
+ * backward ADDS into them (device pointers). */
+typedef struct gnn_grads {
+    float *Win, *bin, *W1, *b1, *W2, *b2, *W3, *b3, *W4, *b4;
+} gnn_grads_t;
+
 /* Execution plan of the fused pipeline (built once per batch by the host; see
  * gnn-fpga_amd/plan.py).  Hits are renumbered by (graph, topological level), cut into tiles of
  * <= tile_hits hits (one workgroup each), degree-sorted inside a tile and padded to 16-hit
@@ -117,6 +123,23 @@ size_t gnn_forward_workspace_bytes(int64_t n_hits, int64_t n_segments, int32_t F
 int gnn_segclf_forward(const gnn_graph_t *g, const gnn_params_t *p, int32_t n_iters,
                        float *e_out, float *e_trace, float *H_trace,
                        void *workspace, size_t workspace_bytes, void *stream);
+
+/* Training forward: like gnn_segclf_forward but keeps what the backward needs - the scores of
+ * every edge pass e_all [(n_iters+1), n_segments] (the last row is the model output) and the hit
+ * features of every iteration H_all [(n_iters+1), n_hits, ldh] (padded rows). */
+int gnn_segclf_forward_train(const gnn_graph_t *g, const gnn_params_t *p, int32_t n_iters,
+                             float *e_all, float *H_all, void *workspace, size_t workspace_bytes,
+                             void *stream);
+
+/* Gradient of a scalar loss w.r.t. the ten parameter tensors, given grad_out [n_segments] =
+ * dLoss/d(scores) and the tensors saved by gnn_segclf_forward_train.  Replaces autograd through
+ * gnn/model.py:140-156 as triggered by loss.backward() in gnn/estimator.py:58.  Adds into
+ * `grads` (zero them first).  Workspace size from gnn_backward_workspace_bytes. */
+size_t gnn_backward_workspace_bytes(int64_t n_hits, int64_t n_segments, int32_t F, int32_t D);
+int gnn_segclf_backward(const gnn_graph_t *g, const gnn_params_t *p, int32_t n_iters,
+                        const float *e_all, const float *H_all, const float *grad_out,
+                        const gnn_grads_t *grads, void *workspace, size_t workspace_bytes,
+                        void *stream);
 
 /* SegmentClassifier.forward (gnn/model.py:140-156) on a planned batch: the fast path.
  * One fused kernel per message-passing iteration (edge scores are recomputed at both
