@@ -83,9 +83,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--global-gather", action="store_true",
                     help="experiment: disable the LDS windows (gather records from global memory)")
-    ap.add_argument("--pmc-traffic-bytes", type=float, default=None,
-                    help="HBM bytes per launch of the dominant kernel from a separate "
-                         "rocprofv3 --pmc pass (profiles/), corrected per MI355X_MICROARCH.md")
+    ap.add_argument("--pmc-traffic", default=os.path.join(REPO, "profiles", "pmc_traffic.json"),
+                    help="per-kernel HBM bytes per launch from separate rocprofv3 --pmc passes of "
+                         "this same command (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md), "
+                         "written by tools/profile_bench.sh; `traffic` is null without it")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -148,6 +149,17 @@ def main():
         ab = algorithmic_bytes(n_tot, e_tot)
         achieved = ab[dom] / (avg_ms[dom] * 1e-3) / 1e9
         ms_step = elapsed / args.steps * 1e3
+        traffic = None
+        if args.pmc_traffic and os.path.exists(args.pmc_traffic) and G == 256:
+            with open(args.pmc_traffic) as f:
+                pk = json.load(f)["kernels"]
+            # the dominant kernel has two template variants (last iteration writes less)
+            vals = [v["hbm_bytes_per_launch"] for k, v in pk.items() if k.startswith(dom + "<")]
+            if len(vals) == 2 and dom == "k_iter":      # (T-1) regular launches + 1 last
+                v = sorted(vals)
+                traffic = (v[1] * (T - 1) + v[0]) / T
+            elif vals:
+                traffic = sum(vals) / len(vals)
         value = world * e_tot * args.steps / elapsed
         out = {
             "metric": "edges/sec (EdgeNet+NodeNet fwd) on 100k-edge TrackML graphs; % HBM roofline",
@@ -166,7 +178,7 @@ def main():
                        "no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": args.pmc_traffic_bytes,
+                         "traffic": traffic,
                          "algorithmic_bytes_per_launch": ab[dom],
                          "avg_launch_ms": avg_ms[dom],
                          "kernel_ms": {k: round(v, 4) for k, v in avg_ms.items()},
