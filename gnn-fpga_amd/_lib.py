@@ -39,7 +39,8 @@ class GnnGrads(ctypes.Structure):
 class GnnPlan(ctypes.Structure):
     _fields_ = [(n, _f) for n in ("X", "src", "dst", "in_off", "in_nbr", "out_off", "out_nbr",
                                   "tiles", "chunks")] + \
-               [("n_pad", _i64), ("n_segments", _i64), ("n_tiles", _i64), ("n_chunks", _i64)]
+               [("n_pad", _i64), ("n_segments", _i64), ("n_tiles", _i64), ("n_chunks", _i64),
+                ("iter_lds_records", _i64), ("edge_lds_rows", _i64)]
 
 
 # name -> (restype, argtypes); must list every function include/gnn_hip.h declares
@@ -274,6 +275,7 @@ def plan_struct(plan):
         setattr(g, k, _dev(getattr(plan, k), torch.int32, "plan." + k))
     g.n_pad, g.n_segments = plan.n_pad, plan.n_segments
     g.n_tiles, g.n_chunks = plan.n_tiles, plan.n_chunks
+    g.iter_lds_records, g.edge_lds_rows = plan.iter_lds_records, plan.edge_lds_rows
     return g
 
 

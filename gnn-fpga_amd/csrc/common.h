@@ -25,6 +25,17 @@ void prof_post(hipStream_t s);
             return gnn::fail(-(int)err_, "%s launch failed: %s", NAME, hipGetErrorString(err_)); \
     } while (0)
 
+// same with dynamic LDS bytes
+#define GNN_LAUNCH_SH(NAME, KERNEL, GRID, BLOCK, SHMEM, STREAM, ...)                             \
+    do {                                                                                         \
+        gnn::prof_pre(NAME, STREAM);                                                             \
+        hipLaunchKernelGGL(KERNEL, dim3(GRID), dim3(BLOCK), SHMEM, STREAM, __VA_ARGS__);         \
+        gnn::prof_post(STREAM);                                                                  \
+        hipError_t err_ = hipGetLastError();                                                     \
+        if (err_ != hipSuccess)                                                                  \
+            return gnn::fail(-(int)err_, "%s launch failed: %s", NAME, hipGetErrorString(err_)); \
+    } while (0)
+
 constexpr int kBlock = 256;   // 4 waves of 64
 
 inline unsigned grid_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }

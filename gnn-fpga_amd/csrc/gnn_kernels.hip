@@ -552,6 +552,8 @@ int gnn_segclf_forward_plan(const gnn_plan_t *pl, const gnn_params_t *p, int32_t
     if (!pl || !p || n_iters < 0 || pl->n_pad < 0 || pl->n_segments < 0 || pl->n_tiles < 0 ||
         pl->n_chunks < 0 || (pl->n_pad & 15))
         return fail(GNN_ERR_BADARG, "gnn_segclf_forward_plan: bad argument");
+    if (pl->iter_lds_records < 0 || pl->edge_lds_rows < 0)
+        return fail(GNN_ERR_BADARG, "gnn_segclf_forward_plan: negative LDS size");
     if (!pl->X || !pl->in_off || !pl->out_off || (pl->n_tiles > 0 && !pl->tiles) ||
         (pl->n_segments > 0 && (!pl->src || !pl->dst || !pl->chunks || !e_out)))
         return fail(GNN_ERR_BADARG, "gnn_segclf_forward_plan: plan array missing");

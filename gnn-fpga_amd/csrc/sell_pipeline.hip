@@ -554,9 +554,10 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_iter(
     using L = TL<F, D>;
     using G = Cfg<F, D>;
     constexpr int d4 = L::d4, NT = G::NT;
-    constexpr int WIN = G::it_rec > 0 ? G::it_rec * 2 * D : 4;
-    __shared__ __attribute__((aligned(16))) float lds[L::total];
-    __shared__ __attribute__((aligned(16))) float win[WIN];
+    // dynamic LDS: [weight table | record windows]; sized by the host from the plan, so batches
+    // of small graphs (small windows) get several workgroups per CU
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *lds = smem, *win = smem + L::total;
     stage4<NT>(table, lds, L::total / 4);
 
     // XCD-affine renumbering (matters for global-mode tiles only): blockIdx is dealt round-robin
@@ -695,8 +696,7 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_edge(
     using G = Cfg<F, D>;
     const float *__restrict__ W2 = table + TL<F, D>::o_flat;   // wave-uniform: scalar loads
     constexpr int NT = G::NT;
-    constexpr int WIN = G::ed_rec > 0 ? G::ed_rec * D : 4;
-    __shared__ __attribute__((aligned(16))) float win[WIN];
+    extern __shared__ __attribute__((aligned(16))) float win[];    // sized from the plan
     const int chunk = (blockIdx.x & 7) * chunks_per_xcd + (blockIdx.x >> 3);
     if (chunk >= n_chunks) return;
     const int32_t *cd = chunks + (int64_t)chunk * DESC;
@@ -774,15 +774,23 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
                        w.Pc, w.Qc, Np);
         const int nt = (int)pl->n_tiles;
         const int tpx = (nt + 7) / 8;
+        const size_t it_lds = (size_t)(L::total + (G::it_rec > 0 ? pl->iter_lds_records : 0) * 2 * D + 4) * sizeof(float);
+        static bool attr_done = false;     // dynamic LDS above 64 KB must be opted into, once
+        if (!attr_done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter<F, D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter<F, D, false>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_edge<F, D>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
+            attr_done = true;
+        }
         const char *ab = getenv("GNN_ABLATE");   // timing diagnostics only (results invalid)
         const int ablate = ab ? atoi(ab) : 0;
         for (int t = 0; t < n_iters; ++t) {
             if (t + 1 == n_iters)
-                GNN_LAUNCH("k_iter", (k_iter<F, D, true>), 8 * tpx, G::NT, s, pl->X, w.table,
+                GNN_LAUNCH_SH("k_iter", (k_iter<F, D, true>), 8 * tpx, G::NT, it_lds, s, pl->X, w.table,
                            pl->tiles, pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PR, QS, w.U,
                            PRn, QSn, w.Pc, w.Qc, Np, tpx, nt, ablate);
             else
-                GNN_LAUNCH("k_iter", (k_iter<F, D, false>), 8 * tpx, G::NT, s, pl->X, w.table,
+                GNN_LAUNCH_SH("k_iter", (k_iter<F, D, false>), 8 * tpx, G::NT, it_lds, s, pl->X, w.table,
                            pl->tiles, pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PR, QS, w.U,
                            PRn, QSn, w.Pc, w.Qc, Np, tpx, nt, ablate);
             float *t1 = PR; PR = PRn; PRn = t1;
@@ -792,7 +800,9 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
     if (E > 0) {
         const int nc = (int)pl->n_chunks;
         const int cpx = (nc + 7) / 8;
-        GNN_LAUNCH("k_edge", (k_edge<F, D>), 8 * cpx, G::NT, s, pl->chunks, pl->src, pl->dst, w.Pc,
+        const size_t ed_lds = (size_t)((G::ed_rec > 0 ? pl->edge_lds_rows : 0) * D + 4) * sizeof(float);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_edge<F, D>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
+        GNN_LAUNCH_SH("k_edge", (k_edge<F, D>), 8 * cpx, G::NT, ed_lds, s, pl->chunks, pl->src, pl->dst, w.Pc,
                    w.Qc, w.table, e_out, Np, cpx, nc);
     }
     return 0;

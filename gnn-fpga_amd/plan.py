@@ -97,6 +97,30 @@ def _sell(key_new, other_rel, n_pad, null_of_slice):
     return off.astype(np.int32), nbr
 
 
+def _chunk_bounds(key, ok, E, CH):
+    """Chunk boundaries of the final edge pass.  Segments arrive grouped (the reference emits
+    them per layer pair, gnn/graph.py:80-93): a run of equal (graph, start level) key has all its
+    start hits in one level and its end hits in the next, i.e. the narrowest possible windows.
+    Runs of at least CH/4 segments keep their own boundaries; everything is then cut into equal
+    parts of at most CH segments."""
+    if E == 0:
+        return np.zeros(1, np.int64)
+    k = key.copy()
+    if not ok.all():                                   # padded segments join the run before them
+        idx = np.where(ok, np.arange(E), 0)
+        np.maximum.accumulate(idx, out=idx)
+        k = key[idx]
+    rb = np.flatnonzero(np.r_[True, k[1:] != k[:-1]])  # run starts
+    rsz = np.diff(np.r_[rb, E])
+    big = rsz >= max(1, CH // 4)
+    marks = np.unique(np.r_[0, rb[big], (rb + rsz)[big], E])
+    out = [np.zeros(1, np.int64)]
+    for a, b in zip(marks[:-1].tolist(), marks[1:].tolist()):
+        parts = -(-(b - a) // CH)
+        out.append(a + (np.arange(1, parts + 1, dtype=np.int64) * (b - a)) // parts)
+    return np.concatenate(out)
+
+
 class SellPlan:
     def __init__(self, batch, limits):
         """batch: HitGraphBatch; limits: dict(tile_hits, iter_records, chunk_segments,
@@ -199,10 +223,8 @@ class SellPlan:
 
         # -- final edge pass: chunks of the caller's segment order --------------------------
         CH = int(limits["chunk_segments"])
-        cb = np.arange(0, E + CH, CH, dtype=np.int64)
-        cb[-1] = E
-        if E == 0:
-            cb = np.zeros(1, np.int64)
+        cb = _chunk_bounds(np.where(ok, gid[np.where(ok, src, 0)] * (int(level.max(initial=0)) + 1)
+                                    + level[np.where(ok, src, 0)], -1), ok, E, CH)
         n_chunks = len(cb) - 1
         big = np.iinfo(np.int64).max
         s_lo_e = np.where(ok, src_new, big)
@@ -229,6 +251,9 @@ class SellPlan:
         chunks[:, 4], chunks[:, 5] = d_lo, d_cnt
         chunks[:, 6] = c_lds
         self.n_chunks = n_chunks
+        # LDS actually needed by the launches (records / rows incl. the two NULL slots)
+        self.iter_lds_records = int((in_cnt + out_cnt + 2)[lds_mode].max(initial=0))
+        self.edge_lds_rows = int((s_cnt + d_cnt + 2)[c_lds].max(initial=0))
 
         Xp = np.zeros((n_pad + 1, X.shape[1]), dtype=np.float32)
         Xp[new_of_rank] = X[old_of_rank]

@@ -80,6 +80,8 @@ typedef struct gnn_plan {
     const int32_t *out_off, *out_nbr;    /* [n_pad/16+1], [out_off[last]] segments starting at a hit -> end hit */
     const int32_t *tiles, *chunks;       /* [n_tiles*8], [n_chunks*8] descriptors                  */
     int64_t n_pad, n_segments, n_tiles, n_chunks;
+    int64_t iter_lds_records;            /* max over LDS-mode tiles of in_cnt + out_cnt + 2        */
+    int64_t edge_lds_rows;               /* max over LDS-mode chunks of src_cnt + dst_cnt + 2      */
 } gnn_plan_t;
 
 int gnn_abi_version(void);
