@@ -39,7 +39,7 @@ def algorithmic_bytes(n, e):
     b_node = 8 * e + 4 * e + 4 * n * C + 4 * n * D
     return {"k_input": b_in, "k_edge": b_edge, "k_node": b_node,
             # fused pipeline: k_iter = one edge pass + one node pass; k_edge4 = final edge pass
-            "k_input4": b_in, "k_iter": b_edge + b_node, "k_edge4": b_edge, "k_pack": 0,
+            "k_input4": b_in, "k_iter": b_edge + b_node, "k_iter2": b_edge + b_node, "k_pack": 0,
             "forward": b_in + (T + 1) * b_edge + T * b_node}
 
 
@@ -155,7 +155,7 @@ def main():
                 pk = json.load(f)["kernels"]
             # the dominant kernel has two template variants (last iteration writes less)
             vals = [v["hbm_bytes_per_launch"] for k, v in pk.items() if k.startswith(dom + "<")]
-            if len(vals) == 2 and dom == "k_iter":      # (T-1) regular launches + 1 last
+            if len(vals) == 2 and dom in ("k_iter", "k_iter2"):   # (T-1) regular launches + 1 last
                 v = sorted(vals)
                 traffic = (v[1] * (T - 1) + v[0]) / T
             elif vals:

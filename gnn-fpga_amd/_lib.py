@@ -38,9 +38,12 @@ class GnnGrads(ctypes.Structure):
 
 class GnnPlan(ctypes.Structure):
     _fields_ = [(n, _f) for n in ("X", "src", "dst", "in_off", "in_nbr", "out_off", "out_nbr",
-                                  "tiles", "chunks")] + \
+                                  "tiles", "chunks", "in_off16", "in_nbr16", "out_off16",
+                                  "out_nbr16")] + \
                [("n_pad", _i64), ("n_segments", _i64), ("n_tiles", _i64), ("n_chunks", _i64),
-                ("iter_lds_records", _i64), ("edge_lds_rows", _i64)]
+                ("iter_lds_records", _i64), ("edge_lds_rows", _i64), ("n_lds_tiles", _i64),
+                ("iter_lds_in", _i64), ("iter_lds_out", _i64), ("tile_hits_max", _i64),
+                ("max_list_steps", _i64)]
 
 
 # name -> (restype, argtypes); must list every function include/gnn_hip.h declares
@@ -271,11 +274,15 @@ def plan_limits(F, D):
 def plan_struct(plan):
     g = GnnPlan()
     g.X = _dev(plan.X, torch.float32, "plan.X")
-    for k in ("src", "dst", "in_off", "in_nbr", "out_off", "out_nbr", "tiles", "chunks"):
+    for k in ("src", "dst", "in_off", "in_nbr", "out_off", "out_nbr", "tiles", "chunks",
+              "in_off16", "in_nbr16", "out_off16", "out_nbr16"):
         setattr(g, k, _dev(getattr(plan, k), torch.int32, "plan." + k))
     g.n_pad, g.n_segments = plan.n_pad, plan.n_segments
     g.n_tiles, g.n_chunks = plan.n_tiles, plan.n_chunks
     g.iter_lds_records, g.edge_lds_rows = plan.iter_lds_records, plan.edge_lds_rows
+    g.n_lds_tiles, g.tile_hits_max = plan.n_lds_tiles, plan.tile_hits_max
+    g.iter_lds_in, g.iter_lds_out = plan.iter_lds_in, plan.iter_lds_out
+    g.max_list_steps = plan.max_list_steps
     return g
 
 

@@ -41,6 +41,7 @@
 #include "common.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 using namespace gnn;
@@ -248,7 +249,7 @@ struct Cfg {
     // k_iter window: records of 2D floats ([P|R] or [Q|S]); k_edge window: rows of D floats
     static constexpr int it_rec = (D <= 16) ? (lds_bytes - table_bytes - 2048) / (8 * D) : 0;
     static constexpr int ed_rec = (D <= 16) ? (lds_bytes - 2048) / (4 * D) : 0;
-    static constexpr int tile_hits = 1024;
+    static constexpr int tile_hits = 1280;      // > one 1000-hit detector level incl. fluctuations
     static constexpr int chunk_segments = 8192;
     // Cross-slice prefetch keeps ~25 asm-loaded registers in flight while a slice is processed.
     // That is only legal if the register allocator never spills: a spill of an in-flight
@@ -257,18 +258,20 @@ struct Cfg {
     // remarks); the others wait for the prefetch immediately (same code, no in-flight window).
     // D >= 32 sits at the 256-register cap: the allocator parks values in AGPRs there.
     static constexpr bool pipelined = (D <= 8 && F <= 3) || (D == 4);
+    // shapes whose persistent phase-split kernel (k_iter2) builds with zero scratch / AGPRs
+    static constexpr bool iter2 = (D <= 8 && F <= 3);
 };
 
 // out[i] = bias[i] + sum_k W[k][i] * in[k]  for this lane's d4 rows.  The block
 // { bias[d4], W[KD+KF][d4] } sits 16-byte aligned in LDS; it is fetched with ds_read_b128
-// into registers in chunks of up to 32 floats before the FMAs consume it (one wait per chunk
-// instead of one per pair of weights).
+// into registers in chunks of 8 floats before the FMAs consume it (larger chunks cost registers
+// the prefetching kernels do not have).
 template <int D4, int KD, int KF>
 __device__ __forceinline__ void role_gemv(const float *w, const float *hn, const float *x,
                                           float *out)
 {
     constexpr int NW = D4 + (KD + KF) * D4;
-    constexpr int CH = 16;
+    constexpr int CH = 8;
     const float4 *w4 = reinterpret_cast<const float4 *>(__builtin_assume_aligned(w, 16));
 #pragma unroll
     for (int c0 = 0; c0 < NW; c0 += CH) {
@@ -368,10 +371,14 @@ __global__ __launch_bounds__(256) void k_input4(const float *__restrict__ X,
 }
 
 // r(z') = 1 / (1 + 2^z'): the only transcendental pair of the edge MLP (see scale folding)
+#ifdef GNN_ABLATE_TRANS
+__device__ __forceinline__ float r_f(float zs) { return fmaf(zs, 0.25f, 0.5f) * zs; }   // timing only
+#else
 __device__ __forceinline__ float r_f(float zs)
 {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(zs));
 }
+#endif
 
 // ---- untracked prefetch ------------------------------------------------------------------------
 // Loads issued through asm are invisible to the compiler's s_waitcnt insertion, which otherwise
@@ -472,8 +479,16 @@ struct Recs {
         constexpr int d4 = D / 4;
         const int nb[4] = {quad_bcast_i<0>(cur), quad_bcast_i<1>(cur), quad_bcast_i<2>(cur),
                            quad_bcast_i<3>(cur)};
+#ifdef GNN_ABLATE_LDS
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 2 * d4; ++i) r[j][i] = __int_as_float(nb[j] + i);   // timing only
+        (void)REC;
+#else
 #pragma unroll
         for (int j = 0; j < 4; ++j) load_vec<2 * d4>(REC + (int64_t)nb[j] * 2 * D + q * 2 * d4, r[j]);
+#endif
     }
 };
 
@@ -536,6 +551,47 @@ __device__ __forceinline__ void sweep(const int *pre, const int32_t *__restrict_
     for (int k = 4 * MAXC; k < len; k += 4) {
         a.read(fix(lst[k * SLICE], len - k), REC, q);
         score4<d4>(a.r, own, w2, b2, q, acc);
+    }
+}
+
+// Walk of a 16-bit packed list (plan.py _pack16): every register of c[] holds 8 steps for the quad
+// (lane q: steps 8sc+2q and 8sc+2q+1), the registers ROTATE through c[0] so this is a real loop.
+// Steps past the list end are NULL entries already (the packed lists are padded), so no fix-up.
+template <int D, int NC>
+__device__ __forceinline__ void sweep16(int (&c)[NC], const int32_t *__restrict__ nbr16,
+                                        const int32_t *__restrict__ off16, int slice, int i16,
+                                        int len, const float *REC, int q, const float *own,
+                                        const float *w2, float b2, float *acc)
+{
+    constexpr int d4 = D / 4;
+    for (int k = 0; k < len; k += 8) {
+        int w = c[0];
+        if (k >= 8 * NC) {      // list longer than the prefetched words (rare): fetch and wait here,
+                                // through asm so the compiler tracks no pending load on `w`
+            a_load_i32<0>(w, nbr16 + __builtin_amdgcn_readfirstlane(off16[slice]) + ((k >> 3) * 4 + q) * SLICE + i16);
+            a_wait_all();
+            asm volatile("" : "+v"(w));
+        }
+#pragma unroll
+        for (int i = 0; i + 1 < NC; ++i) c[i] = c[i + 1];
+        const int w01 = quad_bcast_i<0>(w), w23 = quad_bcast_i<1>(w);
+        {
+            const int nb[4] = {w01 & 0xFFFF, (int)((unsigned)w01 >> 16), w23 & 0xFFFF,
+                               (int)((unsigned)w23 >> 16)};
+            float r[4][2 * d4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) load_vec<2 * d4>(REC + nb[j] * 2 * D + q * 2 * d4, r[j]);
+            score4<d4>(r, own, w2, b2, q, acc);
+        }
+        if (k + 4 < len) {
+            const int w45 = quad_bcast_i<2>(w), w67 = quad_bcast_i<3>(w);
+            const int nb[4] = {w45 & 0xFFFF, (int)((unsigned)w45 >> 16), w67 & 0xFFFF,
+                               (int)((unsigned)w67 >> 16)};
+            float r[4][2 * d4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) load_vec<2 * d4>(REC + nb[j] * 2 * D + q * 2 * d4, r[j]);
+            score4<d4>(r, own, w2, b2, q, acc);
+        }
     }
 }
 
@@ -684,6 +740,223 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_iter(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_iter2: persistent, phase-split variant of k_iter for batches whose tiles all run in LDS mode
+// ---------------------------------------------------------------------------------------------
+// k_iter holds both record windows of a tile in LDS (128 KB at 1000 hits/level, D = 8), so a CU
+// runs one workgroup whose memory phases (window staging, first prefetch, launch) and compute
+// phases simply add up (measured: 0.19 ms VALU issue + 0.24 ms memory = 0.43 ms).  Here ONE
+// workgroup per CU walks its tiles (tile = blockIdx.x + k * gridDim.x, fixed trip count, no
+// inter-workgroup communication) and splits every tile in two phases:
+//   phase A: all in-sweeps of the tile (needs only the PR window, bufA); accumulators of the up to
+//            4 slices a wave owns stay in registers;
+//   phase B: all out-sweeps (QS window, bufB), hit updates and stores.
+// While phase A computes, the tile's QS window is in flight (asm loads into registers, written
+// to bufB at the end of the phase); while phase B computes, the NEXT tile's PR window is in
+// flight.  So window staging, list prefetch and stores all run under VALU work.
+template <int F, int D, bool LAST>
+__global__ __launch_bounds__(1024) void k_iter2(
+    const float *__restrict__ X, const float *__restrict__ table,
+    const int32_t *__restrict__ tiles, const int32_t *__restrict__ in_off,
+    const int32_t *__restrict__ in_off16, const int32_t *__restrict__ in_nbr16,
+    const int32_t *__restrict__ out_off, const int32_t *__restrict__ out_off16,
+    const int32_t *__restrict__ out_nbr16, const float *__restrict__ PR,
+    const float *__restrict__ QS, float *__restrict__ U, float *__restrict__ PRn,
+    float *__restrict__ QSn, float *__restrict__ Pc, float *__restrict__ Qc, int64_t n_pad,
+    int n_tiles, int capA)
+{
+    using L = TL<F, D>;
+    constexpr int d4 = L::d4, NT = 1024, NWV = NT / 64, NC = 4;   // NC words = 32 list steps
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *lds = smem, *bufA = smem + L::total, *bufB = bufA + (int64_t)capA * 2 * D;
+    stage4<NT>(table, lds, L::total / 4);            // visible after the first barrier
+    int tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    const int tid = threadIdx.x, lane = tid & 63, q = lane & 3, i16 = lane >> 2, wv = tid >> 6;
+
+    struct Desc { int s_begin, s_end, in_lo, in_cnt, out_lo, out_cnt; };
+    auto load_desc = [&](int t) {
+        const int32_t *td = tiles + (int64_t)t * DESC;
+        Desc d;
+        d.s_begin = td[0]; d.s_end = td[1]; d.in_lo = td[2]; d.in_cnt = td[3];
+        d.out_lo = td[4]; d.out_cnt = td[5];
+        return d;
+    };
+    auto slice_of = [&](const Desc &d, int r) {      // zig-zag deal of degree-sorted slices
+        const int sl = d.s_begin + r * NWV + ((r & 1) ? NWV - 1 - wv : wv);
+        return sl < d.s_end ? sl : -1;
+    };
+
+    // ---- window staging by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write) -------------
+    // One wave-instruction moves 64 lanes x 16 B = 1 KiB to a wave-uniform LDS address; waves
+    // take 1-KiB pieces round-robin.  The last piece may run up to 1 KiB past the window: the
+    // buffers are sized in whole pieces plus one (NULL record) and the workspace rows are padded.
+    auto stage_issue = [&](const float *src, float *buf, int nrec) {
+        const int pieces = (nrec * 2 * D + 255) / 256;
+        for (int c = wv; c < pieces; c += NWV)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(src + (int64_t)c * 256 + lane * 4),
+                (__attribute__((address_space(3))) void *)(buf + c * 256), 16, 0, 0);
+    };
+    auto stage_commit = [&](float *buf, const float *null_rec, int nrec) {
+        a_wait_all();                                                  // DMA pieces have landed
+        if (tid < 2 * D / 4)                                           // NULL record
+            reinterpret_cast<f4_t *>(buf)[nrec * 2 * D / 4 + tid] =
+                reinterpret_cast<const f4_t *>(null_rec)[tid];
+    };
+
+    // ---- per-slice prefetch (one slice ahead), split by phase -------------------------------------
+    struct PreA { int len; int c[NC]; AVec<d4> Q, U; };             // in-list, own Q, acc init
+    struct PreB { int len; int c[NC]; AVec<d4> P, U; AVec<F> x; };  // out-list, own P, acc, X row
+    auto prefetchA = [&](PreA &p, int slice) {
+        p.len = (__builtin_amdgcn_readfirstlane(in_off[slice + 1]) -
+                 __builtin_amdgcn_readfirstlane(in_off[slice])) >> 4;
+        const int32_t *li = in_nbr16 + __builtin_amdgcn_readfirstlane(in_off16[slice]) + q * SLICE + i16;
+#define GNN_PF(C_) if (8 * C_ < p.len) a_load_i32<C_ * 4 * SLICE * 4>(p.c[C_], li);
+        GNN_PF(0) GNN_PF(1) GNN_PF(2) GNN_PF(3)
+#undef GNN_PF
+        const int64_t n = (int64_t)slice * SLICE + i16;
+        p.Q.load(QS + n * 2 * D + q * 2 * d4);
+        p.U.load(U + n * D + q * d4);
+    };
+    auto prefetchB = [&](PreB &p, int slice) {
+        p.len = (__builtin_amdgcn_readfirstlane(out_off[slice + 1]) -
+                 __builtin_amdgcn_readfirstlane(out_off[slice])) >> 4;
+        const int32_t *lo = out_nbr16 + __builtin_amdgcn_readfirstlane(out_off16[slice]) + q * SLICE + i16;
+#define GNN_PF(C_) if (8 * C_ < p.len) a_load_i32<C_ * 4 * SLICE * 4>(p.c[C_], lo);
+        GNN_PF(0) GNN_PF(1) GNN_PF(2) GNN_PF(3)
+#undef GNN_PF
+        static_assert(NC == 4, "prefetch is written out for 4 words (32 steps)");
+        const int64_t n = (int64_t)slice * SLICE + i16;
+        p.P.load(PR + n * 2 * D + q * 2 * d4);
+        p.U.load(U + n * D + q * d4);        // U[n] + in-sweep sum, written by this lane in phase A
+        p.x.load(X + n * F);
+    };
+    auto arriveA = [&](PreA &p) { a_wait_all(); a_fence(p.c); p.Q.fence(); p.U.fence(); };
+    auto arriveB = [&](PreB &p) { a_wait_all(); a_fence(p.c); p.P.fence(); p.U.fence(); p.x.fence(); };
+
+    // ---- prologue: first tile's PR window, first slice of phase A ---------------------------------
+    Desc d = load_desc(tile);
+    PreA a_cur, a_nxt;
+    PreB b_cur, b_nxt;
+    stage_issue(PR + (int64_t)d.in_lo * 2 * D, bufA, d.in_cnt);
+    if (slice_of(d, 0) >= 0) prefetchA(a_cur, slice_of(d, 0));
+    stage_commit(bufA, PR + n_pad * 2 * D, d.in_cnt);
+    if (slice_of(d, 0) >= 0) arriveA(a_cur);
+
+    float w2[d4];
+    for (;;) {
+        __syncthreads();                               // bufA (and, first time, the table) visible
+#pragma unroll
+        for (int i = 0; i < d4; ++i) w2[i] = lds[q * L::stride + L::o_w2 + i];
+        const float b2 = lds[L::o_b2];
+        const int rounds = (d.s_end - d.s_begin + NWV - 1) / NWV;
+        // ================= phase A: in-sweeps; QS window of this tile in flight ==================
+        // The partial sum goes back to U[n] (same lane reads it again in phase B: an L2 round
+        // trip, not HBM) so that the round loop needs no per-round register state.
+        stage_issue(QS + (int64_t)d.out_lo * 2 * D, bufB, d.out_cnt);
+        // The last round is peeled (LR = true): it requests the first slice of phase B instead of
+        // a next in-slice.  Written as one generic lambda so b_cur is DEFINED only there: a
+        // conditional assignment inside the loop would keep it live across all rounds.
+        auto roundA = [&](int r, auto lr) {
+            constexpr bool LR = decltype(lr)::value;
+            const int slice = slice_of(d, r);
+            const int next = LR ? -1 : slice_of(d, r + 1);
+            // The first slice of phase B re-reads U[n] of round 0.  With several rounds that store is
+            // long done; with a single round it is THIS round's store, so the request goes after it.
+            if constexpr (LR) {
+                if (rounds > 1 && slice_of(d, 0) >= 0) prefetchB(b_cur, slice_of(d, 0));
+            } else {
+                if (next >= 0) prefetchA(a_nxt, next);
+            }
+            float acc[d4];
+            const int64_t n = (int64_t)slice * SLICE + i16;
+            if (slice >= 0) {
+                float Qn[d4];
+                a_cur.U.get(acc);
+                a_cur.Q.get(Qn);
+                const int len = __builtin_amdgcn_readfirstlane(a_cur.len);
+                sweep16<D, NC>(a_cur.c, in_nbr16, in_off16, slice, i16, len, bufA, q, Qn, w2, b2, acc);
+            }
+            if constexpr (!LR) {
+                if (next >= 0) {
+                    arriveA(a_nxt);
+                    a_cur = a_nxt;
+                }
+            }
+            if (slice >= 0) store_vec<d4>(U + n * D + q * d4, acc);
+            if constexpr (LR) {
+                if (rounds <= 1 && slice_of(d, 0) >= 0) prefetchB(b_cur, slice_of(d, 0));
+            }
+        };
+        for (int r = 0; r + 1 < rounds; ++r) roundA(r, std::false_type{});
+        roundA(rounds - 1, std::true_type{});
+        stage_commit(bufB, QS + n_pad * 2 * D, d.out_cnt);   // also makes b_cur readable (vmcnt 0)
+        if (slice_of(d, 0) >= 0) arriveB(b_cur);
+        __syncthreads();                               // bufB visible, bufA free
+        // ================= phase B: out-sweeps, hit update, stores; next PR window in flight ======
+        const int tnext = tile + gridDim.x;
+        Desc dn = d;
+        if (tnext < n_tiles) {
+            dn = load_desc(tnext);
+            stage_issue(PR + (int64_t)dn.in_lo * 2 * D, bufA, dn.in_cnt);
+        }
+        auto roundB = [&](int r, auto lr) {
+            constexpr bool LR = decltype(lr)::value;
+            const int slice = slice_of(d, r);
+            const int next = LR ? -1 : slice_of(d, r + 1);
+            if constexpr (LR) {      // first slice of the next tile's phase A
+                if (tnext < n_tiles && slice_of(dn, 0) >= 0) prefetchA(a_cur, slice_of(dn, 0));
+            } else {
+                if (next >= 0) prefetchB(b_nxt, next);
+            }
+            const int64_t n = (int64_t)slice * SLICE + i16;
+            float xv[F], acc[d4];
+            if (slice >= 0) {
+                float Pn[d4];
+                b_cur.P.get(Pn);
+                b_cur.U.get(acc);
+                b_cur.x.get(xv);
+                const int len = __builtin_amdgcn_readfirstlane(b_cur.len);
+                sweep16<D, NC>(b_cur.c, out_nbr16, out_off16, slice, i16, len, bufB, q, Pn, w2, b2, acc);
+            }
+            // the next slice's registers arrive here (in flight during the sweep); doing it before
+            // the hit update keeps the two register sets from overlapping with the MLP's
+            if constexpr (!LR) {
+                if (next >= 0) {
+                    arriveB(b_nxt);
+                    b_cur = b_nxt;
+                }
+            }
+            if (slice >= 0) {
+                // opaque weight-table offset: keeps the LDS weight reads out of registers
+                int woff = q * L::stride;
+                asm volatile("" : "+v"(woff));
+                const float *wl = lds + woff;
+                // hit update: H' = tanh(W4 tanh(acc) + b4)              (model.py:94-98,125)
+                float ql[d4], qa[D], hl[d4], hn[D];
+#pragma unroll
+                for (int i = 0; i < d4; ++i) ql[i] = tanh_f(acc[i]);
+                quad_allgather<d4>(ql, qa);
+                role_gemv<d4, D, 0>(wl + L::o_4, qa, qa, hl);
+#pragma unroll
+                for (int i = 0; i < d4; ++i) hl[i] = tanh_f(hl[i]);
+                quad_allgather<d4>(hl, hn);
+                Records<F, D, LAST> rec;
+                rec.compute(wl, hn, xv);
+                rec.store(n, q, PRn, QSn, U, Pc, Qc);
+            }
+        };
+        for (int r = 0; r + 1 < rounds; ++r) roundB(r, std::false_type{});
+        roundB(rounds - 1, std::true_type{});
+        if (tnext >= n_tiles) break;
+        stage_commit(bufA, PR + n_pad * 2 * D, dn.in_cnt);   // also makes a_cur readable
+        if (slice_of(dn, 0) >= 0) arriveA(a_cur);
+        tile = tnext;
+        d = dn;
+    }
+}
+
 // final edge pass (model.py:156) for one chunk of the caller's segment order; one lane per
 // segment, P rows of the start hits and Q rows of the end hits from LDS windows or global.
 template <int F, int D>
@@ -745,7 +1018,8 @@ Ws carve(char *b, int64_t n_pad, int table_floats, int D)
         off += align256(nfloat * sizeof(float));
         return p;
     };
-    const size_t rec = (size_t)(n_pad + 1) * 2 * D, vec = (size_t)(n_pad + 1) * D;
+    // + 64 rows: the LDS-DMA staging of k_iter2 reads whole 1-KiB pieces past a window's end
+    const size_t rec = (size_t)(n_pad + 1 + 64) * 2 * D, vec = (size_t)(n_pad + 1) * D;
     w.table = take((size_t)table_floats);
     w.PRa = take(rec); w.PRb = take(rec); w.QSa = take(rec); w.QSb = take(rec);
     w.U = take(vec); w.Pc = take(vec); w.Qc = take(vec);
@@ -784,7 +1058,52 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
         }
         const char *ab = getenv("GNN_ABLATE");   // timing diagnostics only (results invalid)
         const int ablate = ab ? atoi(ab) : 0;
+        // persistent phase-split kernel when every tile runs in LDS mode and both windows fit LDS;
+        // otherwise the general kernel
+        bool use2 = false;
+        size_t it2_lds = 0;
+        int capA = 0, grid2 = 0;
+        if constexpr (D <= 16) {
+            // window buffers in whole 1-KiB DMA pieces (= 128 / D records) plus one piece that
+            // holds the NULL record and absorbs the last piece's overrun
+            const int64_t rpp = 128 / D;                       // records per piece
+            const int64_t capa = (pl->iter_lds_in + rpp - 1) / rpp * rpp + rpp;
+            const int64_t capb = (pl->iter_lds_out + rpp - 1) / rpp * rpp + rpp;
+            use2 = G::iter2 && !getenv("GNN_NO_ITER2") && nt > 0 && pl->n_lds_tiles == nt &&
+                   pl->in_nbr16 && pl->out_nbr16 && pl->in_off16 && pl->out_off16;
+            capA = (int)capa;
+            it2_lds = (size_t)(L::total + (capa + capb) * 2 * D + 4) * sizeof(float);
+            if (it2_lds > (size_t)G::lds_bytes) use2 = false;
+            static int n_cu = 0;
+            if (!n_cu) {
+                int dev = 0;
+                hipDeviceProp_t prop;
+                if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                    n_cu = prop.multiProcessorCount;
+                if (n_cu <= 0) n_cu = 256;
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter2<F, D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter2<F, D, false>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
+            }
+            grid2 = nt < n_cu ? nt : n_cu;
+        }
         for (int t = 0; t < n_iters; ++t) {
+            if constexpr (D <= 16) {
+                if (use2) {
+                    if (t + 1 == n_iters)
+                        GNN_LAUNCH_SH("k_iter2", (k_iter2<F, D, true>), grid2, 1024, it2_lds, s, pl->X, w.table,
+                                      pl->tiles, pl->in_off, pl->in_off16, pl->in_nbr16, pl->out_off,
+                                      pl->out_off16, pl->out_nbr16, PR, QS,
+                                      w.U, PRn, QSn, w.Pc, w.Qc, Np, nt, capA);
+                    else
+                        GNN_LAUNCH_SH("k_iter2", (k_iter2<F, D, false>), grid2, 1024, it2_lds, s, pl->X, w.table,
+                                      pl->tiles, pl->in_off, pl->in_off16, pl->in_nbr16, pl->out_off,
+                                      pl->out_off16, pl->out_nbr16, PR, QS,
+                                      w.U, PRn, QSn, w.Pc, w.Qc, Np, nt, capA);
+                    float *t1 = PR; PR = PRn; PRn = t1;
+                    float *t2 = QS; QS = QSn; QSn = t2;
+                    continue;
+                }
+            }
             if (t + 1 == n_iters)
                 GNN_LAUNCH_SH("k_iter", (k_iter<F, D, true>), 8 * tpx, G::NT, it_lds, s, pl->X, w.table,
                            pl->tiles, pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PR, QS, w.U,

@@ -50,6 +50,15 @@ def topological_levels(src, dst, n, max_iter=64):
         if np.array_equal(new, level):
             break
         level = new
+    # a hit without incoming segments would sit at level 0 whatever its layer and stretch the
+    # windows of that tile over the whole graph: place it one level below its nearest end hit
+    no_in = np.ones(n, dtype=bool)
+    no_in[uniq] = False
+    so = np.argsort(src, kind="stable")
+    us, st = np.unique(src[so], return_index=True)
+    down = np.minimum.reduceat(level[dst[so]], st) - 1
+    fix = no_in[us]
+    level[us[fix]] = np.maximum(down[fix], 0)
     return level
 
 
@@ -95,6 +104,30 @@ def _sell(key_new, other_rel, n_pad, null_of_slice):
     # the kernel reads lists in chunks of 4 steps: up to 3 steps past the end of the last list
     nbr = np.concatenate([nbr, np.zeros(4 * SLICE, dtype=np.int32)])
     return off.astype(np.int32), nbr
+
+
+def _pack16(off, nbr, null_of_slice):
+    """16-bit packed copy of SELL-16 lists for the phase-split kernel (k_iter2).
+
+    Steps are padded per slice to a multiple of 8 with the slice's NULL entry and consecutive
+    step pairs share one 32-bit word: word p of hit i of a slice holds steps 2p (low half) and
+    2p+1 (high half) at `off16[s] + 16*p + i`.  Lane q of a quad loads word 4*sc+q of
+    super-chunk sc, i.e. one load covers 8 list steps.  Entries are window-relative (< 65536)."""
+    n_slices = off.shape[0] - 1
+    L = np.diff(off.astype(np.int64)) // SLICE                 # steps per slice
+    steps8 = (L + 7) // 8 * 8
+    poff = np.zeros(n_slices + 1, dtype=np.int64)
+    np.cumsum(steps8 * SLICE, out=poff[1:])
+    pad = np.repeat((null_of_slice.astype(np.int64) & 0xFFFF), steps8 * SLICE)
+    real = int(off[-1])
+    if real:
+        s_of = np.repeat(np.arange(n_slices), L * SLICE)
+        idx = np.arange(real, dtype=np.int64)
+        pad[idx - off.astype(np.int64)[s_of] + poff[s_of]] = nbr[:real].astype(np.int64) & 0xFFFF
+    pr = pad.reshape(-1, 2, SLICE)
+    words = (pr[:, 0, :] | (pr[:, 1, :] << 16)).reshape(-1)
+    words = np.concatenate([words, np.zeros(64, dtype=np.int64)])
+    return (poff // 2).astype(np.int32), words.astype(np.uint32).view(np.int32)
 
 
 def _chunk_bounds(key, ok, E, CH):
@@ -210,10 +243,11 @@ class SellPlan:
             t = tile_of_new[key_new]
             rel = np.where(lds_mode[t], other_new - lo[t], other_new)
             null = np.where(lds_mode[slice_tile], cnt[slice_tile], n_pad)
-            return _sell(key_new, rel.astype(np.int32), n_pad, null)
+            off, nbr = _sell(key_new, rel.astype(np.int32), n_pad, null)
+            return (off, nbr) + _pack16(off, nbr, null)
 
-        in_off, in_nbr = lists(vd_new, vs_new, in_lo, in_cnt)
-        out_off, out_nbr = lists(vs_new, vd_new, out_lo, out_cnt)
+        in_off, in_nbr, in_off16, in_nbr16 = lists(vd_new, vs_new, in_lo, in_cnt)
+        out_off, out_nbr, out_off16, out_nbr16 = lists(vs_new, vd_new, out_lo, out_cnt)
         tiles = np.zeros((n_tiles, TILE_DESC), dtype=np.int32)
         tiles[:, 0] = tb[:-1] // SLICE
         tiles[:, 1] = tb[1:] // SLICE
@@ -254,6 +288,11 @@ class SellPlan:
         # LDS actually needed by the launches (records / rows incl. the two NULL slots)
         self.iter_lds_records = int((in_cnt + out_cnt + 2)[lds_mode].max(initial=0))
         self.edge_lds_rows = int((s_cnt + d_cnt + 2)[c_lds].max(initial=0))
+        self.n_lds_tiles = int(lds_mode.sum())
+        self.iter_lds_in = int(in_cnt[lds_mode].max(initial=0))
+        self.iter_lds_out = int(out_cnt[lds_mode].max(initial=0))
+        self.tile_hits_max = int(tpad.max(initial=0))
+        self.max_list_steps = int(max(np.diff(in_off).max(initial=0), np.diff(out_off).max(initial=0))) // SLICE
 
         Xp = np.zeros((n_pad + 1, X.shape[1]), dtype=np.float32)
         Xp[new_of_rank] = X[old_of_rank]
@@ -262,6 +301,8 @@ class SellPlan:
         self.src, self.dst = t(src_st.astype(np.int32)), t(dst_st.astype(np.int32))
         self.in_off, self.in_nbr = t(in_off), t(in_nbr)
         self.out_off, self.out_nbr = t(out_off), t(out_nbr)
+        self.in_off16, self.in_nbr16 = t(in_off16), t(in_nbr16)
+        self.out_off16, self.out_nbr16 = t(out_off16), t(out_nbr16)
         self.tiles, self.chunks = t(tiles.reshape(-1)), t(chunks.reshape(-1))
         self.perm = t(perm.astype(np.int32))
         nv = max(1, int(ok.sum()))
@@ -272,8 +313,8 @@ class SellPlan:
         self.src_abs, self.dst_abs = src_new, dst_new
         self.level = level
 
-    _TENSORS = ("X", "src", "dst", "in_off", "in_nbr", "out_off", "out_nbr", "tiles", "chunks",
-                "perm")
+    _TENSORS = ("X", "src", "dst", "in_off", "in_nbr", "out_off", "out_nbr", "in_off16", "in_nbr16",
+                "out_off16", "out_nbr16", "tiles", "chunks", "perm")
 
     def to(self, device):
         for k in self._TENSORS:

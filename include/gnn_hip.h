@@ -79,9 +79,16 @@ typedef struct gnn_plan {
     const int32_t *in_off, *in_nbr;      /* [n_pad/16+1], [in_off[last]]  segments ending at a hit -> start hit */
     const int32_t *out_off, *out_nbr;    /* [n_pad/16+1], [out_off[last]] segments starting at a hit -> end hit */
     const int32_t *tiles, *chunks;       /* [n_tiles*8], [n_chunks*8] descriptors                  */
+    /* 16-bit packed copy of the lists (window-relative entries, steps padded to 8 per slice,
+     * word p of hit i of slice s = steps 2p | 2p+1 << 16 at off16[s] + 16*p + i) */
+    const int32_t *in_off16, *in_nbr16, *out_off16, *out_nbr16;
     int64_t n_pad, n_segments, n_tiles, n_chunks;
     int64_t iter_lds_records;            /* max over LDS-mode tiles of in_cnt + out_cnt + 2        */
     int64_t edge_lds_rows;               /* max over LDS-mode chunks of src_cnt + dst_cnt + 2      */
+    int64_t n_lds_tiles;                 /* number of tiles with mode = 1                          */
+    int64_t iter_lds_in, iter_lds_out;   /* max in_cnt / out_cnt over LDS-mode tiles               */
+    int64_t tile_hits_max;               /* largest tile, in (padded) hits                         */
+    int64_t max_list_steps;              /* longest SELL list of any slice, in steps               */
 } gnn_plan_t;
 
 int gnn_abi_version(void);

@@ -157,15 +157,18 @@ def test_pipelined_kernels_never_spill():
     seen = 0
     for b in blocks:
         name = subprocess.run(["c++filt", b.split()[0]], capture_output=True, text=True).stdout
-        m = re.search(r"k_iter<(\d+), (\d+), (true|false)>", name)
+        m = re.search(r"(k_iter2?)<(\d+), (\d+), (true|false)>", name)
         if not m:
             continue
-        F, D = int(m.group(1)), int(m.group(2))
-        pipelined = (D <= 8 and F <= 3) or D == 4                 # mirrors Cfg::pipelined
+        F, D = int(m.group(2)), int(m.group(3))
+        if m.group(1) == "k_iter":
+            pipelined = (D <= 8 and F <= 3) or D == 4             # mirrors Cfg::pipelined
+        else:
+            pipelined = D <= 8 and F <= 3                         # mirrors Cfg::iter2
         scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
         agprs = int(re.search(r"AGPRs: (\d+)", b).group(1))
         if pipelined:
             seen += 1
-            assert agprs == 0, "k_iter<%d,%d> is pipelined but parks values in AGPRs" % (F, D)
-            assert scratch == 0, "k_iter<%d,%d> is pipelined but spills %d bytes" % (F, D, scratch)
-    assert seen >= 8
+            assert agprs == 0, "%s<%d,%d> is pipelined but parks values in AGPRs" % (m.group(1), F, D)
+            assert scratch == 0, "%s<%d,%d> is pipelined but spills %d bytes" % (m.group(1), F, D, scratch)
+    assert seen >= 16

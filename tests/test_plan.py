@@ -136,3 +136,30 @@ def test_plan_handles_cycles_and_empty():
     empty = HitGraphBatch(X, np.zeros(0, np.int32), np.zeros(0, np.int32))
     pe = SellPlan(empty, _lib.plan_limits(3, 8))
     assert pe.n_segments == 0 and pe.n_chunks == 0 and emulate(pe, fx.params, 2).shape == (0,)
+
+
+def test_packed16_lists_decode_to_the_sell_lists():
+    """plan._pack16: word p of hit i of slice s = steps 2p | 2p+1 << 16, steps padded to 8 with
+    the tile's NULL entry."""
+    graphs = [synth.layered_graph(300, 1500, 3, seed=s) for s in range(3)]
+    b = HitGraphBatch.from_graphs(graphs)
+    plan = SellPlan(b, _lib.plan_limits(3, 8))
+    assert plan.lds_tile_fraction == 1.0
+    tiles = plan.tiles.numpy().reshape(-1, 8)
+    for off, nbr, off16, nbr16, col in ((plan.in_off, plan.in_nbr, plan.in_off16, plan.in_nbr16, 3),
+                                        (plan.out_off, plan.out_nbr, plan.out_off16, plan.out_nbr16, 5)):
+        off, nbr, off16 = off.numpy(), nbr.numpy(), off16.numpy()
+        w = nbr16.numpy().view(np.uint32)
+        for (s0, s1, *_rest) in tiles:
+            null = tiles[np.searchsorted(tiles[:, 0], s0, side="right") - 1][col]
+            for sl in range(s0, s1):
+                L = (off[sl + 1] - off[sl]) // SLICE
+                n8 = (L + 7) // 8 * 8
+                assert (off16[sl + 1] - off16[sl]) == n8 // 2 * SLICE
+                for step in range(n8):
+                    word = w[off16[sl] + (step // 2) * SLICE + np.arange(SLICE)]
+                    got = (word >> (16 * (step % 2))) & 0xFFFF
+                    want = nbr[off[sl] + step * SLICE + np.arange(SLICE)] if step < L else null
+                    assert np.all(got == want)
+    assert plan.max_list_steps == max(np.diff(plan.in_off.numpy()).max(),
+                                      np.diff(plan.out_off.numpy()).max()) // SLICE
