@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--graphs", type=int, default=256, help="graphs per launch per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="experiment: replay the forward from a captured HIP graph")
     ap.add_argument("--global-gather", action="store_true",
                     help="experiment: disable the LDS windows (gather records from global memory)")
     ap.add_argument("--pmc-traffic", default=os.path.join(REPO, "profiles", "pmc_traffic.json"),
@@ -122,10 +124,18 @@ def main():
     with torch.no_grad():
         for _ in range(args.warmup):
             model(batch)
+        step = lambda: model(batch)
+        if args.graph:
+            sync_all()
+            cg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cg):
+                model(batch)
+            step = cg.replay
+            step()
         sync_all()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            model(batch)
+            step()
         sync_all()
         elapsed = time.perf_counter() - t0
         # per-kernel durations: HIP events recorded by the library around every launch,

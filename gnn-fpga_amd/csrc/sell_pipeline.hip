@@ -506,7 +506,11 @@ __device__ __forceinline__ void score4(const float (*rec)[2 * D4], const float *
     for (int j = 0; j < 4; ++j) {
         part[j] = 0.0f;
 #pragma unroll
+#ifdef GNN_TIMING_EXPPROD
+        for (int i = 0; i < D4; ++i) part[j] = fmaf(w2[i], __builtin_amdgcn_rcpf(fmaf(rec[j][i], own[i], 1.0f)), part[j]);
+#else
         for (int i = 0; i < D4; ++i) part[j] = fmaf(w2[i], r_f(rec[j][i] + own[i]), part[j]);
+#endif
     }
     // stage 1 (xor 1): even lanes keep segments {0,2}, odd lanes {1,3}
     const bool odd = q & 1, hi = q & 2;
@@ -760,7 +764,8 @@ __global__ __launch_bounds__(1024) void k_iter2(
     const int32_t *__restrict__ tiles, const int32_t *__restrict__ in_off,
     const int32_t *__restrict__ in_off16, const int32_t *__restrict__ in_nbr16,
     const int32_t *__restrict__ out_off, const int32_t *__restrict__ out_off16,
-    const int32_t *__restrict__ out_nbr16, const float *__restrict__ PR,
+    const int32_t *__restrict__ out_nbr16, const int32_t *__restrict__ sched_a,
+    const int32_t *__restrict__ sched_b, const float *__restrict__ PR,
     const float *__restrict__ QS, float *__restrict__ U, float *__restrict__ PRn,
     float *__restrict__ QSn, float *__restrict__ Pc, float *__restrict__ Qc, int64_t n_pad,
     int n_tiles, int capA)
@@ -772,20 +777,20 @@ __global__ __launch_bounds__(1024) void k_iter2(
     stage4<NT>(table, lds, L::total / 4);            // visible after the first barrier
     int tile = blockIdx.x;
     if (tile >= n_tiles) return;
-    const int tid = threadIdx.x, lane = tid & 63, q = lane & 3, i16 = lane >> 2, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, q = lane & 3, i16 = lane >> 2;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    struct Desc { int s_begin, s_end, in_lo, in_cnt, out_lo, out_cnt; };
+    struct Desc { int s_begin, s_end, in_lo, in_cnt, out_lo, out_cnt, sbase; };
     auto load_desc = [&](int t) {
         const int32_t *td = tiles + (int64_t)t * DESC;
         Desc d;
         d.s_begin = td[0]; d.s_end = td[1]; d.in_lo = td[2]; d.in_cnt = td[3];
-        d.out_lo = td[4]; d.out_cnt = td[5];
+        d.out_lo = td[4]; d.out_cnt = td[5]; d.sbase = td[7];
         return d;
     };
-    auto slice_of = [&](const Desc &d, int r) {      // zig-zag deal of degree-sorted slices
-        const int sl = d.s_begin + r * NWV + ((r & 1) ? NWV - 1 - wv : wv);
-        return sl < d.s_end ? sl : -1;
-    };
+    // which slice this wavefront takes in round r of a phase: the plan's cost-balanced schedule
+    auto slice_a = [&](const Desc &d, int r) { return sched_a[d.sbase + r * NWV + wv]; };
+    auto slice_b = [&](const Desc &d, int r) { return sched_b[d.sbase + r * NWV + wv]; };
 
     // ---- window staging by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write) -------------
     // One wave-instruction moves 64 lanes x 16 B = 1 KiB to a wave-uniform LDS address; waves
@@ -819,7 +824,7 @@ __global__ __launch_bounds__(1024) void k_iter2(
         p.Q.load(QS + n * 2 * D + q * 2 * d4);
         p.U.load(U + n * D + q * d4);
     };
-    auto prefetchB = [&](PreB &p, int slice) {
+    auto prefetchB = [&](PreB &p, int slice, bool with_u) {
         p.len = (__builtin_amdgcn_readfirstlane(out_off[slice + 1]) -
                  __builtin_amdgcn_readfirstlane(out_off[slice])) >> 4;
         const int32_t *lo = out_nbr16 + __builtin_amdgcn_readfirstlane(out_off16[slice]) + q * SLICE + i16;
@@ -829,7 +834,7 @@ __global__ __launch_bounds__(1024) void k_iter2(
         static_assert(NC == 4, "prefetch is written out for 4 words (32 steps)");
         const int64_t n = (int64_t)slice * SLICE + i16;
         p.P.load(PR + n * 2 * D + q * 2 * d4);
-        p.U.load(U + n * D + q * d4);        // U[n] + in-sweep sum, written by this lane in phase A
+        if (with_u) p.U.load(U + n * D + q * d4);   // U[n] + in-sweep sum, stored during phase A
         p.x.load(X + n * F);
     };
     auto arriveA = [&](PreA &p) { a_wait_all(); a_fence(p.c); p.Q.fence(); p.U.fence(); };
@@ -840,9 +845,9 @@ __global__ __launch_bounds__(1024) void k_iter2(
     PreA a_cur, a_nxt;
     PreB b_cur, b_nxt;
     stage_issue(PR + (int64_t)d.in_lo * 2 * D, bufA, d.in_cnt);
-    if (slice_of(d, 0) >= 0) prefetchA(a_cur, slice_of(d, 0));
+    if (slice_a(d, 0) >= 0) prefetchA(a_cur, slice_a(d, 0));
     stage_commit(bufA, PR + n_pad * 2 * D, d.in_cnt);
-    if (slice_of(d, 0) >= 0) arriveA(a_cur);
+    if (slice_a(d, 0) >= 0) arriveA(a_cur);
 
     float w2[d4];
     for (;;) {
@@ -860,12 +865,13 @@ __global__ __launch_bounds__(1024) void k_iter2(
         // conditional assignment inside the loop would keep it live across all rounds.
         auto roundA = [&](int r, auto lr) {
             constexpr bool LR = decltype(lr)::value;
-            const int slice = slice_of(d, r);
-            const int next = LR ? -1 : slice_of(d, r + 1);
-            // The first slice of phase B re-reads U[n] of round 0.  With several rounds that store is
-            // long done; with a single round it is THIS round's store, so the request goes after it.
+            const int slice = slice_a(d, r);
+            const int next = LR ? -1 : slice_a(d, r + 1);
+            // First slice of phase B: its lists, own P and X row are requested here; its U[n]
+            // (the in-sweep sum, possibly written by ANOTHER wavefront of this tile during
+            // phase A - the two phases have their own schedules) only after the phase barrier.
             if constexpr (LR) {
-                if (rounds > 1 && slice_of(d, 0) >= 0) prefetchB(b_cur, slice_of(d, 0));
+                if (slice_b(d, 0) >= 0) prefetchB(b_cur, slice_b(d, 0), false);
             } else {
                 if (next >= 0) prefetchA(a_nxt, next);
             }
@@ -885,15 +891,17 @@ __global__ __launch_bounds__(1024) void k_iter2(
                 }
             }
             if (slice >= 0) store_vec<d4>(U + n * D + q * d4, acc);
-            if constexpr (LR) {
-                if (rounds <= 1 && slice_of(d, 0) >= 0) prefetchB(b_cur, slice_of(d, 0));
-            }
         };
         for (int r = 0; r + 1 < rounds; ++r) roundA(r, std::false_type{});
         roundA(rounds - 1, std::true_type{});
         stage_commit(bufB, QS + n_pad * 2 * D, d.out_cnt);   // also makes b_cur readable (vmcnt 0)
-        if (slice_of(d, 0) >= 0) arriveB(b_cur);
-        __syncthreads();                               // bufB visible, bufA free
+        if (slice_b(d, 0) >= 0) arriveB(b_cur);
+        __syncthreads();                               // bufB visible, bufA free, all U[n] stored
+        if (slice_b(d, 0) >= 0) {                      // now the first slice's in-sweep sum
+            b_cur.U.load(U + ((int64_t)slice_b(d, 0) * SLICE + i16) * D + q * d4);
+            a_wait_all();
+            b_cur.U.fence();
+        }
         // ================= phase B: out-sweeps, hit update, stores; next PR window in flight ======
         const int tnext = tile + gridDim.x;
         Desc dn = d;
@@ -903,12 +911,12 @@ __global__ __launch_bounds__(1024) void k_iter2(
         }
         auto roundB = [&](int r, auto lr) {
             constexpr bool LR = decltype(lr)::value;
-            const int slice = slice_of(d, r);
-            const int next = LR ? -1 : slice_of(d, r + 1);
+            const int slice = slice_b(d, r);
+            const int next = LR ? -1 : slice_b(d, r + 1);
             if constexpr (LR) {      // first slice of the next tile's phase A
-                if (tnext < n_tiles && slice_of(dn, 0) >= 0) prefetchA(a_cur, slice_of(dn, 0));
+                if (tnext < n_tiles && slice_a(dn, 0) >= 0) prefetchA(a_cur, slice_a(dn, 0));
             } else {
-                if (next >= 0) prefetchB(b_nxt, next);
+                if (next >= 0) prefetchB(b_nxt, next, true);
             }
             const int64_t n = (int64_t)slice * SLICE + i16;
             float xv[F], acc[d4];
@@ -951,7 +959,7 @@ __global__ __launch_bounds__(1024) void k_iter2(
         roundB(rounds - 1, std::true_type{});
         if (tnext >= n_tiles) break;
         stage_commit(bufA, PR + n_pad * 2 * D, dn.in_cnt);   // also makes a_cur readable
-        if (slice_of(dn, 0) >= 0) arriveA(a_cur);
+        if (slice_a(dn, 0) >= 0) arriveA(a_cur);
         tile = tnext;
         d = dn;
     }
@@ -1070,7 +1078,7 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
             const int64_t capa = (pl->iter_lds_in + rpp - 1) / rpp * rpp + rpp;
             const int64_t capb = (pl->iter_lds_out + rpp - 1) / rpp * rpp + rpp;
             use2 = G::iter2 && !getenv("GNN_NO_ITER2") && nt > 0 && pl->n_lds_tiles == nt &&
-                   pl->in_nbr16 && pl->out_nbr16 && pl->in_off16 && pl->out_off16;
+                   pl->in_nbr16 && pl->out_nbr16 && pl->in_off16 && pl->out_off16 && pl->sched_a && pl->sched_b;
             capA = (int)capa;
             it2_lds = (size_t)(L::total + (capa + capb) * 2 * D + 4) * sizeof(float);
             if (it2_lds > (size_t)G::lds_bytes) use2 = false;
@@ -1092,12 +1100,12 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
                     if (t + 1 == n_iters)
                         GNN_LAUNCH_SH("k_iter2", (k_iter2<F, D, true>), grid2, 1024, it2_lds, s, pl->X, w.table,
                                       pl->tiles, pl->in_off, pl->in_off16, pl->in_nbr16, pl->out_off,
-                                      pl->out_off16, pl->out_nbr16, PR, QS,
+                                      pl->out_off16, pl->out_nbr16, pl->sched_a, pl->sched_b, PR, QS,
                                       w.U, PRn, QSn, w.Pc, w.Qc, Np, nt, capA);
                     else
                         GNN_LAUNCH_SH("k_iter2", (k_iter2<F, D, false>), grid2, 1024, it2_lds, s, pl->X, w.table,
                                       pl->tiles, pl->in_off, pl->in_off16, pl->in_nbr16, pl->out_off,
-                                      pl->out_off16, pl->out_nbr16, PR, QS,
+                                      pl->out_off16, pl->out_nbr16, pl->sched_a, pl->sched_b, PR, QS,
                                       w.U, PRn, QSn, w.Pc, w.Qc, Np, nt, capA);
                     float *t1 = PR; PR = PRn; PRn = t1;
                     float *t2 = QS; QS = QSn; QSn = t2;
@@ -1120,7 +1128,11 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
         const int nc = (int)pl->n_chunks;
         const int cpx = (nc + 7) / 8;
         const size_t ed_lds = (size_t)((G::ed_rec > 0 ? pl->edge_lds_rows : 0) * D + 4) * sizeof(float);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_edge<F, D>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
+        static bool edge_attr = false;
+        if (!edge_attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_edge<F, D>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
+            edge_attr = true;
+        }
         GNN_LAUNCH_SH("k_edge", (k_edge<F, D>), 8 * cpx, G::NT, ed_lds, s, pl->chunks, pl->src, pl->dst, w.Pc,
                    w.Qc, w.table, e_out, Np, cpx, nc);
     }

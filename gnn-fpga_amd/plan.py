@@ -30,7 +30,7 @@ import numpy as np
 import torch
 
 SLICE = 16
-TILE_DESC = 8    # ints per tile:  slice_begin, slice_end, in_lo, in_cnt, out_lo, out_cnt, mode, 0
+TILE_DESC = 8    # ints per tile:  slice_begin, slice_end, in_lo, in_cnt, out_lo, out_cnt, mode, sched_base
 CHUNK_DESC = 8   # ints per chunk: seg_begin, seg_end, src_lo, src_cnt, dst_lo, dst_cnt, mode, 0
 
 
@@ -254,6 +254,30 @@ class SellPlan:
         tiles[:, 2], tiles[:, 3] = in_lo, in_cnt
         tiles[:, 4], tiles[:, 5] = out_lo, out_cnt
         tiles[:, 6] = lds_mode
+        # per-phase schedules of the phase-split kernel: which slice a wavefront (16 per tile)
+        # takes in round r.  Slices are dealt in snake order of decreasing cost, so the waves of
+        # a tile reach each phase barrier together and a partial last round holds the lightest
+        # slices.  sched[base + 16*r + wave] = slice id or -1; base = tiles[:, 7].
+        nsl = (tiles[:, 1] - tiles[:, 0]).astype(np.int64)
+        rounds = (nsl + 15) // 16
+        sbase = np.zeros(n_tiles + 1, dtype=np.int64)
+        np.cumsum(rounds * 16, out=sbase[1:])
+        tiles[:, 7] = sbase[:-1]
+        tile_of_slice = np.repeat(np.arange(n_tiles), nsl)
+
+        def schedule(cost):
+            order = np.lexsort((-cost, tile_of_slice))           # tile-major, heaviest first
+            rank = np.arange(order.shape[0]) - np.repeat(np.cumsum(nsl) - nsl, nsl)
+            r, c = rank // 16, rank % 16
+            wave = np.where(r % 2 == 0, c, 15 - c)
+            out = np.full(int(sbase[-1]) + 16, -1, dtype=np.int32)
+            out[sbase[tile_of_slice[order]] + r * 16 + wave] = order
+            return out
+
+        steps_in = np.diff(in_off.astype(np.int64)) // SLICE
+        steps_out = np.diff(out_off.astype(np.int64)) // SLICE
+        sched_a = schedule((steps_in + 7) // 8 * 2 + 1)          # score groups + fixed part
+        sched_b = schedule((steps_out + 7) // 8 * 2 + 6)         # + hit update
 
         # -- final edge pass: chunks of the caller's segment order --------------------------
         CH = int(limits["chunk_segments"])
@@ -304,6 +328,7 @@ class SellPlan:
         self.in_off16, self.in_nbr16 = t(in_off16), t(in_nbr16)
         self.out_off16, self.out_nbr16 = t(out_off16), t(out_nbr16)
         self.tiles, self.chunks = t(tiles.reshape(-1)), t(chunks.reshape(-1))
+        self.sched_a, self.sched_b = t(sched_a), t(sched_b)
         self.perm = t(perm.astype(np.int32))
         nv = max(1, int(ok.sum()))
         self.padding = (int(in_off[-1]) + int(out_off[-1])) / (2 * nv) - 1.0
@@ -314,7 +339,7 @@ class SellPlan:
         self.level = level
 
     _TENSORS = ("X", "src", "dst", "in_off", "in_nbr", "out_off", "out_nbr", "in_off16", "in_nbr16",
-                "out_off16", "out_nbr16", "tiles", "chunks", "perm")
+                "out_off16", "out_nbr16", "tiles", "chunks", "sched_a", "sched_b", "perm")
 
     def to(self, device):
         for k in self._TENSORS:

@@ -71,7 +71,7 @@ typedef struct gnn_grads {
  * neighbour id windows fit the LDS budget (gnn_plan_limits) runs in LDS mode (mode = 1): its
  * list / endpoint entries are window-relative and NULL = window size; otherwise entries are
  * absolute padded ids.  Scores stay per segment in the caller's segment order.
- *   tile  descriptor, 8 ints: slice_begin, slice_end, in_lo, in_cnt, out_lo, out_cnt, mode, 0
+ *   tile  descriptor, 8 ints: slice_begin, slice_end, in_lo, in_cnt, out_lo, out_cnt, mode, sched_base
  *   chunk descriptor, 8 ints: seg_begin, seg_end, src_lo, src_cnt, dst_lo, dst_cnt, mode, 0 */
 typedef struct gnn_plan {
     const float *X;                      /* [n_pad+1, F] renumbered features, dummy/NULL rows zero */
@@ -82,6 +82,9 @@ typedef struct gnn_plan {
     /* 16-bit packed copy of the lists (window-relative entries, steps padded to 8 per slice,
      * word p of hit i of slice s = steps 2p | 2p+1 << 16 at off16[s] + 16*p + i) */
     const int32_t *in_off16, *in_nbr16, *out_off16, *out_nbr16;
+    /* per-phase wave schedules of the phase-split kernel: sched[tile[7] + 16*round + wave] = slice
+     * id (or -1) that wavefront `wave` of the tile's workgroup takes in `round` */
+    const int32_t *sched_a, *sched_b;
     int64_t n_pad, n_segments, n_tiles, n_chunks;
     int64_t iter_lds_records;            /* max over LDS-mode tiles of in_cnt + out_cnt + 2        */
     int64_t edge_lds_rows;               /* max over LDS-mode chunks of src_cnt + dst_cnt + 2      */
