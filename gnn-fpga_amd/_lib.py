@@ -16,6 +16,7 @@ GNN_ABI_VERSION = 1
 GNN_ERR_UNSUPPORTED = -10001
 GNN_ERR_BADARG = -10002
 GNN_ERR_WORKSPACE = -10003
+GNN_FLAG_EXP_PRODUCT = 1
 
 _f = ctypes.c_void_p          # device pointers travel as integers
 _i32, _i64, _sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
@@ -23,7 +24,7 @@ _i32, _i64, _sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
 
 class GnnParams(ctypes.Structure):
     _fields_ = [(n, _f) for n in ("Win", "bin", "W1", "b1", "W2", "b2", "W3", "b3", "W4", "b4")] + \
-               [("F", _i32), ("D", _i32)]
+               [("F", _i32), ("D", _i32), ("flags", _i32)]
 
 
 class GnnGraph(ctypes.Structure):
@@ -70,6 +71,7 @@ SIGNATURES = {
                                                _i32, _f, _f, _sz, _f]),
     "gnn_plan_shape_supported": (ctypes.c_int, [_i32, _i32]),
     "gnn_plan_limits": (ctypes.c_int, [_i32, _i32, ctypes.POINTER(_i32)]),
+    "gnn_exp_product_bound": (ctypes.c_int, [ctypes.POINTER(GnnParams), _f, _f, _f]),
     "gnn_profile_begin": (ctypes.c_int, [_i32]),
     "gnn_profile_end": (ctypes.c_int, [ctypes.POINTER(ctypes.c_char_p),
                                        ctypes.POINTER(ctypes.c_float), _i32]),
@@ -145,13 +147,22 @@ def graph_struct(batch):
     return g
 
 
-def params_struct(weights, F, D):
+def params_struct(weights, F, D, flags=0):
     """weights: the ten effective (masked) tensors in state_dict order."""
     p = GnnParams()
     for name, w in zip(("Win", "bin", "W1", "b1", "W2", "b2", "W3", "b3", "W4", "b4"), weights):
         setattr(p, name, _dev(w, torch.float32, name))
-    p.F, p.D = F, D
+    p.F, p.D, p.flags = F, D, flags
     return p
+
+
+def exp_product_bound(weights, F, D, x_absmax):
+    """max |P'|, |Q'| bound (python float; synchronises).  <= 60 permits GNN_FLAG_EXP_PRODUCT."""
+    out = torch.empty(1, dtype=torch.float32, device=x_absmax.device)
+    p = params_struct(weights, F, D)
+    _check(load().gnn_exp_product_bound(ctypes.byref(p), _dev(x_absmax, torch.float32, "x_absmax"),
+                                        out.data_ptr(), _stream()))
+    return float(out.item())
 
 
 def input_fwd(X, Win, bin_):
@@ -290,7 +301,7 @@ def plan_workspace_bytes(n_hits, n_segments, F, D):
     return int(load().gnn_plan_workspace_bytes(n_hits, n_segments, F, D))
 
 
-def segclf_forward_plan(plan, weights, F, D, n_iters, out=None, workspace=None):
+def segclf_forward_plan(plan, weights, F, D, n_iters, out=None, workspace=None, flags=0):
     """Whole SegmentClassifier forward on a planned batch (fused pipeline) -> scores [E]."""
     dev = plan.X.device
     if not plan_shape_supported(F, D):
@@ -301,7 +312,7 @@ def segclf_forward_plan(plan, weights, F, D, n_iters, out=None, workspace=None):
     if out is None:
         out = torch.empty(plan.n_segments, dtype=torch.float32, device=dev)
     g = plan_struct(plan)
-    p = params_struct(weights, F, D)
+    p = params_struct(weights, F, D, flags)
     _check(load().gnn_segclf_forward_plan(ctypes.byref(g), ctypes.byref(p), n_iters,
                                           _dev(out, torch.float32, "out"),
                                           workspace.data_ptr(), workspace.numel(), _stream()))

@@ -267,6 +267,27 @@ __global__ __launch_bounds__(kBlock) void k_node(
     if (PQ) store_pq<F, D>(hn, W1, b1, PQ + n * 2 * D);
 }
 
+// bound of |P'|, |Q'| over all hits given |H'| <= 1 and per-feature max |X| (one wavefront)
+__global__ __launch_bounds__(64) void k_exp_bound(const float *__restrict__ W1,
+                                                 const float *__restrict__ b1,
+                                                 const float *__restrict__ xmax, int F, int D,
+                                                 float *__restrict__ out)
+{
+    const int C = F + D;
+    float worst = 0.0f;
+    for (int i = threadIdx.x; i < 2 * D; i += 64) {       // rows of the P block, then the Q block
+        const int row = i % D, half = i / D;
+        float acc = half == 0 ? fabsf(b1[row]) : 0.0f;
+        for (int k = 0; k < C; ++k) {
+            const float w = fabsf(W1[row * 2 * C + half * C + k]);
+            acc += k < D ? w : w * xmax[k - D];
+        }
+        worst = fmaxf(worst, acc);
+    }
+    for (int o = 32; o > 0; o >>= 1) worst = fmaxf(worst, __shfl_xor(worst, o));
+    if (threadIdx.x == 0) out[0] = 2.8853900817779268f * worst;
+}
+
 // H (padded rows) -> unpadded [n_hits, C] trace rows (parity tests only).
 __global__ __launch_bounds__(kBlock) void k_unpad(const float *__restrict__ H, int ldh, int C,
                                                   float *__restrict__ out, int64_t total)
@@ -560,6 +581,16 @@ int gnn_segclf_forward_plan(const gnn_plan_t *pl, const gnn_params_t *p, int32_t
     if (!p->Win || !p->bin || !p->W1 || !p->b1 || !p->W2 || !p->b2 || !p->W3 || !p->b3 || !p->W4 || !p->b4)
         return fail(GNN_ERR_BADARG, "gnn_segclf_forward_plan: weight pointer missing");
     return sell_forward(pl, p, n_iters, e_out, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int gnn_exp_product_bound(const gnn_params_t *p, const float *x_absmax, float *bound_out,
+                          void *stream)
+{
+    if (!p || !p->W1 || !p->b1 || !x_absmax || !bound_out || p->F <= 0 || p->D <= 0)
+        return fail(GNN_ERR_BADARG, "gnn_exp_product_bound: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    GNN_LAUNCH("k_exp_bound", k_exp_bound, 1, 64, s, p->W1, p->b1, x_absmax, p->F, p->D, bound_out);
+    return 0;
 }
 
 int gnn_profile_begin(int32_t capacity)

@@ -80,7 +80,7 @@ struct TL {
 constexpr float kTwoLog2e = 2.8853900817779268f;
 constexpr float kLog2e = 1.4426950408889634f;
 
-template <int F, int D>
+template <int F, int D, bool XP>
 __global__ __launch_bounds__(256) void k_pack(gnn_params_t p, float *__restrict__ table,
                                               float *PRa, float *PRb, float *QSa, float *QSb,
                                               float *U, float *Pc, float *Qc, int64_t n_hits)
@@ -143,16 +143,20 @@ __global__ __launch_bounds__(256) void k_pack(gnn_params_t p, float *__restrict_
     // padded segment scores sigmoid(W2 tanh(b1) + b2) (gnn/trainSegmentClassifier.py:83-93).
     for (int t = threadIdx.x; t < 2 * D; t += 256) {
         const int q = t / (2 * d4), w = t % (2 * d4);
-        const float pv = (w < d4) ? kTwoLog2e * p.b1[q * d4 + w] : 0.0f;
+        // exp-product mode stores 2^P', 2^Q' instead of P', Q' (see score4)
+        float pv = (w < d4) ? kTwoLog2e * p.b1[q * d4 + w] : 0.0f;
+        if (XP && w < d4) pv = __builtin_amdgcn_exp2f(pv);
+        const float qv = (XP && w < d4) ? 1.0f : 0.0f;
         PRa[n_hits * 2 * D + t] = pv;
         PRb[n_hits * 2 * D + t] = pv;
-        QSa[n_hits * 2 * D + t] = 0.0f;
-        QSb[n_hits * 2 * D + t] = 0.0f;
+        QSa[n_hits * 2 * D + t] = qv;
+        QSb[n_hits * 2 * D + t] = qv;
     }
     for (int t = threadIdx.x; t < D; t += 256) {
         U[n_hits * D + t] = 0.0f;
-        Pc[n_hits * D + t] = kTwoLog2e * p.b1[t];
-        Qc[n_hits * D + t] = 0.0f;
+        const float pb = kTwoLog2e * p.b1[t];
+        Pc[n_hits * D + t] = XP ? __builtin_amdgcn_exp2f(pb) : pb;
+        Qc[n_hits * D + t] = XP ? 1.0f : 0.0f;
     }
 }
 
@@ -301,7 +305,7 @@ __device__ __forceinline__ void role_gemv(const float *w, const float *hn, const
 
 // This lane's chunk of the records the next pass gathers, computed from the new hit features
 // [hn (D) | x (F)]: PR = [P | R], QS = [Q | S], U; for the last iteration compact P and Q only.
-template <int F, int D, bool LAST>
+template <int F, int D, bool LAST, bool XP>
 struct Records {
     static constexpr int d4 = D / 4;
     float pr[LAST ? d4 : 2 * d4], qs[LAST ? d4 : 2 * d4], u[d4];
@@ -318,6 +322,13 @@ struct Records {
             role_gemv<d4, D, F>(wl + L::o_m + 2 * L::m_st, hn, x, qs);
             role_gemv<d4, D, F>(wl + L::o_m + 3 * L::m_st, hn, x, qs + d4);
             role_gemv<d4, D, F>(wl + L::o_m + 4 * L::m_st, hn, x, u);
+        }
+        if constexpr (XP) {          // publish 2^P', 2^Q': the per-segment exp becomes a multiply
+#pragma unroll
+            for (int i = 0; i < d4; ++i) {
+                pr[i] = __builtin_amdgcn_exp2f(pr[i]);
+                qs[i] = __builtin_amdgcn_exp2f(qs[i]);
+            }
         }
     }
     __device__ __forceinline__ void store(int64_t n, int q, float *__restrict__ PRn,
@@ -340,7 +351,7 @@ struct Records {
 // ---------------------------------------------------------------------------------------------
 // input network (model.py:144-146) + records of iteration 0.  4 lanes per hit, over the padded
 // hit range (dummy hits have X = 0 and are never gathered).
-template <int F, int D, bool LAST>
+template <int F, int D, bool LAST, bool XP>
 __global__ __launch_bounds__(256) void k_input4(const float *__restrict__ X,
                                                 const float *__restrict__ table,
                                                 float *__restrict__ PRn, float *__restrict__ QSn,
@@ -365,7 +376,7 @@ __global__ __launch_bounds__(256) void k_input4(const float *__restrict__ X,
     for (int i = 0; i < d4; ++i) hl[i] = tanh_f(hl[i]);
     float hn[D];
     quad_allgather<d4>(hl, hn);
-    Records<F, D, LAST> rec;
+    Records<F, D, LAST, XP> rec;
     rec.compute(wl, hn, x);
     rec.store(n, q, PRn, QSn, U, Pc, Qc);
 }
@@ -497,7 +508,10 @@ struct Recs {
 //   a 4x4 transpose-add inside the quad leaves lane j with the full pre-activation of segment j,
 //   so each lane evaluates ONE sigmoid (not the same one four times); the scores come back with a
 //   DPP broadcast.  Steps past the list end (rem < 4) read the NULL record: they add e * 0.
-template <int D4>
+// XP (exp-product mode): records hold 2^P' / 2^Q' and 2^(P'+Q') is their product, so each hidden
+// unit costs fma + v_rcp instead of add + v_exp + add + v_rcp.  Only valid while |P'|, |Q'| <= 60
+// (no overflow / flush in either factor): the caller proves that bound, see GNN_FLAG_EXP_PRODUCT.
+template <int D4, bool XP>
 __device__ __forceinline__ void score4(const float (*rec)[2 * D4], const float *own,
                                        const float *w2, float b2, int q, float *acc)
 {
@@ -506,11 +520,11 @@ __device__ __forceinline__ void score4(const float (*rec)[2 * D4], const float *
     for (int j = 0; j < 4; ++j) {
         part[j] = 0.0f;
 #pragma unroll
-#ifdef GNN_TIMING_EXPPROD
-        for (int i = 0; i < D4; ++i) part[j] = fmaf(w2[i], __builtin_amdgcn_rcpf(fmaf(rec[j][i], own[i], 1.0f)), part[j]);
-#else
-        for (int i = 0; i < D4; ++i) part[j] = fmaf(w2[i], r_f(rec[j][i] + own[i]), part[j]);
-#endif
+        for (int i = 0; i < D4; ++i) {
+            const float r = XP ? __builtin_amdgcn_rcpf(fmaf(rec[j][i], own[i], 1.0f))
+                               : r_f(rec[j][i] + own[i]);
+            part[j] = fmaf(w2[i], r, part[j]);
+        }
     }
     // stage 1 (xor 1): even lanes keep segments {0,2}, odd lanes {1,3}
     const bool odd = q & 1, hi = q & 2;
@@ -532,7 +546,7 @@ __device__ __forceinline__ void score4(const float (*rec)[2 * D4], const float *
 // walk one list: the first MAXC chunks were prefetched into `pre`, the rest (rare) streams from
 // `lst` (= nbr + base + 16*q + i16).  REC is the record table (LDS window or global memory);
 // `null_idx` is the NULL record's index in REC.
-template <int D>
+template <int D, bool XP>
 __device__ __forceinline__ void sweep(const int *pre, const int32_t *__restrict__ lst, int len,
                                       int null_idx, const float *REC, int q, const float *own,
                                       const float *w2, float b2, float *acc)
@@ -548,20 +562,20 @@ __device__ __forceinline__ void sweep(const int *pre, const int32_t *__restrict_
     for (int c = 0; c < MAXC; ++c) {
         if (4 * c < len) {
             a.read(fix(pre[c], len - 4 * c), REC, q);
-            score4<d4>(a.r, own, w2, b2, q, acc);
+            score4<d4, XP>(a.r, own, w2, b2, q, acc);
         }
     }
     // lists longer than 4*MAXC steps (rare): stream the remaining chunks
     for (int k = 4 * MAXC; k < len; k += 4) {
         a.read(fix(lst[k * SLICE], len - k), REC, q);
-        score4<d4>(a.r, own, w2, b2, q, acc);
+        score4<d4, XP>(a.r, own, w2, b2, q, acc);
     }
 }
 
 // Walk of a 16-bit packed list (plan.py _pack16): every register of c[] holds 8 steps for the quad
 // (lane q: steps 8sc+2q and 8sc+2q+1), the registers ROTATE through c[0] so this is a real loop.
 // Steps past the list end are NULL entries already (the packed lists are padded), so no fix-up.
-template <int D, int NC>
+template <int D, int NC, bool XP>
 __device__ __forceinline__ void sweep16(int (&c)[NC], const int32_t *__restrict__ nbr16,
                                         const int32_t *__restrict__ off16, int slice, int i16,
                                         int len, const float *REC, int q, const float *own,
@@ -585,7 +599,7 @@ __device__ __forceinline__ void sweep16(int (&c)[NC], const int32_t *__restrict_
             float r[4][2 * d4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) load_vec<2 * d4>(REC + nb[j] * 2 * D + q * 2 * d4, r[j]);
-            score4<d4>(r, own, w2, b2, q, acc);
+            score4<d4, XP>(r, own, w2, b2, q, acc);
         }
         if (k + 4 < len) {
             const int w45 = quad_bcast_i<2>(w), w67 = quad_bcast_i<3>(w);
@@ -594,14 +608,14 @@ __device__ __forceinline__ void sweep16(int (&c)[NC], const int32_t *__restrict_
             float r[4][2 * d4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) load_vec<2 * d4>(REC + nb[j] * 2 * D + q * 2 * d4, r[j]);
-            score4<d4>(r, own, w2, b2, q, acc);
+            score4<d4, XP>(r, own, w2, b2, q, acc);
         }
     }
 }
 
 // one message-passing iteration for one tile: edge scores + weighted aggregation + hit update
 // (+ records for the next pass).  One workgroup per tile; each wavefront takes 16-hit slices.
-template <int F, int D, bool LAST>
+template <int F, int D, bool LAST, bool XP>
 __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_iter(
     const float *__restrict__ X, const float *__restrict__ table,
     const int32_t *__restrict__ tiles, const int32_t *__restrict__ in_off,
@@ -704,7 +718,7 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_iter(
             prefetch(nxt, next);
             if constexpr (!G::pipelined) arrive(nxt);
         }
-        Records<F, D, LAST> rec;
+        Records<F, D, LAST, XP> rec;
         const int64_t n = (int64_t)slice * SLICE + i16;
         if (slice >= 0) {
             // the weight-table offset is made opaque per iteration: otherwise the compiler hoists
@@ -717,11 +731,11 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_iter(
             if (ablate & 2) {
             } else if (G::it_rec > 0 && mode) {
                 // segments ending here: P[start] + Q[n], adds e * R[start]; then starting here
-                sweep<D>(cur.cin, in_nbr + cur.ib + q * SLICE + i16, cur.il, in_cnt, winA, q, Qn, w2, b2, acc);
-                sweep<D>(cur.cout, out_nbr + cur.ob + q * SLICE + i16, cur.ol, out_cnt, winB, q, Pn, w2, b2, acc);
+                sweep<D, XP>(cur.cin, in_nbr + cur.ib + q * SLICE + i16, cur.il, in_cnt, winA, q, Qn, w2, b2, acc);
+                sweep<D, XP>(cur.cout, out_nbr + cur.ob + q * SLICE + i16, cur.ol, out_cnt, winB, q, Pn, w2, b2, acc);
             } else {
-                sweep<D>(cur.cin, in_nbr + cur.ib + q * SLICE + i16, cur.il, (int)n_pad, PR, q, Qn, w2, b2, acc);
-                sweep<D>(cur.cout, out_nbr + cur.ob + q * SLICE + i16, cur.ol, (int)n_pad, QS, q, Pn, w2, b2, acc);
+                sweep<D, XP>(cur.cin, in_nbr + cur.ib + q * SLICE + i16, cur.il, (int)n_pad, PR, q, Qn, w2, b2, acc);
+                sweep<D, XP>(cur.cout, out_nbr + cur.ob + q * SLICE + i16, cur.ol, (int)n_pad, QS, q, Pn, w2, b2, acc);
             }
             // hit update: H' = tanh(W4 tanh(acc) + b4)                  (model.py:94-98,125)
             float ql[d4], qa[D];
@@ -758,7 +772,7 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_iter(
 // While phase A computes, the tile's QS window is in flight (asm loads into registers, written
 // to bufB at the end of the phase); while phase B computes, the NEXT tile's PR window is in
 // flight.  So window staging, list prefetch and stores all run under VALU work.
-template <int F, int D, bool LAST>
+template <int F, int D, bool LAST, bool XP>
 __global__ __launch_bounds__(1024) void k_iter2(
     const float *__restrict__ X, const float *__restrict__ table,
     const int32_t *__restrict__ tiles, const int32_t *__restrict__ in_off,
@@ -882,7 +896,7 @@ __global__ __launch_bounds__(1024) void k_iter2(
                 a_cur.U.get(acc);
                 a_cur.Q.get(Qn);
                 const int len = __builtin_amdgcn_readfirstlane(a_cur.len);
-                sweep16<D, NC>(a_cur.c, in_nbr16, in_off16, slice, i16, len, bufA, q, Qn, w2, b2, acc);
+                sweep16<D, NC, XP>(a_cur.c, in_nbr16, in_off16, slice, i16, len, bufA, q, Qn, w2, b2, acc);
             }
             if constexpr (!LR) {
                 if (next >= 0) {
@@ -926,7 +940,7 @@ __global__ __launch_bounds__(1024) void k_iter2(
                 b_cur.U.get(acc);
                 b_cur.x.get(xv);
                 const int len = __builtin_amdgcn_readfirstlane(b_cur.len);
-                sweep16<D, NC>(b_cur.c, out_nbr16, out_off16, slice, i16, len, bufB, q, Pn, w2, b2, acc);
+                sweep16<D, NC, XP>(b_cur.c, out_nbr16, out_off16, slice, i16, len, bufB, q, Pn, w2, b2, acc);
             }
             // the next slice's registers arrive here (in flight during the sweep); doing it before
             // the hit update keeps the two register sets from overlapping with the MLP's
@@ -950,7 +964,7 @@ __global__ __launch_bounds__(1024) void k_iter2(
 #pragma unroll
                 for (int i = 0; i < d4; ++i) hl[i] = tanh_f(hl[i]);
                 quad_allgather<d4>(hl, hn);
-                Records<F, D, LAST> rec;
+                Records<F, D, LAST, XP> rec;
                 rec.compute(wl, hn, xv);
                 rec.store(n, q, PRn, QSn, U, Pc, Qc);
             }
@@ -967,7 +981,7 @@ __global__ __launch_bounds__(1024) void k_iter2(
 
 // final edge pass (model.py:156) for one chunk of the caller's segment order; one lane per
 // segment, P rows of the start hits and Q rows of the end hits from LDS windows or global.
-template <int F, int D>
+template <int F, int D, bool XP>
 __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_edge(
     const int32_t *__restrict__ chunks, const int32_t *__restrict__ src,
     const int32_t *__restrict__ dst, const float *__restrict__ Pc, const float *__restrict__ Qc,
@@ -1004,7 +1018,8 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_edge(
         }
         float acc = b2;
 #pragma unroll
-        for (int k = 0; k < D; ++k) acc = fmaf(W2[k], r_f(p[k] + qq[k]), acc);
+        for (int k = 0; k < D; ++k)
+            acc = fmaf(W2[k], XP ? __builtin_amdgcn_rcpf(fmaf(p[k], qq[k], 1.0f)) : r_f(p[k] + qq[k]), acc);
         e[j] = r_f(acc);
     }
 }
@@ -1035,7 +1050,7 @@ Ws carve(char *b, int64_t n_pad, int table_floats, int D)
     return w;
 }
 
-template <int F, int D>
+template <int F, int D, bool XP>
 int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e_out, char *ws,
               hipStream_t s)
 {
@@ -1043,25 +1058,25 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
     using G = Cfg<F, D>;
     const int64_t Np = pl->n_pad, E = pl->n_segments;
     Ws w = carve(ws, Np, L::total, D);
-    GNN_LAUNCH("k_pack", (k_pack<F, D>), 1, 256, s, *p, w.table, w.PRa, w.PRb, w.QSa, w.QSb, w.U,
+    GNN_LAUNCH("k_pack", (k_pack<F, D, XP>), 1, 256, s, *p, w.table, w.PRa, w.PRb, w.QSa, w.QSb, w.U,
                w.Pc, w.Qc, Np);
     float *PR = w.PRa, *PRn = w.PRb, *QS = w.QSa, *QSn = w.QSb;
     if (Np > 0) {
         const unsigned g = (unsigned)((Np * 4 + 255) / 256);
         if (n_iters == 0)
-            GNN_LAUNCH("k_input4", (k_input4<F, D, true>), g, 256, s, pl->X, w.table, PR, QS, w.U,
+            GNN_LAUNCH("k_input4", (k_input4<F, D, true, XP>), g, 256, s, pl->X, w.table, PR, QS, w.U,
                        w.Pc, w.Qc, Np);
         else
-            GNN_LAUNCH("k_input4", (k_input4<F, D, false>), g, 256, s, pl->X, w.table, PR, QS, w.U,
+            GNN_LAUNCH("k_input4", (k_input4<F, D, false, XP>), g, 256, s, pl->X, w.table, PR, QS, w.U,
                        w.Pc, w.Qc, Np);
         const int nt = (int)pl->n_tiles;
         const int tpx = (nt + 7) / 8;
         const size_t it_lds = (size_t)(L::total + (G::it_rec > 0 ? pl->iter_lds_records : 0) * 2 * D + 4) * sizeof(float);
         static bool attr_done = false;     // dynamic LDS above 64 KB must be opted into, once
         if (!attr_done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter<F, D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter<F, D, false>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_edge<F, D>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter<F, D, true, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter<F, D, false, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_edge<F, D, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
             attr_done = true;
         }
         const char *ab = getenv("GNN_ABLATE");   // timing diagnostics only (results invalid)
@@ -1089,8 +1104,8 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
                 if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
                     n_cu = prop.multiProcessorCount;
                 if (n_cu <= 0) n_cu = 256;
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter2<F, D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter2<F, D, false>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter2<F, D, true, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter2<F, D, false, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
             }
             grid2 = nt < n_cu ? nt : n_cu;
         }
@@ -1098,12 +1113,12 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
             if constexpr (D <= 16) {
                 if (use2) {
                     if (t + 1 == n_iters)
-                        GNN_LAUNCH_SH("k_iter2", (k_iter2<F, D, true>), grid2, 1024, it2_lds, s, pl->X, w.table,
+                        GNN_LAUNCH_SH("k_iter2", (k_iter2<F, D, true, XP>), grid2, 1024, it2_lds, s, pl->X, w.table,
                                       pl->tiles, pl->in_off, pl->in_off16, pl->in_nbr16, pl->out_off,
                                       pl->out_off16, pl->out_nbr16, pl->sched_a, pl->sched_b, PR, QS,
                                       w.U, PRn, QSn, w.Pc, w.Qc, Np, nt, capA);
                     else
-                        GNN_LAUNCH_SH("k_iter2", (k_iter2<F, D, false>), grid2, 1024, it2_lds, s, pl->X, w.table,
+                        GNN_LAUNCH_SH("k_iter2", (k_iter2<F, D, false, XP>), grid2, 1024, it2_lds, s, pl->X, w.table,
                                       pl->tiles, pl->in_off, pl->in_off16, pl->in_nbr16, pl->out_off,
                                       pl->out_off16, pl->out_nbr16, pl->sched_a, pl->sched_b, PR, QS,
                                       w.U, PRn, QSn, w.Pc, w.Qc, Np, nt, capA);
@@ -1113,11 +1128,11 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
                 }
             }
             if (t + 1 == n_iters)
-                GNN_LAUNCH_SH("k_iter", (k_iter<F, D, true>), 8 * tpx, G::NT, it_lds, s, pl->X, w.table,
+                GNN_LAUNCH_SH("k_iter", (k_iter<F, D, true, XP>), 8 * tpx, G::NT, it_lds, s, pl->X, w.table,
                            pl->tiles, pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PR, QS, w.U,
                            PRn, QSn, w.Pc, w.Qc, Np, tpx, nt, ablate);
             else
-                GNN_LAUNCH_SH("k_iter", (k_iter<F, D, false>), 8 * tpx, G::NT, it_lds, s, pl->X, w.table,
+                GNN_LAUNCH_SH("k_iter", (k_iter<F, D, false, XP>), 8 * tpx, G::NT, it_lds, s, pl->X, w.table,
                            pl->tiles, pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PR, QS, w.U,
                            PRn, QSn, w.Pc, w.Qc, Np, tpx, nt, ablate);
             float *t1 = PR; PR = PRn; PRn = t1;
@@ -1130,10 +1145,10 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
         const size_t ed_lds = (size_t)((G::ed_rec > 0 ? pl->edge_lds_rows : 0) * D + 4) * sizeof(float);
         static bool edge_attr = false;
         if (!edge_attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_edge<F, D>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_edge<F, D, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
             edge_attr = true;
         }
-        GNN_LAUNCH_SH("k_edge", (k_edge<F, D>), 8 * cpx, G::NT, ed_lds, s, pl->chunks, pl->src, pl->dst, w.Pc,
+        GNN_LAUNCH_SH("k_edge", (k_edge<F, D, XP>), 8 * cpx, G::NT, ed_lds, s, pl->chunks, pl->src, pl->dst, w.Pc,
                    w.Qc, w.table, e_out, Np, cpx, nc);
     }
     return 0;
@@ -1186,7 +1201,10 @@ int sell_forward(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float
     if (need == 0) return fail(GNN_ERR_UNSUPPORTED, "no fused kernel for input_dim=%d hidden_dim=%d", p->F, p->D);
     if (!ws || ws_bytes < need) return fail(GNN_ERR_WORKSPACE, "workspace too small: need %zu bytes", need);
     char *base = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
-#define X_(F_, D_) if (p->F == F_ && p->D == D_) return forward_t<F_, D_>(pl, p, n_iters, e_out, base, s);
+#define X_(F_, D_)                                                                              \
+    if (p->F == F_ && p->D == D_)                                                              \
+        return (p->flags & GNN_FLAG_EXP_PRODUCT) ? forward_t<F_, D_, true>(pl, p, n_iters, e_out, base, s) \
+                                                 : forward_t<F_, D_, false>(pl, p, n_iters, e_out, base, s);
     SELL_FOR_EACH_SHAPE(X_)
 #undef X_
     return fail(GNN_ERR_UNSUPPORTED, "unreachable");

@@ -156,12 +156,26 @@ class SegmentClassifier(nn.Module):
                                         hidden_activation, masks_n)
         self._workspace = None
         self.use_plan = True      # False: per-module CSR kernels instead of the fused pipeline
+        self.exp_product = True   # allow GNN_FLAG_EXP_PRODUCT when the bound check passes
+        self._xp_cache = None     # (key, flag): the bound check synchronises, so it is cached
 
     def effective_weights(self):
         """The ten tensors the kernels consume, in state_dict order, masks applied."""
         lin = self.input_network[0]
         return ([_f32c(lin.weight), _f32c(lin.bias)] + self.edge_network.weights() +
                 self.node_network.weights())
+
+    def _exp_product_flag(self, plan, weights):
+        """GNN_FLAG_EXP_PRODUCT iff max|P'|, |Q'| <= 60 is PROVEN for these weights and this
+        batch's feature range (include/gnn_hip.h).  Re-evaluated only when a parameter changed
+        in place (tensor._version), was replaced, or another plan is used."""
+        if not self.exp_product:
+            return 0
+        key = (id(plan),) + tuple((id(p), p._version) for p in self.parameters())
+        if self._xp_cache is None or self._xp_cache[0] != key:
+            bound = _lib.exp_product_bound(weights, self.input_dim, self.hidden_dim, plan.x_absmax)
+            self._xp_cache = (key, _lib.GNN_FLAG_EXP_PRODUCT if bound <= 60.0 else 0)
+        return self._xp_cache[1]
 
     def forward(self, inputs, trace=False):
         """Apply forward pass of the model: inputs = [X, Ri, Ro] or a HitGraphBatch."""
@@ -187,8 +201,10 @@ class SegmentClassifier(nn.Module):
                 self._workspace.device != batch.X.device):
             self._workspace = torch.empty(need, dtype=torch.uint8, device=batch.X.device)
         if fused:     # relabel + SELL-16 plan, fused iteration kernels (csrc/sell_pipeline.hip)
-            res = _lib.segclf_forward_plan(plan, self.effective_weights(), F, D,
-                                           self.n_iters, workspace=self._workspace)
+            weights = self.effective_weights()
+            res = _lib.segclf_forward_plan(plan, weights, F, D, self.n_iters,
+                                           workspace=self._workspace,
+                                           flags=self._exp_product_flag(plan, weights))
         else:         # CSR kernels, one per reference module (csrc/gnn_kernels.hip); traces
             res = _lib.segclf_forward(batch, self.effective_weights(), F, D, self.n_iters,
                                       workspace=self._workspace, trace=trace)

@@ -322,6 +322,7 @@ class SellPlan:
         Xp[new_of_rank] = X[old_of_rank]
         t = torch.from_numpy
         self.X = t(Xp)
+        self.x_absmax = t(np.abs(Xp).max(axis=0).astype(np.float32)) if n else t(np.zeros(X.shape[1], np.float32))
         self.src, self.dst = t(src_st.astype(np.int32)), t(dst_st.astype(np.int32))
         self.in_off, self.in_nbr = t(in_off), t(in_nbr)
         self.out_off, self.out_nbr = t(out_off), t(out_nbr)
@@ -339,7 +340,8 @@ class SellPlan:
         self.level = level
 
     _TENSORS = ("X", "src", "dst", "in_off", "in_nbr", "out_off", "out_nbr", "in_off16", "in_nbr16",
-                "out_off16", "out_nbr16", "tiles", "chunks", "sched_a", "sched_b", "perm")
+                "out_off16", "out_nbr16", "tiles", "chunks", "sched_a", "sched_b", "perm",
+                "x_absmax")
 
     def to(self, device):
         for k in self._TENSORS:

@@ -44,7 +44,16 @@ typedef struct gnn_params {
     const float *W3, *b3;   /* node_network.network.0    [D,3C] [D]   gnn/model.py:94-95   */
     const float *W4, *b4;   /* node_network.network.2    [D,D]  [D]   gnn/model.py:97      */
     int32_t F, D;
+    int32_t flags;          /* GNN_FLAG_* (fused pipeline only)                                */
 } gnn_params_t;
+
+/* The caller asserts max(|P'|, |Q'|) <= 60 for every hit, with P' = 2 log2(e) (W1[:, :C] H + b1),
+ * Q' = 2 log2(e) W1[:, C:] H.  Since |H'| <= 1 (tanh) a sufficient condition is
+ *   2 log2(e) * max_i ( sum_{k<D} |W1[i,k]| + sum_{k<F} |W1[i,D+k]| max|X[:,k]| + |b1[i]| ) <= 60
+ * (same for the columns C..2C without the bias); gnn_exp_product_bound computes the left side.
+ * With the flag set the fused kernels publish 2^P', 2^Q' and form 2^(P'+Q') by multiplication
+ * (one transcendental less per hidden unit and segment); without it they use the exact path. */
+#define GNN_FLAG_EXP_PRODUCT 1
 
 /* One block-diagonal batch of hit graphs in index form (replaces the dense Ri/Ro of
  * gnn/graph.py:28-35).  CSR arrays list, per hit, the segments ending (in_*) / starting
@@ -166,6 +175,11 @@ int gnn_plan_shape_supported(int32_t F, int32_t D);
  * edge_records } - the tile / chunk sizes and the LDS window budgets (in records of 2D floats
  * for the iteration kernel, rows of D floats for the edge kernel). */
 int gnn_plan_limits(int32_t F, int32_t D, int32_t *out4);
+
+/* bound_out (device, 1 float) = the left side of the GNN_FLAG_EXP_PRODUCT condition;
+ * x_absmax (device, [F]) = per-feature max |X|.  Asynchronous on `stream`. */
+int gnn_exp_product_bound(const gnn_params_t *p, const float *x_absmax, float *bound_out,
+                          void *stream);
 
 /* Per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).
  * gnn_profile_begin(capacity) arms recording of up to `capacity` kernel launches;

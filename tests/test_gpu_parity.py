@@ -52,9 +52,15 @@ def test_fused_plan_forward_matches_reference_golden(hip, name):
     dev = torch.device("cuda:0")
     batch = HitGraphBatch.from_graphs([fx.graph]).to(dev)
     plan = batch.build_plan(fx.D)
-    e = hip.segclf_forward_plan(plan, _weights(fx, dev), fx.F, fx.D, fx.n_iters)
+    w = _weights(fx, dev)
+    e = hip.segclf_forward_plan(plan, w, fx.F, fx.D, fx.n_iters)
     torch.cuda.synchronize()
     assert np.abs(e.cpu().numpy() - fx.scores).max() < TOL
+    # exp-product mode (2^P' * 2^Q' instead of 2^(P'+Q')) where its range bound is proven
+    if hip.exp_product_bound(w, fx.F, fx.D, plan.x_absmax) <= 60.0:
+        ex = hip.segclf_forward_plan(plan, w, fx.F, fx.D, fx.n_iters,
+                                     flags=hip.GNN_FLAG_EXP_PRODUCT)
+        assert np.abs(ex.cpu().numpy() - fx.scores).max() < TOL
     # n_iters = 0 (input network + one edge pass) against the first traced edge pass
     if fx.e_trace is not None:
         e0 = hip.segclf_forward_plan(plan, _weights(fx, dev), fx.F, fx.D, 0)
@@ -238,3 +244,23 @@ def test_masked_training_gradients(hip):
         assert np.abs(g - r).max() < 1e-6 + 1e-4 * np.abs(r).max(), k
         if k in fx.masks:
             assert np.all(g[fx.masks[k] == 0] == 0)
+
+
+def test_exp_product_bound_and_fallback(hip):
+    """The model takes the exp-product fast path only while max|P'|,|Q'| <= 60 is proven; with
+    huge first-layer weights it must fall back to the exact path and still match the oracle."""
+    from gnn_fpga_amd.model import SegmentClassifier
+    torch.manual_seed(3)
+    g = synth.layered_graph(300, 1500, 3, seed=9)
+    batch = HitGraphBatch.from_graphs([g]).cuda()
+    m = SegmentClassifier(input_dim=3, hidden_dim=8, n_iters=2).cuda().eval()
+    with torch.no_grad():
+        e = m(batch)
+        assert m._xp_cache[1] == hip.GNN_FLAG_EXP_PRODUCT          # default init: tiny bound
+        m.edge_network.network[0].weight.mul_(40.0)                # pre-activations of +-100
+        e_big = m(batch)
+        assert m._xp_cache[1] == 0                                 # in-place update seen, exact path
+    params = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    ref = index_c.segment_classifier(g.X, g.src, g.dst, params, 2)
+    assert np.abs(e_big.cpu().numpy() - ref).max() < TOL
+    assert not torch.equal(e, e_big)
