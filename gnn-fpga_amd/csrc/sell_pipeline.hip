@@ -346,6 +346,49 @@ struct Records {
     }
 };
 
+// Same records, computed and stored piecewise (P|R, then Q|S, then U): shorter live ranges than
+// Records for callers that may issue the stores right away (k_iter2: its prefetch has arrived).
+template <int F, int D, bool LAST, bool XP>
+__device__ __forceinline__ void emit_now(const float *wl, const float *hn, const float *x,
+                                         int64_t n, int q, float *__restrict__ PRn,
+                                         float *__restrict__ QSn, float *__restrict__ U,
+                                         float *__restrict__ Pc, float *__restrict__ Qc)
+{
+    using L = TL<F, D>;
+    constexpr int d4 = D / 4;
+    {
+        float pr[LAST ? d4 : 2 * d4];
+        role_gemv<d4, D, F>(wl + L::o_m + 0 * L::m_st, hn, x, pr);
+        if constexpr (XP)
+#pragma unroll
+            for (int i = 0; i < d4; ++i) pr[i] = __builtin_amdgcn_exp2f(pr[i]);
+        if constexpr (LAST) {
+            store_vec<d4>(Pc + n * D + q * d4, pr);
+        } else {
+            role_gemv<d4, D, F>(wl + L::o_m + 1 * L::m_st, hn, x, pr + d4);
+            store_vec<2 * d4>(PRn + n * 2 * D + q * 2 * d4, pr);
+        }
+    }
+    {
+        float qs[LAST ? d4 : 2 * d4];
+        role_gemv<d4, D, F>(wl + L::o_m + 2 * L::m_st, hn, x, qs);
+        if constexpr (XP)
+#pragma unroll
+            for (int i = 0; i < d4; ++i) qs[i] = __builtin_amdgcn_exp2f(qs[i]);
+        if constexpr (LAST) {
+            store_vec<d4>(Qc + n * D + q * d4, qs);
+        } else {
+            role_gemv<d4, D, F>(wl + L::o_m + 3 * L::m_st, hn, x, qs + d4);
+            store_vec<2 * d4>(QSn + n * 2 * D + q * 2 * d4, qs);
+        }
+    }
+    if constexpr (!LAST) {
+        float u[d4];
+        role_gemv<d4, D, F>(wl + L::o_m + 4 * L::m_st, hn, x, u);
+        store_vec<d4>(U + n * D + q * d4, u);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
@@ -802,9 +845,8 @@ __global__ __launch_bounds__(1024) void k_iter2(
         d.out_lo = td[4]; d.out_cnt = td[5]; d.sbase = td[7];
         return d;
     };
-    // which slice this wavefront takes in round r of a phase: the plan's cost-balanced schedule
+    // which slice this wavefront takes in round r (both phases): the plan's cost-balanced schedule
     auto slice_a = [&](const Desc &d, int r) { return sched_a[d.sbase + r * NWV + wv]; };
-    auto slice_b = [&](const Desc &d, int r) { return sched_b[d.sbase + r * NWV + wv]; };
 
     // ---- window staging by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write) -------------
     // One wave-instruction moves 64 lanes x 16 B = 1 KiB to a wave-uniform LDS address; waves
@@ -826,7 +868,7 @@ __global__ __launch_bounds__(1024) void k_iter2(
 
     // ---- per-slice prefetch (one slice ahead), split by phase -------------------------------------
     struct PreA { int len; int c[NC]; AVec<d4> Q, U; };             // in-list, own Q, acc init
-    struct PreB { int len; int c[NC]; AVec<d4> P, U; AVec<F> x; };  // out-list, own P, acc, X row
+    struct PreB { int len; int c[NC]; AVec<d4> P; AVec<F> x; };      // out-list, own P, X row
     auto prefetchA = [&](PreA &p, int slice) {
         p.len = (__builtin_amdgcn_readfirstlane(in_off[slice + 1]) -
                  __builtin_amdgcn_readfirstlane(in_off[slice])) >> 4;
@@ -838,7 +880,7 @@ __global__ __launch_bounds__(1024) void k_iter2(
         p.Q.load(QS + n * 2 * D + q * 2 * d4);
         p.U.load(U + n * D + q * d4);
     };
-    auto prefetchB = [&](PreB &p, int slice, bool with_u) {
+    auto prefetchB = [&](PreB &p, int slice) {
         p.len = (__builtin_amdgcn_readfirstlane(out_off[slice + 1]) -
                  __builtin_amdgcn_readfirstlane(out_off[slice])) >> 4;
         const int32_t *lo = out_nbr16 + __builtin_amdgcn_readfirstlane(out_off16[slice]) + q * SLICE + i16;
@@ -848,11 +890,35 @@ __global__ __launch_bounds__(1024) void k_iter2(
         static_assert(NC == 4, "prefetch is written out for 4 words (32 steps)");
         const int64_t n = (int64_t)slice * SLICE + i16;
         p.P.load(PR + n * 2 * D + q * 2 * d4);
-        if (with_u) p.U.load(U + n * D + q * d4);   // U[n] + in-sweep sum, stored during phase A
         p.x.load(X + n * F);
     };
     auto arriveA = [&](PreA &p) { a_wait_all(); a_fence(p.c); p.Q.fence(); p.U.fence(); };
-    auto arriveB = [&](PreB &p) { a_wait_all(); a_fence(p.c); p.P.fence(); p.U.fence(); p.x.fence(); };
+    auto arriveB = [&](PreB &p) { a_wait_all(); a_fence(p.c); p.P.fence(); p.x.fence(); };
+
+    // Partial sums of the (at most MAXR) slices a wavefront owns in a tile stay in registers
+    // across the phase barrier.  Round indices are wave-uniform, so a scalar switch selects
+    // the slot; the sweep code itself exists once.
+    constexpr int MAXR = 5;                    // tile_hits 1280 = 80 slices = 5 rounds of 16 waves
+    // (five separate arrays and selects: an indexed 2-D private array is demoted to scratch)
+    float ac0[d4], ac1[d4], ac2[d4], ac3[d4], ac4[d4];
+    auto acc_put = [&](int r, const float *a) {
+#pragma unroll
+        for (int i = 0; i < d4; ++i) {
+            ac0[i] = (r == 0) ? a[i] : ac0[i];
+            ac1[i] = (r == 1) ? a[i] : ac1[i];
+            ac2[i] = (r == 2) ? a[i] : ac2[i];
+            ac3[i] = (r == 3) ? a[i] : ac3[i];
+            ac4[i] = (r >= 4) ? a[i] : ac4[i];
+        }
+    };
+    auto acc_get = [&](int r, float *a) {
+#pragma unroll
+        for (int i = 0; i < d4; ++i)
+            a[i] = (r == 0) ? ac0[i] : (r == 1) ? ac1[i] : (r == 2) ? ac2[i] : (r == 3) ? ac3[i] : ac4[i];
+    };
+    static_assert(MAXR == 5, "accumulator slots are written out for 5 rounds");
+#pragma unroll
+    for (int i = 0; i < d4; ++i) ac0[i] = ac1[i] = ac2[i] = ac3[i] = ac4[i] = 0.0f;
 
     // ---- prologue: first tile's PR window, first slice of phase A ---------------------------------
     Desc d = load_desc(tile);
@@ -871,8 +937,6 @@ __global__ __launch_bounds__(1024) void k_iter2(
         const float b2 = lds[L::o_b2];
         const int rounds = (d.s_end - d.s_begin + NWV - 1) / NWV;
         // ================= phase A: in-sweeps; QS window of this tile in flight ==================
-        // The partial sum goes back to U[n] (same lane reads it again in phase B: an L2 round
-        // trip, not HBM) so that the round loop needs no per-round register state.
         stage_issue(QS + (int64_t)d.out_lo * 2 * D, bufB, d.out_cnt);
         // The last round is peeled (LR = true): it requests the first slice of phase B instead of
         // a next in-slice.  Written as one generic lambda so b_cur is DEFINED only there: a
@@ -881,11 +945,9 @@ __global__ __launch_bounds__(1024) void k_iter2(
             constexpr bool LR = decltype(lr)::value;
             const int slice = slice_a(d, r);
             const int next = LR ? -1 : slice_a(d, r + 1);
-            // First slice of phase B: its lists, own P and X row are requested here; its U[n]
-            // (the in-sweep sum, possibly written by ANOTHER wavefront of this tile during
-            // phase A - the two phases have their own schedules) only after the phase barrier.
+            // first slice of phase B (same wave, same slices as phase A): lists, own P, X row
             if constexpr (LR) {
-                if (slice_b(d, 0) >= 0) prefetchB(b_cur, slice_b(d, 0), false);
+                if (slice_a(d, 0) >= 0) prefetchB(b_cur, slice_a(d, 0));
             } else {
                 if (next >= 0) prefetchA(a_nxt, next);
             }
@@ -904,18 +966,13 @@ __global__ __launch_bounds__(1024) void k_iter2(
                     a_cur = a_nxt;
                 }
             }
-            if (slice >= 0) store_vec<d4>(U + n * D + q * d4, acc);
+            if (slice >= 0) acc_put(r, acc);
         };
         for (int r = 0; r + 1 < rounds; ++r) roundA(r, std::false_type{});
         roundA(rounds - 1, std::true_type{});
         stage_commit(bufB, QS + n_pad * 2 * D, d.out_cnt);   // also makes b_cur readable (vmcnt 0)
-        if (slice_b(d, 0) >= 0) arriveB(b_cur);
-        __syncthreads();                               // bufB visible, bufA free, all U[n] stored
-        if (slice_b(d, 0) >= 0) {                      // now the first slice's in-sweep sum
-            b_cur.U.load(U + ((int64_t)slice_b(d, 0) * SLICE + i16) * D + q * d4);
-            a_wait_all();
-            b_cur.U.fence();
-        }
+        if (slice_a(d, 0) >= 0) arriveB(b_cur);
+        __syncthreads();                               // bufB visible, bufA free
         // ================= phase B: out-sweeps, hit update, stores; next PR window in flight ======
         const int tnext = tile + gridDim.x;
         Desc dn = d;
@@ -925,19 +982,19 @@ __global__ __launch_bounds__(1024) void k_iter2(
         }
         auto roundB = [&](int r, auto lr) {
             constexpr bool LR = decltype(lr)::value;
-            const int slice = slice_b(d, r);
-            const int next = LR ? -1 : slice_b(d, r + 1);
+            const int slice = slice_a(d, r);
+            const int next = LR ? -1 : slice_a(d, r + 1);
             if constexpr (LR) {      // first slice of the next tile's phase A
                 if (tnext < n_tiles && slice_a(dn, 0) >= 0) prefetchA(a_cur, slice_a(dn, 0));
             } else {
-                if (next >= 0) prefetchB(b_nxt, next, true);
+                if (next >= 0) prefetchB(b_nxt, next);
             }
             const int64_t n = (int64_t)slice * SLICE + i16;
             float xv[F], acc[d4];
             if (slice >= 0) {
                 float Pn[d4];
                 b_cur.P.get(Pn);
-                b_cur.U.get(acc);
+                acc_get(r, acc);
                 b_cur.x.get(xv);
                 const int len = __builtin_amdgcn_readfirstlane(b_cur.len);
                 sweep16<D, NC, XP>(b_cur.c, out_nbr16, out_off16, slice, i16, len, bufB, q, Pn, w2, b2, acc);
@@ -964,9 +1021,7 @@ __global__ __launch_bounds__(1024) void k_iter2(
 #pragma unroll
                 for (int i = 0; i < d4; ++i) hl[i] = tanh_f(hl[i]);
                 quad_allgather<d4>(hl, hn);
-                Records<F, D, LAST, XP> rec;
-                rec.compute(wl, hn, xv);
-                rec.store(n, q, PRn, QSn, U, Pc, Qc);
+emit_now<F, D, LAST, XP>(wl, hn, xv, n, q, PRn, QSn, U, Pc, Qc);
             }
         };
         for (int r = 0; r + 1 < rounds; ++r) roundB(r, std::false_type{});

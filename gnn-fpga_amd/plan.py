@@ -276,8 +276,11 @@ class SellPlan:
 
         steps_in = np.diff(in_off.astype(np.int64)) // SLICE
         steps_out = np.diff(out_off.astype(np.int64)) // SLICE
-        sched_a = schedule((steps_in + 7) // 8 * 2 + 1)          # score groups + fixed part
-        sched_b = schedule((steps_out + 7) // 8 * 2 + 6)         # + hit update
+        # sched_a: one schedule for both phases (k_iter2 keeps a slice's partial sum in registers
+        # of the wave that owns it), balanced on the total; sched_b: out-phase-only balance (kept
+        # for kernels that decouple the phases)
+        sched_a = schedule((steps_in + 7) // 8 * 2 + (steps_out + 7) // 8 * 2 + 7)
+        sched_b = schedule((steps_out + 7) // 8 * 2 + 6)
 
         # -- final edge pass: chunks of the caller's segment order --------------------------
         CH = int(limits["chunk_segments"])
