@@ -40,7 +40,7 @@ class GnnGrads(ctypes.Structure):
 class GnnPlan(ctypes.Structure):
     _fields_ = [(n, _f) for n in ("X", "src", "dst", "in_off", "in_nbr", "out_off", "out_nbr",
                                   "tiles", "chunks", "in_off16", "in_nbr16", "out_off16",
-                                  "out_nbr16", "sched_a", "sched_b")] + \
+                                  "out_nbr16", "sched_a", "sched_b", "sd16")] + \
                [("n_pad", _i64), ("n_segments", _i64), ("n_tiles", _i64), ("n_chunks", _i64),
                 ("iter_lds_records", _i64), ("edge_lds_rows", _i64), ("n_lds_tiles", _i64),
                 ("iter_lds_in", _i64), ("iter_lds_out", _i64), ("tile_hits_max", _i64),
@@ -286,7 +286,7 @@ def plan_struct(plan):
     g = GnnPlan()
     g.X = _dev(plan.X, torch.float32, "plan.X")
     for k in ("src", "dst", "in_off", "in_nbr", "out_off", "out_nbr", "tiles", "chunks",
-              "in_off16", "in_nbr16", "out_off16", "out_nbr16", "sched_a", "sched_b"):
+              "in_off16", "in_nbr16", "out_off16", "out_nbr16", "sched_a", "sched_b", "sd16"):
         setattr(g, k, _dev(getattr(plan, k), torch.int32, "plan." + k))
     g.n_pad, g.n_segments = plan.n_pad, plan.n_segments
     g.n_tiles, g.n_chunks = plan.n_tiles, plan.n_chunks

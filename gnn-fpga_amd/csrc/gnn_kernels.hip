@@ -576,7 +576,7 @@ int gnn_segclf_forward_plan(const gnn_plan_t *pl, const gnn_params_t *p, int32_t
     if (pl->iter_lds_records < 0 || pl->edge_lds_rows < 0)
         return fail(GNN_ERR_BADARG, "gnn_segclf_forward_plan: negative LDS size");
     if (!pl->X || !pl->in_off || !pl->out_off || (pl->n_tiles > 0 && !pl->tiles) ||
-        (pl->n_segments > 0 && (!pl->src || !pl->dst || !pl->chunks || !e_out)))
+        (pl->n_segments > 0 && (!pl->src || !pl->dst || !pl->sd16 || !pl->chunks || !e_out)))
         return fail(GNN_ERR_BADARG, "gnn_segclf_forward_plan: plan array missing");
     if (!p->Win || !p->bin || !p->W1 || !p->b1 || !p->W2 || !p->b2 || !p->W3 || !p->b3 || !p->W4 || !p->b4)
         return fail(GNN_ERR_BADARG, "gnn_segclf_forward_plan: weight pointer missing");

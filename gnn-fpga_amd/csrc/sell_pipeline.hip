@@ -406,22 +406,25 @@ __global__ __launch_bounds__(256) void k_input4(const float *__restrict__ X,
     __shared__ __attribute__((aligned(16))) float lds[L::total];
     stage4<256>(table, lds, L::total / 4);
     __syncthreads();
-    const int64_t n = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 2;   // n_pad % 16 == 0
-    if (n >= n_pad) return;                                             // whole quads exit
     const int q = threadIdx.x & 3;
-    const float *wl = lds + q * L::stride;
-    float x[F];
+    // grid-stride over 64-hit groups: the weight table is staged once per workgroup, not per
+    // 64 hits (n_pad % 16 == 0, so whole quads run or exit together)
+    for (int64_t n = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 2; n < n_pad;
+         n += (int64_t)gridDim.x * 64) {
+        int woff = q * L::stride;                   // opaque: keeps LDS weight reads in the loop
+        asm volatile("" : "+v"(woff));
+        const float *wl = lds + woff;
+        float x[F];
 #pragma unroll
-    for (int k = 0; k < F; ++k) x[k] = X[n * F + k];
-    float hl[d4];
-    role_gemv<d4, 0, F>(wl + L::o_in, x, x, hl);
+        for (int k = 0; k < F; ++k) x[k] = X[n * F + k];
+        float hl[d4];
+        role_gemv<d4, 0, F>(wl + L::o_in, x, x, hl);
 #pragma unroll
-    for (int i = 0; i < d4; ++i) hl[i] = tanh_f(hl[i]);
-    float hn[D];
-    quad_allgather<d4>(hl, hn);
-    Records<F, D, LAST, XP> rec;
-    rec.compute(wl, hn, x);
-    rec.store(n, q, PRn, QSn, U, Pc, Qc);
+        for (int i = 0; i < d4; ++i) hl[i] = tanh_f(hl[i]);
+        float hn[D];
+        quad_allgather<d4>(hl, hn);
+        emit_now<F, D, LAST, XP>(wl, hn, x, n, q, PRn, QSn, U, Pc, Qc);
+    }
 }
 
 // r(z') = 1 / (1 + 2^z'): the only transcendental pair of the edge MLP (see scale folding)
@@ -1039,7 +1042,8 @@ emit_now<F, D, LAST, XP>(wl, hn, xv, n, q, PRn, QSn, U, Pc, Qc);
 template <int F, int D, bool XP>
 __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_edge(
     const int32_t *__restrict__ chunks, const int32_t *__restrict__ src,
-    const int32_t *__restrict__ dst, const float *__restrict__ Pc, const float *__restrict__ Qc,
+    const int32_t *__restrict__ dst, const int32_t *__restrict__ sd16,
+    const float *__restrict__ Pc, const float *__restrict__ Qc,
     const float *__restrict__ table, float *__restrict__ e, int64_t n_pad, int chunks_per_xcd,
     int n_chunks)
 {
@@ -1062,12 +1066,13 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_edge(
     }
     const float b2 = W2[D];
     for (int j = e0 + (int)threadIdx.x; j < e1; j += NT) {
-        const int s = src[j], d = dst[j];
         float p[D], qq[D];
         if (G::ed_rec > 0 && mode) {
-            load_vec<D>(winA + s * D, p);
-            load_vec<D>(winB + d * D, qq);
+            const unsigned w = (unsigned)sd16[j];           // both window-relative endpoints
+            load_vec<D>(winA + (w & 0xFFFFu) * D, p);
+            load_vec<D>(winB + (w >> 16) * D, qq);
         } else {
+            const int s = src[j], d = dst[j];
             load_vec<D>(Pc + (int64_t)s * D, p);
             load_vec<D>(Qc + (int64_t)d * D, qq);
         }
@@ -1117,7 +1122,8 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
                w.Pc, w.Qc, Np);
     float *PR = w.PRa, *PRn = w.PRb, *QS = w.QSa, *QSn = w.QSb;
     if (Np > 0) {
-        const unsigned g = (unsigned)((Np * 4 + 255) / 256);
+        const int64_t g_need = (Np * 4 + 255) / 256;
+        const unsigned g = (unsigned)(g_need < 4096 ? g_need : 4096);   // 16 workgroups per CU, grid-stride
         if (n_iters == 0)
             GNN_LAUNCH("k_input4", (k_input4<F, D, true, XP>), g, 256, s, pl->X, w.table, PR, QS, w.U,
                        w.Pc, w.Qc, Np);
@@ -1203,7 +1209,7 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_edge<F, D, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
             edge_attr = true;
         }
-        GNN_LAUNCH_SH("k_edge", (k_edge<F, D, XP>), 8 * cpx, G::NT, ed_lds, s, pl->chunks, pl->src, pl->dst, w.Pc,
+        GNN_LAUNCH_SH("k_edge", (k_edge<F, D, XP>), 8 * cpx, G::NT, ed_lds, s, pl->chunks, pl->src, pl->dst, pl->sd16, w.Pc,
                    w.Qc, w.table, e_out, Np, cpx, nc);
     }
     return 0;

@@ -327,6 +327,9 @@ class SellPlan:
         self.X = t(Xp)
         self.x_absmax = t(np.abs(Xp).max(axis=0).astype(np.float32)) if n else t(np.zeros(X.shape[1], np.float32))
         self.src, self.dst = t(src_st.astype(np.int32)), t(dst_st.astype(np.int32))
+        # LDS-mode chunks: both window-relative endpoints in one word (dst << 16 | src)
+        sd = np.where(c_lds[c], (dst_st.astype(np.int64) << 16) | (src_st.astype(np.int64) & 0xFFFF), 0) if E else np.zeros(0, np.int64)
+        self.sd16 = t(sd.astype(np.uint32).view(np.int32))
         self.in_off, self.in_nbr = t(in_off), t(in_nbr)
         self.out_off, self.out_nbr = t(out_off), t(out_nbr)
         self.in_off16, self.in_nbr16 = t(in_off16), t(in_nbr16)
@@ -344,7 +347,7 @@ class SellPlan:
 
     _TENSORS = ("X", "src", "dst", "in_off", "in_nbr", "out_off", "out_nbr", "in_off16", "in_nbr16",
                 "out_off16", "out_nbr16", "tiles", "chunks", "sched_a", "sched_b", "perm",
-                "x_absmax")
+                "x_absmax", "sd16")
 
     def to(self, device):
         for k in self._TENSORS:

@@ -94,6 +94,7 @@ typedef struct gnn_plan {
     /* per-phase wave schedules of the phase-split kernel: sched[tile[7] + 16*round + wave] = slice
      * id (or -1) that wavefront `wave` of the tile's workgroup takes in `round` */
     const int32_t *sched_a, *sched_b;
+    const int32_t *sd16;                 /* [n_segments] LDS-mode chunks: dst_rel << 16 | src_rel   */
     int64_t n_pad, n_segments, n_tiles, n_chunks;
     int64_t iter_lds_records;            /* max over LDS-mode tiles of in_cnt + out_cnt + 2        */
     int64_t edge_lds_rows;               /* max over LDS-mode chunks of src_cnt + dst_cnt + 2      */
