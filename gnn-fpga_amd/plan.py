@@ -163,6 +163,11 @@ class SellPlan:
         X = batch.X.cpu().numpy()
         n, E = batch.n_hits, batch.n_segments
         tile_hits = int(limits["tile_hits"])
+        # small batches: shrink the tiles so that there are a few hundred workgroups to spread
+        # over the CUs (a 10k-hit graph would otherwise be 10 workgroups); windows stay whole
+        # levels, so this costs staging traffic that only matters once the chip is full anyway
+        if n < 512 * tile_hits:
+            tile_hits = max(64, ((n + 511) // 512 + SLICE - 1) // SLICE * SLICE)
         ok = src >= 0
         vs, vd = src[ok], dst[ok]
         deg_in = np.bincount(vd, minlength=n)
@@ -174,7 +179,9 @@ class SellPlan:
         level = topological_levels(vs, vd, n)
 
         # -- (graph, level) units -> tiles ------------------------------------------------
-        base = np.lexsort((level, gid))                       # position -> old id
+        # units are degree-sorted inside, so a unit that is cut into several tiles yields tiles of
+        # near-uniform list lengths
+        base = np.lexsort((-deg_out, -deg_in, level, gid))    # position -> old id
         ukey = gid[base] * (int(level.max(initial=0)) + 1) + level[base]
         ustart = np.flatnonzero(np.r_[True, ukey[1:] != ukey[:-1]]) if n else np.zeros(0, np.int64)
         usize = np.diff(np.r_[ustart, n])
