@@ -301,18 +301,27 @@ def plan_workspace_bytes(n_hits, n_segments, F, D):
     return int(load().gnn_plan_workspace_bytes(n_hits, n_segments, F, D))
 
 
-def segclf_forward_plan(plan, weights, F, D, n_iters, out=None, workspace=None, flags=0):
-    """Whole SegmentClassifier forward on a planned batch (fused pipeline) -> scores [E]."""
+def segclf_forward_plan(plan, weights, F, D, n_iters, out=None, workspace=None, flags=0,
+                        params=None):
+    """Whole SegmentClassifier forward on a planned batch (fused pipeline) -> scores [E].
+    `params`: a GnnParams built earlier from the same `weights` (skips re-validation)."""
     dev = plan.X.device
-    if not plan_shape_supported(F, D):
-        raise GnnHipError("no fused HIP kernel for input_dim=%d hidden_dim=%d" % (F, D))
-    need = plan_workspace_bytes(plan.n_pad, plan.n_segments, F, D)
+    need = getattr(plan, "_ws_need", None)
+    if need is None or plan._ws_need_shape != (F, D):
+        if not plan_shape_supported(F, D):
+            raise GnnHipError("no fused HIP kernel for input_dim=%d hidden_dim=%d" % (F, D))
+        need = plan._ws_need = plan_workspace_bytes(plan.n_pad, plan.n_segments, F, D)
+        plan._ws_need_shape = (F, D)
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(need, dtype=torch.uint8, device=dev)
     if out is None:
         out = torch.empty(plan.n_segments, dtype=torch.float32, device=dev)
-    g = plan_struct(plan)
-    p = params_struct(weights, F, D, flags)
+    g = getattr(plan, "_struct", None)
+    if g is None or plan._struct_dev != dev:       # device pointers are stable while the plan lives
+        g = plan._struct = plan_struct(plan)
+        plan._struct_dev = dev
+    p = params if params is not None else params_struct(weights, F, D, flags)
+    p.flags = flags
     _check(load().gnn_segclf_forward_plan(ctypes.byref(g), ctypes.byref(p), n_iters,
                                           _dev(out, torch.float32, "out"),
                                           workspace.data_ptr(), workspace.numel(), _stream()))

@@ -158,6 +158,7 @@ class SegmentClassifier(nn.Module):
         self.use_plan = True      # False: per-module CSR kernels instead of the fused pipeline
         self.exp_product = True   # allow GNN_FLAG_EXP_PRODUCT when the bound check passes
         self._xp_cache = None     # (key, flag): the bound check synchronises, so it is cached
+        self._w_cache = None      # (key, weights, GnnParams): rebuilt when a parameter changes
 
     def effective_weights(self):
         """The ten tensors the kernels consume, in state_dict order, masks applied."""
@@ -165,13 +166,27 @@ class SegmentClassifier(nn.Module):
         return ([_f32c(lin.weight), _f32c(lin.bias)] + self.edge_network.weights() +
                 self.node_network.weights())
 
+    def _param_key(self):
+        """Changes whenever a parameter is replaced, updated in place, moved, or (un)masked."""
+        layers = [self.edge_network.network[0], self.edge_network.network[2],
+                  self.node_network.network[0], self.node_network.network[2]]
+        return (tuple((id(p), p._version, p.data_ptr()) for p in self.parameters()) +
+                tuple((l.mask_flag, id(l.mask)) for l in layers))
+
+    def _cached_weights(self):
+        key = self._param_key()
+        if self._w_cache is None or self._w_cache[0] != key:
+            w = self.effective_weights()
+            self._w_cache = (key, w, _lib.params_struct(w, self.input_dim, self.hidden_dim))
+        return self._w_cache[1], self._w_cache[2]
+
     def _exp_product_flag(self, plan, weights):
         """GNN_FLAG_EXP_PRODUCT iff max|P'|, |Q'| <= 60 is PROVEN for these weights and this
         batch's feature range (include/gnn_hip.h).  Re-evaluated only when a parameter changed
         in place (tensor._version), was replaced, or another plan is used."""
         if not self.exp_product:
             return 0
-        key = (id(plan),) + tuple((id(p), p._version) for p in self.parameters())
+        key = (id(plan),) + self._param_key()
         if self._xp_cache is None or self._xp_cache[0] != key:
             bound = _lib.exp_product_bound(weights, self.input_dim, self.hidden_dim, plan.x_absmax)
             self._xp_cache = (key, _lib.GNN_FLAG_EXP_PRODUCT if bound <= 60.0 else 0)
@@ -201,10 +216,11 @@ class SegmentClassifier(nn.Module):
                 self._workspace.device != batch.X.device):
             self._workspace = torch.empty(need, dtype=torch.uint8, device=batch.X.device)
         if fused:     # relabel + SELL-16 plan, fused iteration kernels (csrc/sell_pipeline.hip)
-            weights = self.effective_weights()
+            weights, pstruct = self._cached_weights()
             res = _lib.segclf_forward_plan(plan, weights, F, D, self.n_iters,
                                            workspace=self._workspace,
-                                           flags=self._exp_product_flag(plan, weights))
+                                           flags=self._exp_product_flag(plan, weights),
+                                           params=pstruct)
         else:         # CSR kernels, one per reference module (csrc/gnn_kernels.hip); traces
             res = _lib.segclf_forward(batch, self.effective_weights(), F, D, self.n_iters,
                                       workspace=self._workspace, trace=trace)
