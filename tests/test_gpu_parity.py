@@ -264,3 +264,59 @@ def test_exp_product_bound_and_fallback(hip):
     ref = index_c.segment_classifier(g.X, g.src, g.dst, params, 2)
     assert np.abs(e_big.cpu().numpy() - ref).max() < TOL
     assert not torch.equal(e, e_big)
+
+
+def _random_graph(n, e, F, seed, self_loops=True):
+    """Not layered: arbitrary endpoints, multi-edges, cycles and (optionally) self loops."""
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(-1, 1, (n, F)).astype(np.float32)
+    src = rng.integers(0, n, e).astype(np.int32)
+    dst = rng.integers(0, n, e).astype(np.int32)
+    if not self_loops:
+        dst = np.where(dst == src, (dst + 1) % n, dst).astype(np.int32)
+    return synth.HitGraph(X, src, dst, np.zeros(e, np.float32))
+
+
+@pytest.mark.parametrize("F,D,T", [(3, 8, 3), (2, 4, 2), (11, 8, 2), (3, 16, 2)])
+def test_irregular_graphs_and_forced_global_mode(hip, F, D, T):
+    """Graphs without any layer structure (cycles, multi-edges, self loops) and plans forced into
+    global-gather mode: the general kernels (k_iter / k_edge without LDS windows) against the
+    C oracle, then the same batch through whatever the default plan picks."""
+    from gnn_fpga_amd.model import SegmentClassifier
+    torch.manual_seed(7)
+    graphs = [_random_graph(400, 3000, F, 1), _random_graph(37, 90, F, 2),
+              synth.layered_graph(600, 5000, F, seed=3), _random_graph(5, 40, F, 4)]
+    m = SegmentClassifier(input_dim=F, hidden_dim=D, n_iters=T).cuda().eval()
+    params = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    refs = [index_c.segment_classifier(g.X, g.src, g.dst, params, T) for g in graphs]
+    for limits in ({"iter_records": 0, "edge_records": 0}, None):
+        batch = HitGraphBatch.from_graphs(graphs).cuda()
+        plan = batch.build_plan(D, limits)
+        if limits:
+            assert plan.n_lds_tiles == 0 and plan.lds_chunk_fraction == 0.0
+        with torch.no_grad():
+            e = m(batch).cpu().numpy()
+        for eg, ref in zip(batch.split_scores(e), refs):
+            assert np.abs(eg - ref).max() < TOL
+
+
+def test_all_padded_and_degenerate_batches(hip):
+    """Only padded segments; hits without any segment; a single hit."""
+    from gnn_fpga_amd.model import SegmentClassifier
+    torch.manual_seed(1)
+    m = SegmentClassifier(input_dim=3, hidden_dim=8, n_iters=2).cuda().eval()
+    w = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    e_pad = torch.sigmoid(w["edge_network.network.2.weight"][0] @
+                          torch.tanh(w["edge_network.network.0.bias"]) +
+                          w["edge_network.network.2.bias"][0]).item()
+    X = np.random.default_rng(0).uniform(-1, 1, (9, 3)).astype(np.float32)
+    pad = -np.ones(6, np.int32)
+    with torch.no_grad():
+        e = m(HitGraphBatch(X, pad, pad).cuda())
+        assert e.shape == (6,) and np.abs(e.cpu().numpy() - e_pad).max() < 1e-6
+        e0 = m(HitGraphBatch(X, np.zeros(0, np.int32), np.zeros(0, np.int32)).cuda())
+        assert e0.shape == (0,)
+        e1 = m(HitGraphBatch(X[:1], np.zeros(1, np.int32), np.zeros(1, np.int32)).cuda())   # self loop
+    params = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    ref = index_c.segment_classifier(X[:1], np.zeros(1, np.int32), np.zeros(1, np.int32), params, 2)
+    assert np.abs(e1.cpu().numpy() - ref).max() < TOL
