@@ -320,3 +320,36 @@ def test_all_padded_and_degenerate_batches(hip):
     params = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
     ref = index_c.segment_classifier(X[:1], np.zeros(1, np.int32), np.zeros(1, np.int32), params, 2)
     assert np.abs(e1.cpu().numpy() - ref).max() < TOL
+
+
+def test_training_loop_like_estimator_fit_gen(hip):
+    """The loop of gnn/estimator.py:98-104 (zero_grad, forward, BCELoss, backward, Adam step) on
+    the HIP forward/backward, with the flat gradient all-reduce helper in its single-rank form:
+    the loss must fall and must track the same loop run through the dense oracle on CPU."""
+    from gnn_fpga_amd import shard
+    from gnn_fpga_amd.model import SegmentClassifier
+    from oracle import dense_torch
+    torch.manual_seed(5)
+    g = synth.layered_graph(150, 600, 3, seed=11)
+    y = torch.from_numpy(g.y)
+    m = SegmentClassifier(input_dim=3, hidden_dim=8, n_iters=2).cuda().train()
+    ref = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    opt = torch.optim.Adam(m.parameters(), lr=0.02)
+    opt_ref = torch.optim.Adam(ref.values(), lr=0.02)
+    batch = HitGraphBatch.from_graphs([g]).cuda()
+    Xd, Ri, Ro = (torch.from_numpy(a)[None] for a in synth.to_dense(g))
+    losses, losses_ref = [], []
+    for _ in range(25):
+        m.zero_grad()
+        out = m(batch)
+        loss_sum = torch.nn.functional.binary_cross_entropy(out, y.cuda(), reduction="sum")
+        loss_sum.backward()
+        losses.append(shard.allreduce_step(m.parameters(), loss_sum.item(), out.numel()))
+        opt.step()
+        opt_ref.zero_grad()
+        lr = torch.nn.BCELoss()(dense_torch.segment_classifier(Xd, Ri, Ro, ref, 2)[0], y)
+        lr.backward()
+        opt_ref.step()
+        losses_ref.append(lr.item())
+    assert losses[-1] < 0.8 * losses[0]
+    assert np.abs(np.array(losses) - np.array(losses_ref)).max() < 2e-4
