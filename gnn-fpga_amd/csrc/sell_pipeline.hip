@@ -80,70 +80,75 @@ struct TL {
 constexpr float kTwoLog2e = 2.8853900817779268f;
 constexpr float kLog2e = 1.4426950408889634f;
 
-template <int F, int D, bool XP>
-__global__ __launch_bounds__(256) void k_pack(gnn_params_t p, float *__restrict__ table,
-                                              float *PRa, float *PRb, float *QSa, float *QSb,
-                                              float *U, float *Pc, float *Qc, int64_t n_hits)
+// One packed-table entry (weights in per-lane-role consumption order, activation scales folded).
+template <int F, int D>
+__device__ __forceinline__ float table_entry(const gnn_params_t &p, int idx)
 {
     using L = TL<F, D>;
     constexpr int d4 = L::d4, C = L::C;
-    for (int idx = threadIdx.x; idx < L::total; idx += 256) {
-        const int q = idx / L::stride, pos = idx % L::stride;
-        float v = 0.0f;
-        if (idx >= L::o_flat) {
-            const int t = idx - L::o_flat;
-            if (t < D) {
-                v = kTwoLog2e * p.W2[t];
-            } else if (t == D) {
-                float sw = p.b2[0];
-                for (int k = 0; k < D; ++k) sw += p.W2[k];
-                v = -kLog2e * sw;
-            }
-        } else if (pos < d4) {
-            v = kTwoLog2e * p.W2[q * d4 + pos];
-        } else if (pos >= L::o_in && pos < L::o_in + L::in_sz) {
-            const int t = pos - L::o_in;
-            if (t < d4) {
-                v = p.bin[q * d4 + t];
-            } else {
-                const int k = (t - d4) / d4, i = (t - d4) % d4;
-                v = p.Win[(q * d4 + i) * F + k];
-            }
-        } else if (pos >= L::o_4 && pos < L::o_4 + L::w4_sz) {
-            const int t = pos - L::o_4;
-            if (t < d4) {
-                v = p.b4[q * d4 + t];
-            } else {
-                const int k = (t - d4) / d4, i = (t - d4) % d4;
-                v = p.W4[(q * d4 + i) * D + k];
-            }
-        } else if (pos >= L::o_m && pos < L::o_b2 && (pos - L::o_m) % L::m_st < L::m_sz) {
-            const int t = pos - L::o_m, m = t / L::m_st, u = t % L::m_st;
-            if (u < d4) {
-                const int r = q * d4 + u;
-                v = (m == 0) ? kTwoLog2e * p.b1[r] : (m == 4) ? p.b3[r] : 0.0f;
-            } else {
-                const int k = (u - d4) / d4, r = q * d4 + (u - d4) % d4;
-                switch (m) {
-                case 0: v = kTwoLog2e * p.W1[r * 2 * C + k]; break;      // P (scaled)
-                case 1: v = p.W3[r * 3 * C + k]; break;                  // R
-                case 2: v = kTwoLog2e * p.W1[r * 2 * C + C + k]; break;  // Q (scaled)
-                case 3: v = p.W3[r * 3 * C + C + k]; break;              // S
-                default: v = p.W3[r * 3 * C + 2 * C + k]; break;         // U
-                }
-            }
-        } else if (pos == L::o_b2) {
+    const int q = idx / L::stride, pos = idx % L::stride;
+    float v = 0.0f;
+    if (idx >= L::o_flat) {
+        const int t = idx - L::o_flat;
+        if (t < D) {
+            v = kTwoLog2e * p.W2[t];
+        } else if (t == D) {
             float sw = p.b2[0];
             for (int k = 0; k < D; ++k) sw += p.W2[k];
             v = -kLog2e * sw;
         }
-        table[idx] = v;
+    } else if (pos < d4) {
+        v = kTwoLog2e * p.W2[q * d4 + pos];
+    } else if (pos >= L::o_in && pos < L::o_in + L::in_sz) {
+        const int t = pos - L::o_in;
+        if (t < d4) {
+            v = p.bin[q * d4 + t];
+        } else {
+            const int k = (t - d4) / d4, i = (t - d4) % d4;
+            v = p.Win[(q * d4 + i) * F + k];
+        }
+    } else if (pos >= L::o_4 && pos < L::o_4 + L::w4_sz) {
+        const int t = pos - L::o_4;
+        if (t < d4) {
+            v = p.b4[q * d4 + t];
+        } else {
+            const int k = (t - d4) / d4, i = (t - d4) % d4;
+            v = p.W4[(q * d4 + i) * D + k];
+        }
+    } else if (pos >= L::o_m && pos < L::o_b2 && (pos - L::o_m) % L::m_st < L::m_sz) {
+        const int t = pos - L::o_m, m = t / L::m_st, u = t % L::m_st;
+        if (u < d4) {
+            const int r = q * d4 + u;
+            v = (m == 0) ? kTwoLog2e * p.b1[r] : (m == 4) ? p.b3[r] : 0.0f;
+        } else {
+            const int k = (u - d4) / d4, r = q * d4 + (u - d4) % d4;
+            switch (m) {
+            case 0: v = kTwoLog2e * p.W1[r * 2 * C + k]; break;      // P (scaled)
+            case 1: v = p.W3[r * 3 * C + k]; break;                  // R
+            case 2: v = kTwoLog2e * p.W1[r * 2 * C + C + k]; break;  // Q (scaled)
+            case 3: v = p.W3[r * 3 * C + C + k]; break;              // S
+            default: v = p.W3[r * 3 * C + 2 * C + k]; break;         // U
+            }
+        }
+    } else if (pos == L::o_b2) {
+        float sw = p.b2[0];
+        for (int k = 0; k < D; ++k) sw += p.W2[k];
+        v = -kLog2e * sw;
     }
-    // NULL hit (id n_hits): P = (scaled) b1, everything else 0.  A padded list entry adds e * 0; a
-    // padded segment scores sigmoid(W2 tanh(b1) + b2) (gnn/trainSegmentClassifier.py:83-93).
+    return v;
+}
+
+// NULL hit (id n_hits): P = (scaled) b1, everything else 0.  A padded list entry adds e * 0; a
+// padded segment scores sigmoid(W2 tanh(b1) + b2) (gnn/trainSegmentClassifier.py:83-93).
+// Exp-product mode stores 2^P', 2^Q' instead of P', Q' (see score4).
+template <int F, int D, bool XP>
+__device__ __forceinline__ void write_null_rows(const gnn_params_t &p, float *PRa, float *PRb,
+                                                float *QSa, float *QSb, float *U, float *Pc,
+                                                float *Qc, int64_t n_hits)
+{
+    constexpr int d4 = D / 4;
     for (int t = threadIdx.x; t < 2 * D; t += 256) {
         const int q = t / (2 * d4), w = t % (2 * d4);
-        // exp-product mode stores 2^P', 2^Q' instead of P', Q' (see score4)
         float pv = (w < d4) ? kTwoLog2e * p.b1[q * d4 + w] : 0.0f;
         if (XP && w < d4) pv = __builtin_amdgcn_exp2f(pv);
         const float qv = (XP && w < d4) ? 1.0f : 0.0f;
@@ -158,6 +163,17 @@ __global__ __launch_bounds__(256) void k_pack(gnn_params_t p, float *__restrict_
         Pc[n_hits * D + t] = XP ? __builtin_amdgcn_exp2f(pb) : pb;
         Qc[n_hits * D + t] = XP ? 1.0f : 0.0f;
     }
+}
+
+// stand-alone pack (only needed when a batch has no hits at all: k_input4 normally does this)
+template <int F, int D, bool XP>
+__global__ __launch_bounds__(256) void k_pack(gnn_params_t p, float *__restrict__ table,
+                                              float *PRa, float *PRb, float *QSa, float *QSb,
+                                              float *U, float *Pc, float *Qc, int64_t n_hits)
+{
+    using L = TL<F, D>;
+    for (int idx = threadIdx.x; idx < L::total; idx += 256) table[idx] = table_entry<F, D>(p, idx);
+    write_null_rows<F, D, XP>(p, PRa, PRb, QSa, QSb, U, Pc, Qc, n_hits);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -395,16 +411,25 @@ __device__ __forceinline__ void emit_now(const float *wl, const float *hn, const
 // input network (model.py:144-146) + records of iteration 0.  4 lanes per hit, over the padded
 // hit range (dummy hits have X = 0 and are never gathered).
 template <int F, int D, bool LAST, bool XP>
-__global__ __launch_bounds__(256) void k_input4(const float *__restrict__ X,
-                                                const float *__restrict__ table,
+__global__ __launch_bounds__(256) void k_input4(const float *__restrict__ X, gnn_params_t p,
+                                                float *__restrict__ table,
                                                 float *__restrict__ PRn, float *__restrict__ QSn,
+                                                float *PRo, float *QSo,
                                                 float *__restrict__ U, float *__restrict__ Pc,
                                                 float *__restrict__ Qc, int64_t n_pad)
 {
     using L = TL<F, D>;
     constexpr int d4 = L::d4;
     __shared__ __attribute__((aligned(16))) float lds[L::total];
-    stage4<256>(table, lds, L::total / 4);
+    // Every workgroup packs the weight table straight from the raw weights (a few L2-resident
+    // loads per thread: cheaper than one more kernel boundary); workgroup 0 also publishes it
+    // and the NULL rows for the kernels that follow.
+    for (int idx = threadIdx.x; idx < L::total; idx += 256) {
+        const float v = table_entry<F, D>(p, idx);
+        lds[idx] = v;
+        if (blockIdx.x == 0) table[idx] = v;
+    }
+    if (blockIdx.x == 0) write_null_rows<F, D, XP>(p, PRn, PRo, QSn, QSo, U, Pc, Qc, n_pad);
     __syncthreads();
     const int q = threadIdx.x & 3;
     // grid-stride over 64-hit groups: the weight table is staged once per workgroup, not per
@@ -1118,18 +1143,19 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
     using G = Cfg<F, D>;
     const int64_t Np = pl->n_pad, E = pl->n_segments;
     Ws w = carve(ws, Np, L::total, D);
-    GNN_LAUNCH("k_pack", (k_pack<F, D, XP>), 1, 256, s, *p, w.table, w.PRa, w.PRb, w.QSa, w.QSb, w.U,
-               w.Pc, w.Qc, Np);
+    if (Np == 0)      // nothing for k_input4 to do: pack the table / NULL rows on their own
+        GNN_LAUNCH("k_pack", (k_pack<F, D, XP>), 1, 256, s, *p, w.table, w.PRa, w.PRb, w.QSa, w.QSb,
+                   w.U, w.Pc, w.Qc, Np);
     float *PR = w.PRa, *PRn = w.PRb, *QS = w.QSa, *QSn = w.QSb;
     if (Np > 0) {
         const int64_t g_need = (Np * 4 + 255) / 256;
         const unsigned g = (unsigned)(g_need < 4096 ? g_need : 4096);   // 16 workgroups per CU, grid-stride
         if (n_iters == 0)
-            GNN_LAUNCH("k_input4", (k_input4<F, D, true, XP>), g, 256, s, pl->X, w.table, PR, QS, w.U,
-                       w.Pc, w.Qc, Np);
+            GNN_LAUNCH("k_input4", (k_input4<F, D, true, XP>), g, 256, s, pl->X, *p, w.table, PR, QS,
+                       PRn, QSn, w.U, w.Pc, w.Qc, Np);
         else
-            GNN_LAUNCH("k_input4", (k_input4<F, D, false, XP>), g, 256, s, pl->X, w.table, PR, QS, w.U,
-                       w.Pc, w.Qc, Np);
+            GNN_LAUNCH("k_input4", (k_input4<F, D, false, XP>), g, 256, s, pl->X, *p, w.table, PR, QS,
+                       PRn, QSn, w.U, w.Pc, w.Qc, Np);
         const int nt = (int)pl->n_tiles;
         const int tpx = (nt + 7) / 8;
         const size_t it_lds = (size_t)(L::total + (G::it_rec > 0 ? pl->iter_lds_records : 0) * 2 * D + 4) * sizeof(float);
