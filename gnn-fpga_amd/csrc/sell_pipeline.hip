@@ -18,18 +18,24 @@
 // D-vector and the matching 16-byte (at D=8) chunk of a record, so a quad reads a neighbour's
 // record as one coalesced 64-byte access and a wavefront (16 hits = one SELL-16 slice) reads
 // its 16 neighbour ids as one 64-byte access.  The D-wide dot product with W2 is finished with
-// two DPP quad-permute adds.  After the degree sort of plan.py all 16 hits of a slice have
-// the same list length: no divergence, ~3 % padding (padded entries point at the NULL
+// a 4x4 transpose-add in the quad, so that each lane evaluates the sigmoid of ONE of four
+// segments.  After the degree sort of plan.py the 16 hits of a slice have near-equal list
+// lengths: no divergence, ~12 % padding at 1000-hit levels (padded entries point at the NULL
 // record, whose R/S half is zero).
 //
 // Hit-update MLP tail: lane q computes its D/4 rows of W4 and of the five record matrices;
-// its weight rows differ per q, so they cannot be scalar operands: a tiny pack kernel lays
-// the weights out per lane role in consumption order and each workgroup copies that table
-// (2.4 KB at F=3, D=8) into LDS; the 4 roles read 4 distinct addresses per instruction
-// (broadcast, conflict-free).
+// its weight rows differ per q, so they cannot be scalar operands: the weights are laid out
+// per lane role in consumption order (table_entry; 2.6 KB at F=3, D=8) and live in LDS; the 4
+// roles read 4 distinct addresses per instruction (broadcast, conflict-free).
+//
+// Kernels: k_input4 (input network, first records, packs the weight table), k_iter2 (persistent
+// phase-split iteration kernel: the fast path, see its comment), k_iter (general iteration
+// kernel: any supported shape, global-gather tiles), k_edge (final edge pass), k_pack (table only,
+// for batches without hits).  Activation scales are folded into the weights and an optional
+// exp-product mode trades v_exp for a multiply (score4).
 //
 // LDS-staged windows: plan.py orders hits by (graph, topological level) and cuts them into
-// tiles of <= 1024 hits, one workgroup each.  All start hits of a tile's incoming segments lie
+// tiles of <= 1280 hits (smaller for small batches), one workgroup each.  All start hits of a tile's incoming segments lie
 // in one contiguous id window and all end hits of its outgoing segments in another, so the
 // workgroup copies the two windows of records (PR of the previous level, QS of the next: 64 KB
 // each at 1000 hits/level, D = 8) into LDS with fully coalesced reads and gathers from LDS
