@@ -486,18 +486,22 @@ __device__ __forceinline__ void a_load_i32(int &dst, const int32_t *p)
 
 // N floats loaded by asm: the asm outputs ARE the storage (no element is copied out before
 // arrive), as pieces of 4 / 3 / 2 / 1 dwords.
+struct AEmpty {};
 template <int N>
 struct AVec {
     static constexpr int N4 = N / 4, R = N % 4;
-    f4_t v4[N4 ? N4 : 1];
-    f3_t v3;
-    f2_t v2;
-    float v1;
+    // only the pieces that exist are members: a struct copy (cur = nxt) must not drag unused
+    // vector registers along
+    struct V4 { f4_t v[N4 > 0 ? N4 : 1]; };
+    [[no_unique_address]] std::conditional_t<(N4 > 0), V4, AEmpty> p4;
+    [[no_unique_address]] std::conditional_t<R == 3, f3_t, AEmpty> v3;
+    [[no_unique_address]] std::conditional_t<R == 2, f2_t, AEmpty> v2;
+    [[no_unique_address]] std::conditional_t<R == 1, float, AEmpty> v1;
     template <int I>
     __device__ __forceinline__ void load4(const float *p)
     {
         if constexpr (I < N4) {
-            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(v4[I]) : "v"(p), "n"(16 * I));
+            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(p4.v[I]) : "v"(p), "n"(16 * I));
             load4<I + 1>(p);
         }
     }
@@ -512,20 +516,32 @@ struct AVec {
         if constexpr (R == 1)
             asm volatile("global_load_dword %0, %1, off offset:%2" : "=v"(v1) : "v"(p), "n"(16 * N4));
     }
+    template <int I>
+    __device__ __forceinline__ void fence4()
+    {
+        if constexpr (I < N4) {
+            asm volatile("" : "+v"(p4.v[I]));
+            fence4<I + 1>();
+        }
+    }
     __device__ __forceinline__ void fence()
     {
-#pragma unroll
-        for (int i = 0; i < N4; ++i) asm volatile("" : "+v"(v4[i]));
+        fence4<0>();
         if constexpr (R == 3) asm volatile("" : "+v"(v3));
         if constexpr (R == 2) asm volatile("" : "+v"(v2));
         if constexpr (R == 1) asm volatile("" : "+v"(v1));
     }
+    template <int I>
+    __device__ __forceinline__ void get4(float *dst) const
+    {
+        if constexpr (I < N4) {
+            dst[4 * I] = p4.v[I].x; dst[4 * I + 1] = p4.v[I].y; dst[4 * I + 2] = p4.v[I].z; dst[4 * I + 3] = p4.v[I].w;
+            get4<I + 1>(dst);
+        }
+    }
     __device__ __forceinline__ void get(float *dst) const     // only after arrive
     {
-#pragma unroll
-        for (int i = 0; i < N4; ++i) {
-            dst[4 * i] = v4[i].x; dst[4 * i + 1] = v4[i].y; dst[4 * i + 2] = v4[i].z; dst[4 * i + 3] = v4[i].w;
-        }
+        get4<0>(dst);
         if constexpr (R == 3) { dst[4 * N4] = v3.x; dst[4 * N4 + 1] = v3.y; dst[4 * N4 + 2] = v3.z; }
         if constexpr (R == 2) { dst[4 * N4] = v2.x; dst[4 * N4 + 1] = v2.y; }
         if constexpr (R == 1) dst[4 * N4] = v1;
@@ -652,40 +668,67 @@ __device__ __forceinline__ void sweep(const int *pre, const int32_t *__restrict_
 // Walk of a 16-bit packed list (plan.py _pack16): every register of c[] holds 8 steps for the quad
 // (lane q: steps 8sc+2q and 8sc+2q+1), the registers ROTATE through c[0] so this is a real loop.
 // Steps past the list end are NULL entries already (the packed lists are padded), so no fix-up.
-template <int D, int NC, bool XP>
+template <int D, int NC, bool XP, bool PIPE>
 __device__ __forceinline__ void sweep16(int (&c)[NC], const int32_t *__restrict__ nbr16,
                                         const int32_t *__restrict__ off16, int slice, int i16,
                                         int len, const float *REC, int q, const float *own,
                                         const float *w2, float b2, float *acc)
 {
     constexpr int d4 = D / 4;
-    for (int k = 0; k < len; k += 8) {
+    if (len <= 0) return;
+    int taken = 0;
+    auto take_word = [&]() {            // next 8 list steps of the quad
         int w = c[0];
-        if (k >= 8 * NC) {      // list longer than the prefetched words (rare): fetch and wait here,
-                                // through asm so the compiler tracks no pending load on `w`
-            a_load_i32<0>(w, nbr16 + __builtin_amdgcn_readfirstlane(off16[slice]) + ((k >> 3) * 4 + q) * SLICE + i16);
+        if (taken >= NC) {              // list longer than the prefetched words (rare): fetch and
+                                        // wait here, through asm: no tracked pending load on `w`
+            a_load_i32<0>(w, nbr16 + __builtin_amdgcn_readfirstlane(off16[slice]) +
+                                 (taken * 4 + q) * SLICE + i16);
             a_wait_all();
             asm volatile("" : "+v"(w));
         }
 #pragma unroll
         for (int i = 0; i + 1 < NC; ++i) c[i] = c[i + 1];
-        const int w01 = quad_bcast_i<0>(w), w23 = quad_bcast_i<1>(w);
-        {
-            const int nb[4] = {w01 & 0xFFFF, (int)((unsigned)w01 >> 16), w23 & 0xFFFF,
-                               (int)((unsigned)w23 >> 16)};
-            float r[4][2 * d4];
+        ++taken;
+        return w;
+    };
+    // the 4 records of one step group; HI = 0: steps held by lanes 0,1 of the quad, 1: lanes 2,3
+    auto issue = [&](float (*r)[2 * d4], int w, bool hi) {
+        const int wa = hi ? quad_bcast_i<2>(w) : quad_bcast_i<0>(w);
+        const int wb = hi ? quad_bcast_i<3>(w) : quad_bcast_i<1>(w);
+        const int nb[4] = {wa & 0xFFFF, (int)((unsigned)wa >> 16), wb & 0xFFFF,
+                           (int)((unsigned)wb >> 16)};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) load_vec<2 * d4>(REC + nb[j] * 2 * D + q * 2 * d4, r[j]);
+        for (int j = 0; j < 4; ++j) load_vec<2 * d4>(REC + nb[j] * 2 * D + q * 2 * d4, r[j]);
+    };
+    // Software pipeline: the LDS reads of step group g+1 are issued before group g is scored, so
+    // the ~100+ cycle (bank-conflicted) LDS latency runs under the 50 VALU instructions of a group
+    // instead of in front of them (only 3 sibling waves share the SIMD).
+    if constexpr (!PIPE) {              // plain form (where registers are short): read, then score
+        for (int k = 0; k < len; k += 8) {
+            const int w = take_word();
+            float r[4][2 * d4];
+            issue(r, w, false);
             score4<d4, XP>(r, own, w2, b2, q, acc);
+            if (k + 4 < len) {
+                issue(r, w, true);
+                score4<d4, XP>(r, own, w2, b2, q, acc);
+            }
         }
-        if (k + 4 < len) {
-            const int w45 = quad_bcast_i<2>(w), w67 = quad_bcast_i<3>(w);
-            const int nb[4] = {w45 & 0xFFFF, (int)((unsigned)w45 >> 16), w67 & 0xFFFF,
-                               (int)((unsigned)w67 >> 16)};
-            float r[4][2 * d4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) load_vec<2 * d4>(REC + nb[j] * 2 * D + q * 2 * d4, r[j]);
-            score4<d4, XP>(r, own, w2, b2, q, acc);
+        return;
+    }
+    float ra[4][2 * d4], rb[4][2 * d4];
+    int w = take_word();
+    issue(ra, w, false);
+    for (int k = 0; k < len; k += 8) {
+        const bool has_hi = k + 4 < len;
+        if (has_hi) issue(rb, w, true);
+        score4<d4, XP>(ra, own, w2, b2, q, acc);
+        if (has_hi) {
+            if (k + 8 < len) {
+                w = take_word();
+                issue(ra, w, false);
+            }
+            score4<d4, XP>(rb, own, w2, b2, q, acc);
         }
     }
 }
@@ -862,7 +905,7 @@ __global__ __launch_bounds__(1024) void k_iter2(
     int n_tiles, int capA)
 {
     using L = TL<F, D>;
-    constexpr int d4 = L::d4, NT = 1024, NWV = NT / 64, NC = 4;   // NC words = 32 list steps
+    constexpr int d4 = L::d4, NT = 1024, NWV = NT / 64, NC = 3;   // NC words = 24 list steps
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *lds = smem, *bufA = smem + L::total, *bufB = bufA + (int64_t)capA * 2 * D;
     stage4<NT>(table, lds, L::total / 4);            // visible after the first barrier
@@ -908,7 +951,7 @@ __global__ __launch_bounds__(1024) void k_iter2(
                  __builtin_amdgcn_readfirstlane(in_off[slice])) >> 4;
         const int32_t *li = in_nbr16 + __builtin_amdgcn_readfirstlane(in_off16[slice]) + q * SLICE + i16;
 #define GNN_PF(C_) if (8 * C_ < p.len) a_load_i32<C_ * 4 * SLICE * 4>(p.c[C_], li);
-        GNN_PF(0) GNN_PF(1) GNN_PF(2) GNN_PF(3)
+        GNN_PF(0) GNN_PF(1) GNN_PF(2)
 #undef GNN_PF
         const int64_t n = (int64_t)slice * SLICE + i16;
         p.Q.load(QS + n * 2 * D + q * 2 * d4);
@@ -919,9 +962,9 @@ __global__ __launch_bounds__(1024) void k_iter2(
                  __builtin_amdgcn_readfirstlane(out_off[slice])) >> 4;
         const int32_t *lo = out_nbr16 + __builtin_amdgcn_readfirstlane(out_off16[slice]) + q * SLICE + i16;
 #define GNN_PF(C_) if (8 * C_ < p.len) a_load_i32<C_ * 4 * SLICE * 4>(p.c[C_], lo);
-        GNN_PF(0) GNN_PF(1) GNN_PF(2) GNN_PF(3)
+        GNN_PF(0) GNN_PF(1) GNN_PF(2)
 #undef GNN_PF
-        static_assert(NC == 4, "prefetch is written out for 4 words (32 steps)");
+        static_assert(NC == 3, "prefetch is written out for 3 words (24 steps)");
         const int64_t n = (int64_t)slice * SLICE + i16;
         p.P.load(PR + n * 2 * D + q * 2 * d4);
         p.x.load(X + n * F);
@@ -992,7 +1035,7 @@ __global__ __launch_bounds__(1024) void k_iter2(
                 a_cur.U.get(acc);
                 a_cur.Q.get(Qn);
                 const int len = __builtin_amdgcn_readfirstlane(a_cur.len);
-                sweep16<D, NC, XP>(a_cur.c, in_nbr16, in_off16, slice, i16, len, bufA, q, Qn, w2, b2, acc);
+                sweep16<D, NC, XP, true>(a_cur.c, in_nbr16, in_off16, slice, i16, len, bufA, q, Qn, w2, b2, acc);
             }
             if constexpr (!LR) {
                 if (next >= 0) {
@@ -1031,7 +1074,7 @@ __global__ __launch_bounds__(1024) void k_iter2(
                 acc_get(r, acc);
                 b_cur.x.get(xv);
                 const int len = __builtin_amdgcn_readfirstlane(b_cur.len);
-                sweep16<D, NC, XP>(b_cur.c, out_nbr16, out_off16, slice, i16, len, bufB, q, Pn, w2, b2, acc);
+                sweep16<D, NC, XP, false>(b_cur.c, out_nbr16, out_off16, slice, i16, len, bufB, q, Pn, w2, b2, acc);
             }
             // the next slice's registers arrive here (in flight during the sweep); doing it before
             // the hit update keeps the two register sets from overlapping with the MLP's
