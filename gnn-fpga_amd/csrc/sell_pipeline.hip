@@ -188,8 +188,10 @@ __global__ __launch_bounds__(256) void k_pack(gnn_params_t p, float *__restrict_
 template <int CTRL>
 __device__ __forceinline__ float dpp(float v)
 {
+    // quad_perm reads only lanes of the own quad (always valid), so no "old" value is needed:
+    // mov_dpp (old = undef) saves the v_mov that update_dpp(0, ...) needs to set it up
     return __builtin_bit_cast(
-        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+        float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 
 // sum over the 4 lanes of a quad, identical bits in all 4 lanes
@@ -231,9 +233,27 @@ __device__ __forceinline__ void load_vec(const float *__restrict__ src, float *d
     }
 }
 
+typedef float f2_t __attribute__((ext_vector_type(2)));
+typedef float f3_t __attribute__((ext_vector_type(3)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+
 template <int N>
 __device__ __forceinline__ void store_vec(float *__restrict__ dst, const float *src)
 {
+#ifdef GNN_NT_STORE     // experiment: streaming stores for the records
+    if constexpr (N == 1) {
+        __builtin_nontemporal_store(src[0], dst);
+    } else if constexpr (N == 2) {
+        f2_t v = {src[0], src[1]};
+        __builtin_nontemporal_store(v, reinterpret_cast<f2_t *>(dst));
+    } else {
+#pragma unroll
+        for (int i = 0; i < N / 4; ++i) {
+            f4_t v = {src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]};
+            __builtin_nontemporal_store(v, reinterpret_cast<f4_t *>(dst) + i);
+        }
+    }
+#else
     if constexpr (N == 1) {
         dst[0] = src[0];
     } else if constexpr (N == 2) {
@@ -245,6 +265,7 @@ __device__ __forceinline__ void store_vec(float *__restrict__ dst, const float *
             reinterpret_cast<float4 *>(dst)[i] =
                 make_float4(src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
     }
+#endif
 }
 
 // copy n4 float4s global -> LDS with the whole workgroup (no barrier); 8 loads in flight per
@@ -276,7 +297,7 @@ struct Cfg {
     static constexpr int it_rec = (D <= 16) ? (lds_bytes - table_bytes - 2048) / (8 * D) : 0;
     static constexpr int ed_rec = (D <= 16) ? (lds_bytes - 2048) / (4 * D) : 0;
     static constexpr int tile_hits = 1280;      // > one 1000-hit detector level incl. fluctuations
-    static constexpr int chunk_segments = 8192;
+    static constexpr int chunk_segments = 16384;   // > one level pair of a 100k-segment graph
     // Cross-slice prefetch keeps ~25 asm-loaded registers in flight while a slice is processed.
     // That is only legal if the register allocator never spills: a spill of an in-flight
     // register would save garbage.  Enabled for the shapes whose k_iter builds with zero scratch
@@ -286,6 +307,8 @@ struct Cfg {
     static constexpr bool pipelined = (D <= 8 && F <= 3) || (D == 4);
     // shapes whose persistent phase-split kernel (k_iter2) builds with zero scratch / AGPRs
     static constexpr bool iter2 = (D <= 8 && F <= 3);
+    // ... and whose first-iteration variant (input network fused in, FIRST) does as well
+    static constexpr bool fuse_first = iter2 && !(F == 2 && D == 8);
 };
 
 // out[i] = bias[i] + sum_k W[k][i] * in[k]  for this lane's d4 rows.  The block
@@ -371,11 +394,10 @@ struct Records {
 // Same records, computed and stored piecewise (P|R, then Q|S, then U): shorter live ranges than
 // Records for callers that may issue the stores right away (k_iter2: its prefetch has arrived).
 template <int F, int D, bool LAST, bool XP>
-__device__ __forceinline__ void emit_now(const float *wl, const float *hn, const float *x,
-                                         int64_t n, int q, float *__restrict__ PRn,
-                                         float *__restrict__ QSn, float *__restrict__ U,
-                                         float *__restrict__ Pc, float *__restrict__ Qc)
-{
+__device__ __forceinline__ void emit_to(const float *wl, const float *hn, const float *x,
+                                        float *__restrict__ pr_dst, float *__restrict__ qs_dst,
+                                        float *__restrict__ u_dst)
+{   // pr_dst / qs_dst: this lane's piece of the hit's PR / QS record (LAST: of its Pc / Qc row)
     using L = TL<F, D>;
     constexpr int d4 = D / 4;
     {
@@ -384,12 +406,8 @@ __device__ __forceinline__ void emit_now(const float *wl, const float *hn, const
         if constexpr (XP)
 #pragma unroll
             for (int i = 0; i < d4; ++i) pr[i] = __builtin_amdgcn_exp2f(pr[i]);
-        if constexpr (LAST) {
-            store_vec<d4>(Pc + n * D + q * d4, pr);
-        } else {
-            role_gemv<d4, D, F>(wl + L::o_m + 1 * L::m_st, hn, x, pr + d4);
-            store_vec<2 * d4>(PRn + n * 2 * D + q * 2 * d4, pr);
-        }
+        if constexpr (!LAST) role_gemv<d4, D, F>(wl + L::o_m + 1 * L::m_st, hn, x, pr + d4);
+        store_vec<LAST ? d4 : 2 * d4>(pr_dst, pr);
     }
     {
         float qs[LAST ? d4 : 2 * d4];
@@ -397,18 +415,28 @@ __device__ __forceinline__ void emit_now(const float *wl, const float *hn, const
         if constexpr (XP)
 #pragma unroll
             for (int i = 0; i < d4; ++i) qs[i] = __builtin_amdgcn_exp2f(qs[i]);
-        if constexpr (LAST) {
-            store_vec<d4>(Qc + n * D + q * d4, qs);
-        } else {
-            role_gemv<d4, D, F>(wl + L::o_m + 3 * L::m_st, hn, x, qs + d4);
-            store_vec<2 * d4>(QSn + n * 2 * D + q * 2 * d4, qs);
-        }
+        if constexpr (!LAST) role_gemv<d4, D, F>(wl + L::o_m + 3 * L::m_st, hn, x, qs + d4);
+        store_vec<LAST ? d4 : 2 * d4>(qs_dst, qs);
     }
     if constexpr (!LAST) {
         float u[d4];
         role_gemv<d4, D, F>(wl + L::o_m + 4 * L::m_st, hn, x, u);
-        store_vec<d4>(U + n * D + q * d4, u);
+        store_vec<d4>(u_dst, u);
     }
+}
+
+template <int F, int D, bool LAST, bool XP>
+__device__ __forceinline__ void emit_now(const float *wl, const float *hn, const float *x,
+                                         int64_t n, int q, float *__restrict__ PRn,
+                                         float *__restrict__ QSn, float *__restrict__ U,
+                                         float *__restrict__ Pc, float *__restrict__ Qc)
+{
+    constexpr int d4 = D / 4;
+    if constexpr (LAST)
+        emit_to<F, D, LAST, XP>(wl, hn, x, Pc + n * D + q * d4, Qc + n * D + q * d4, nullptr);
+    else
+        emit_to<F, D, LAST, XP>(wl, hn, x, PRn + n * 2 * D + q * 2 * d4, QSn + n * 2 * D + q * 2 * d4,
+                                U + n * D + q * d4);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -474,14 +502,18 @@ __device__ __forceinline__ float r_f(float zs)
 // consumed.  Contract kept by k_iter: the asm outputs are the final storage of the loaded
 // values, and nothing reads them until a_wait_all() has executed and they have passed a fence;
 // both are asm volatile, so they stay ordered after the loads.
-typedef float f2_t __attribute__((ext_vector_type(2)));
-typedef float f3_t __attribute__((ext_vector_type(3)));
-typedef float f4_t __attribute__((ext_vector_type(4)));
-
 template <int OFF>
 __device__ __forceinline__ void a_load_i32(int &dst, const int32_t *p)
 {
     asm volatile("global_load_dword %0, %1, off offset:%2" : "=v"(dst) : "v"(p), "n"(OFF));
+}
+
+// same, address = wave-uniform base (SGPR pair) + 32-bit per-lane byte offset: the lane part of
+// an address costs ONE long-lived VGPR instead of a 64-bit pair per array
+template <int OFF>
+__device__ __forceinline__ void a_load_i32_s(int &dst, const void *sbase, unsigned voff)
+{
+    asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(OFF));
 }
 
 // N floats loaded by asm: the asm outputs ARE the storage (no element is copied out before
@@ -515,6 +547,24 @@ struct AVec {
             asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(v2) : "v"(p), "n"(16 * N4));
         if constexpr (R == 1)
             asm volatile("global_load_dword %0, %1, off offset:%2" : "=v"(v1) : "v"(p), "n"(16 * N4));
+    }
+    template <int I>
+    __device__ __forceinline__ void load4_s(const void *sb, unsigned vo)
+    {
+        if constexpr (I < N4) {
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(p4.v[I]) : "v"(vo), "s"(sb), "n"(16 * I));
+            load4_s<I + 1>(sb, vo);
+        }
+    }
+    __device__ __forceinline__ void load_s(const void *sb, unsigned vo)   // uniform base + lane offset
+    {
+        load4_s<0>(sb, vo);
+        if constexpr (R == 3)
+            asm volatile("global_load_dwordx3 %0, %1, %2 offset:%3" : "=v"(v3) : "v"(vo), "s"(sb), "n"(16 * N4));
+        if constexpr (R == 2)
+            asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(v2) : "v"(vo), "s"(sb), "n"(16 * N4));
+        if constexpr (R == 1)
+            asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(v1) : "v"(vo), "s"(sb), "n"(16 * N4));
     }
     template <int I>
     __device__ __forceinline__ void fence4()
@@ -564,7 +614,7 @@ __device__ __forceinline__ void a_fence(T (&r)[N])
 template <int J>
 __device__ __forceinline__ int quad_bcast_i(int v)
 {
-    return __builtin_amdgcn_update_dpp(0, v, J * 0x55, 0xF, 0xF, false);
+    return __builtin_amdgcn_mov_dpp(v, J * 0x55, 0xF, 0xF, true);
 }
 template <int J>
 __device__ __forceinline__ float quad_bcast_f(float v)
@@ -609,14 +659,44 @@ __device__ __forceinline__ void score4(const float (*rec)[2 * D4], const float *
                                        const float *w2, float b2, int q, float *acc)
 {
     float part[4];
+#ifndef GNN_NO_PK
+    constexpr bool use_pk = (D4 == 2);
+#else
+    constexpr bool use_pk = false;   // ablation builds
+#endif
+    if constexpr (use_pk) {
+        // packed fp32 (v_pk_fma_f32 / v_pk_mul_f32: two lanes of math per issue slot): the two
+        // hidden units of a record are a register pair, and the partial sums pair up by segment
+        const f2_t o2 = {own[0], own[1]}, one2 = {1.0f, 1.0f};
+        float r[4][2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        part[j] = 0.0f;
+        for (int j = 0; j < 4; ++j) {
+            const f2_t pj = {rec[j][0], rec[j][1]};
+            f2_t a;
+            if constexpr (XP) {
+                a = pj * o2 + one2;
+            } else {
+                const f2_t z = pj + o2;
+                const f2_t ex = {__builtin_amdgcn_exp2f(z.x), __builtin_amdgcn_exp2f(z.y)};
+                a = ex + one2;
+            }
+            r[j][0] = __builtin_amdgcn_rcpf(a.x);
+            r[j][1] = __builtin_amdgcn_rcpf(a.y);
+        }
+        const f2_t wa = {w2[0], w2[0]}, wb = {w2[1], w2[1]};
+        const f2_t p01 = wa * f2_t{r[0][0], r[1][0]} + wb * f2_t{r[0][1], r[1][1]};
+        const f2_t p23 = wa * f2_t{r[2][0], r[3][0]} + wb * f2_t{r[2][1], r[3][1]};
+        part[0] = p01.x; part[1] = p01.y; part[2] = p23.x; part[3] = p23.y;
+    } else {
 #pragma unroll
-        for (int i = 0; i < D4; ++i) {
-            const float r = XP ? __builtin_amdgcn_rcpf(fmaf(rec[j][i], own[i], 1.0f))
-                               : r_f(rec[j][i] + own[i]);
-            part[j] = fmaf(w2[i], r, part[j]);
+        for (int j = 0; j < 4; ++j) {
+            part[j] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < D4; ++i) {
+                const float r = XP ? __builtin_amdgcn_rcpf(fmaf(rec[j][i], own[i], 1.0f))
+                                   : r_f(rec[j][i] + own[i]);
+                part[j] = fmaf(w2[i], r, part[j]);
+            }
         }
     }
     // stage 1 (xor 1): even lanes keep segments {0,2}, odd lanes {1,3}
@@ -681,8 +761,8 @@ __device__ __forceinline__ void sweep16(int (&c)[NC], const int32_t *__restrict_
         int w = c[0];
         if (taken >= NC) {              // list longer than the prefetched words (rare): fetch and
                                         // wait here, through asm: no tracked pending load on `w`
-            a_load_i32<0>(w, nbr16 + __builtin_amdgcn_readfirstlane(off16[slice]) +
-                                 (taken * 4 + q) * SLICE + i16);
+            a_load_i32_s<0>(w, nbr16 + __builtin_amdgcn_readfirstlane(off16[slice]) + taken * 4 * SLICE,
+                            (unsigned)(q * SLICE + i16) * 4u);
             a_wait_all();
             asm volatile("" : "+v"(w));
         }
@@ -692,14 +772,31 @@ __device__ __forceinline__ void sweep16(int (&c)[NC], const int32_t *__restrict_
         return w;
     };
     // the 4 records of one step group; HI = 0: steps held by lanes 0,1 of the quad, 1: lanes 2,3
+    // LDS byte address of this lane's piece of record 0; v_mad_u32_u16 then turns a 16-bit window
+    // index (either half of a packed word, op_sel) into the piece's address in ONE instruction
+    typedef __attribute__((address_space(3))) const float lds_cf;
+    const unsigned rec0 = (unsigned)(uintptr_t)(lds_cf *)(REC + q * 2 * d4);
     auto issue = [&](float (*r)[2 * d4], int w, bool hi) {
         const int wa = hi ? quad_bcast_i<2>(w) : quad_bcast_i<0>(w);
         const int wb = hi ? quad_bcast_i<3>(w) : quad_bcast_i<1>(w);
-        const int nb[4] = {wa & 0xFFFF, (int)((unsigned)wa >> 16), wb & 0xFFFF,
-                           (int)((unsigned)wb >> 16)};
+        unsigned ad[4];
+        static_assert(8 * D <= 64, "record size must be an inline constant");
+        asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(ad[0]) : "v"(wa), "n"(8 * D), "v"(rec0));
+        asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(ad[1]) : "v"(wa), "n"(8 * D), "v"(rec0));
+        asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(ad[2]) : "v"(wb), "n"(8 * D), "v"(rec0));
+        asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(ad[3]) : "v"(wb), "n"(8 * D), "v"(rec0));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) load_vec<2 * d4>(REC + nb[j] * 2 * D + q * 2 * d4, r[j]);
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (d4 == 2) {
+                const f4_t v = *(const __attribute__((address_space(3))) f4_t *)(uintptr_t)ad[j];
+                r[j][0] = v.x; r[j][1] = v.y; r[j][2] = v.z; r[j][3] = v.w;
+            } else {
+                const f2_t v = *(const __attribute__((address_space(3))) f2_t *)(uintptr_t)ad[j];
+                r[j][0] = v.x; r[j][1] = v.y;
+            }
+        }
     };
+    static_assert(d4 == 1 || d4 == 2, "record piece is 8 or 16 bytes");
     // Software pipeline: the LDS reads of step group g+1 are issued before group g is scored, so
     // the ~100+ cycle (bank-conflicted) LDS latency runs under the 50 VALU instructions of a group
     // instead of in front of them (only 3 sibling waves share the SIMD).
@@ -892,9 +989,10 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_iter(
 // While phase A computes, the tile's QS window is in flight (asm loads into registers, written
 // to bufB at the end of the phase); while phase B computes, the NEXT tile's PR window is in
 // flight.  So window staging, list prefetch and stores all run under VALU work.
-template <int F, int D, bool LAST, bool XP>
+template <int F, int D, bool LAST, bool XP, bool FIRST>
 __global__ __launch_bounds__(1024) void k_iter2(
-    const float *__restrict__ X, const float *__restrict__ table,
+    const float *__restrict__ X, const float *__restrict__ table, gnn_params_t p,
+    float *__restrict__ table_out,
     const int32_t *__restrict__ tiles, const int32_t *__restrict__ in_off,
     const int32_t *__restrict__ in_off16, const int32_t *__restrict__ in_nbr16,
     const int32_t *__restrict__ out_off, const int32_t *__restrict__ out_off16,
@@ -902,17 +1000,32 @@ __global__ __launch_bounds__(1024) void k_iter2(
     const int32_t *__restrict__ sched_b, const float *__restrict__ PR,
     const float *__restrict__ QS, float *__restrict__ U, float *__restrict__ PRn,
     float *__restrict__ QSn, float *__restrict__ Pc, float *__restrict__ Qc, int64_t n_pad,
-    int n_tiles, int capA)
+    int n_tiles, int capA, int capB)
 {
     using L = TL<F, D>;
     constexpr int d4 = L::d4, NT = 1024, NWV = NT / 64, NC = 3;   // NC words = 24 list steps
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *lds = smem, *bufA = smem + L::total, *bufB = bufA + (int64_t)capA * 2 * D;
-    stage4<NT>(table, lds, L::total / 4);            // visible after the first barrier
-    int tile = blockIdx.x;
-    if (tile >= n_tiles) return;
+    float *xbuf = bufB + (int64_t)capB * 2 * D;      // FIRST only: X rows of the next window
     const int tid = threadIdx.x, lane = tid & 63, q = lane & 3, i16 = lane >> 2;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if constexpr (FIRST) {
+        // first iteration: there are no records yet.  The workgroup packs the weight table from
+        // the raw weights (workgroup 0 publishes it and the NULL rows for the launches that
+        // follow) and computes every record it needs from X (see compute_window).
+        for (int idx = tid; idx < L::total; idx += NT) {
+            const float v = table_entry<F, D>(p, idx);
+            lds[idx] = v;
+            if (blockIdx.x == 0) table_out[idx] = v;
+        }
+        if (blockIdx.x == 0)
+            write_null_rows<F, D, XP>(p, PRn, const_cast<float *>(PR), QSn, const_cast<float *>(QS),
+                                      U, Pc, Qc, n_pad);
+    } else {
+        stage4<NT>(table, lds, L::total / 4);        // visible after the first barrier
+    }
+    int tile = blockIdx.x;
+    if (tile >= n_tiles) return;
 
     struct Desc { int s_begin, s_end, in_lo, in_cnt, out_lo, out_cnt, sbase; };
     auto load_desc = [&](int t) {
@@ -931,46 +1044,142 @@ __global__ __launch_bounds__(1024) void k_iter2(
     // buffers are sized in whole pieces plus one (NULL record) and the workspace rows are padded.
     auto stage_issue = [&](const float *src, float *buf, int nrec) {
         const int pieces = (nrec * 2 * D + 255) / 256;
+        unsigned lb = (unsigned)lane * 16u;         // opaque: the 64-bit lane address is rebuilt per
+        asm volatile("" : "+v"(lb));                // call instead of living in a register pair
         for (int c = wv; c < pieces; c += NWV)
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(src + (int64_t)c * 256 + lane * 4),
+                (const __attribute__((address_space(1))) void *)(
+                    reinterpret_cast<const char *>(src + (int64_t)c * 256) + lb),
                 (__attribute__((address_space(3))) void *)(buf + c * 256), 16, 0, 0);
     };
-    auto stage_commit = [&](float *buf, const float *null_rec, int nrec) {
+    // NULL record of a window (write_null_rows: P = scaled b1, Q = R = S = 0; 2^x of that in
+    // exp-product mode), rebuilt from the LDS weight table: no per-lane global address to keep
+    // Written by the wave that issued the window's last DMA piece (the piece that may cover the
+    // NULL slot): that wave has waited for its own DMA, the others' pieces lie below the slot.
+    auto put_null = [&](float *buf, int nrec, auto which) {
+        constexpr int M = decltype(which)::value;                      // 0: [P|R], 1: [Q|S]
+        const int pieces = (nrec * 2 * D + 255) / 256;
+        if (wv == (pieces > 0 ? (pieces - 1) % NWV : 0) && lane < 4) {
+            int l = lane;                       // opaque: addresses and constants of this rare
+            asm volatile("" : "+v"(l));         // path are built here, not kept in registers
+#pragma unroll
+            for (int i = 0; i < d4; ++i) {
+                float v = (M == 0) ? lds[l * L::stride + L::o_m + i] : 0.0f, z = 0.0f;
+                if (XP) v = (M == 0) ? __builtin_amdgcn_exp2f(v) : 1.0f;
+                asm volatile("" : "+v"(v), "+v"(z));
+                buf[nrec * 2 * D + l * 2 * d4 + i] = v;
+                buf[nrec * 2 * D + l * 2 * d4 + d4 + i] = z;
+            }
+        }
+    };
+    using WinA = std::integral_constant<int, 0>;
+    using WinB = std::integral_constant<int, 1>;
+    auto stage_commit = [&](float *buf, int nrec, auto which) {
         a_wait_all();                                                  // DMA pieces have landed
-        if (tid < 2 * D / 4)                                           // NULL record
-            reinterpret_cast<f4_t *>(buf)[nrec * 2 * D / 4 + tid] =
-                reinterpret_cast<const f4_t *>(null_rec)[tid];
+        put_null(buf, nrec, which);
+    };
+
+    // ---- FIRST: windows computed from X ------------------------------------------------------------
+    // The X rows of a window (cnt * F floats, 12 KB) arrive by LDS-DMA one phase ahead, like the
+    // record windows of the later iterations; between the phases every quad turns rows into
+    // records: H0 = [tanh(Win x + bin) | x] (model.py:144-146), then [P | R] (M = 0) or [Q | S]
+    // (M = 1) with the same role_gemv blocks k_input4 / emit_now use - same bits.
+    auto xstage_issue = [&](int lo, int cnt) {
+        const int pieces = (cnt * F + 63) / 64;                        // 256-byte pieces
+        unsigned lb = (unsigned)lane * 4u;
+        asm volatile("" : "+v"(lb));
+        for (int c = wv; c < pieces; c += NWV)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(
+                    reinterpret_cast<const char *>(X + (int64_t)lo * F + c * 64) + lb),
+                (__attribute__((address_space(3))) void *)(xbuf + c * 64), 4, 0, 0);
+    };
+    auto h0_of = [&](const float *wl, const float *x, float *hn) {
+        float hl[d4];
+        role_gemv<d4, 0, F>(wl + L::o_in, x, x, hl);
+#pragma unroll
+        for (int i = 0; i < d4; ++i) hl[i] = tanh_f(hl[i]);
+        quad_allgather<d4>(hl, hn);
+    };
+    auto compute_window = [&](float *buf, int cnt, auto which) {
+        constexpr int M = decltype(which)::value;
+        a_wait_all();                                  // this wave's DMA pieces have landed
+        __syncthreads();                               // ... and everybody else's
+        for (int h = tid >> 2; h < cnt; h += NT / 4) {
+            int woff = q * L::stride;
+            asm volatile("" : "+v"(woff));
+            const float *wl = lds + woff;
+            float x[F], hn[D], rec[2 * d4];
+#pragma unroll
+            for (int k = 0; k < F; ++k) x[k] = xbuf[h * F + k];
+            h0_of(wl, x, hn);
+            role_gemv<d4, D, F>(wl + L::o_m + (2 * M) * L::m_st, hn, x, rec);
+            if constexpr (XP)
+#pragma unroll
+                for (int i = 0; i < d4; ++i) rec[i] = __builtin_amdgcn_exp2f(rec[i]);
+            role_gemv<d4, D, F>(wl + L::o_m + (2 * M + 1) * L::m_st, hn, x, rec + d4);
+            store_vec<2 * d4>(buf + h * 2 * D + q * 2 * d4, rec);
+        }
+        put_null(buf, cnt, which);
     };
 
     // ---- per-slice prefetch (one slice ahead), split by phase -------------------------------------
-    struct PreA { int len; int c[NC]; AVec<d4> Q, U; };             // in-list, own Q, acc init
-    struct PreB { int len; int c[NC]; AVec<d4> P; AVec<F> x; };      // out-list, own P, X row
-    auto prefetchA = [&](PreA &p, int slice) {
+    struct PreA0 { int len; int c[NC]; AVec<d4> Q, U; };            // in-list, own Q, acc init
+    struct PreB0 { int len; int c[NC]; AVec<d4> P; AVec<F> x; };     // out-list, own P, X row
+    struct PreX { int len; int c[NC]; AVec<F> x; };                  // FIRST: own values come from x
+    using PreA = std::conditional_t<FIRST, PreX, PreA0>;
+    using PreB = std::conditional_t<FIRST, PreX, PreB0>;
+    // Addresses are a wave-uniform base (slice-dependent, SGPRs) plus one of four per-lane byte
+    // offsets; nothing lane-dependent is 64 bits wide.
+    const unsigned lo_list = (unsigned)(q * SLICE + i16) * 4u;                 // packed list word
+    const unsigned lo_rec = (unsigned)(i16 * 2 * D + q * 2 * d4) * 4u;         // piece of a record
+    const unsigned lo_vec = (unsigned)(i16 * D + q * d4) * 4u;                 // piece of a D-row
+    const unsigned lo_x = (unsigned)(i16 * F) * 4u;                            // X row
+    auto prefetchA = [&](PreA &p, int slice_) {
+        const int slice = __builtin_amdgcn_readfirstlane(slice_);
         p.len = (__builtin_amdgcn_readfirstlane(in_off[slice + 1]) -
                  __builtin_amdgcn_readfirstlane(in_off[slice])) >> 4;
-        const int32_t *li = in_nbr16 + __builtin_amdgcn_readfirstlane(in_off16[slice]) + q * SLICE + i16;
-#define GNN_PF(C_) if (8 * C_ < p.len) a_load_i32<C_ * 4 * SLICE * 4>(p.c[C_], li);
+        const int32_t *li = in_nbr16 + __builtin_amdgcn_readfirstlane(in_off16[slice]);
+#define GNN_PF(C_) if (8 * C_ < p.len) a_load_i32_s<C_ * 4 * SLICE * 4>(p.c[C_], li, lo_list);
         GNN_PF(0) GNN_PF(1) GNN_PF(2)
 #undef GNN_PF
-        const int64_t n = (int64_t)slice * SLICE + i16;
-        p.Q.load(QS + n * 2 * D + q * 2 * d4);
-        p.U.load(U + n * D + q * d4);
+        const int64_t n0 = (int64_t)slice * SLICE;
+        if constexpr (FIRST) {
+            p.x.load_s(X + n0 * F, lo_x);
+        } else {
+            p.Q.load_s(QS + n0 * 2 * D, lo_rec);
+            p.U.load_s(U + n0 * D, lo_vec);
+        }
     };
-    auto prefetchB = [&](PreB &p, int slice) {
+    auto prefetchB = [&](PreB &p, int slice_) {
+        const int slice = __builtin_amdgcn_readfirstlane(slice_);
         p.len = (__builtin_amdgcn_readfirstlane(out_off[slice + 1]) -
                  __builtin_amdgcn_readfirstlane(out_off[slice])) >> 4;
-        const int32_t *lo = out_nbr16 + __builtin_amdgcn_readfirstlane(out_off16[slice]) + q * SLICE + i16;
-#define GNN_PF(C_) if (8 * C_ < p.len) a_load_i32<C_ * 4 * SLICE * 4>(p.c[C_], lo);
+        const int32_t *lo = out_nbr16 + __builtin_amdgcn_readfirstlane(out_off16[slice]);
+#define GNN_PF(C_) if (8 * C_ < p.len) a_load_i32_s<C_ * 4 * SLICE * 4>(p.c[C_], lo, lo_list);
         GNN_PF(0) GNN_PF(1) GNN_PF(2)
 #undef GNN_PF
         static_assert(NC == 3, "prefetch is written out for 3 words (24 steps)");
-        const int64_t n = (int64_t)slice * SLICE + i16;
-        p.P.load(PR + n * 2 * D + q * 2 * d4);
-        p.x.load(X + n * F);
+        const int64_t n0 = (int64_t)slice * SLICE;
+        if constexpr (!FIRST) p.P.load_s(PR + n0 * 2 * D, lo_rec);
+        p.x.load_s(X + n0 * F, lo_x);
     };
-    auto arriveA = [&](PreA &p) { a_wait_all(); a_fence(p.c); p.Q.fence(); p.U.fence(); };
-    auto arriveB = [&](PreB &p) { a_wait_all(); a_fence(p.c); p.P.fence(); p.x.fence(); };
+    auto arriveA = [&](PreA &p) {
+        a_wait_all();
+        a_fence(p.c);
+        if constexpr (FIRST) {
+            p.x.fence();
+        } else {
+            p.Q.fence();
+            p.U.fence();
+        }
+    };
+    auto arriveB = [&](PreB &p) {
+        a_wait_all();
+        a_fence(p.c);
+        if constexpr (!FIRST) p.P.fence();
+        p.x.fence();
+    };
 
     // Partial sums of the (at most MAXR) slices a wavefront owns in a tile stay in registers
     // across the phase barrier.  Round indices are wave-uniform, so a scalar switch selects
@@ -1001,9 +1210,16 @@ __global__ __launch_bounds__(1024) void k_iter2(
     Desc d = load_desc(tile);
     PreA a_cur, a_nxt;
     PreB b_cur, b_nxt;
-    stage_issue(PR + (int64_t)d.in_lo * 2 * D, bufA, d.in_cnt);
-    if (slice_a(d, 0) >= 0) prefetchA(a_cur, slice_a(d, 0));
-    stage_commit(bufA, PR + n_pad * 2 * D, d.in_cnt);
+    if constexpr (FIRST) {
+        xstage_issue(d.in_lo, d.in_cnt);
+        if (slice_a(d, 0) >= 0) prefetchA(a_cur, slice_a(d, 0));
+        compute_window(bufA, d.in_cnt, WinA{});   // barrier inside: table visible
+    } else {
+        stage_issue(PR + (int64_t)d.in_lo * 2 * D, bufA, d.in_cnt);
+        if (slice_a(d, 0) >= 0) prefetchA(a_cur, slice_a(d, 0));
+        __syncthreads();                               // weight table visible (put_null reads it)
+        stage_commit(bufA, d.in_cnt, WinA{});
+    }
     if (slice_a(d, 0) >= 0) arriveA(a_cur);
 
     float w2[d4];
@@ -1014,7 +1230,10 @@ __global__ __launch_bounds__(1024) void k_iter2(
         const float b2 = lds[L::o_b2];
         const int rounds = (d.s_end - d.s_begin + NWV - 1) / NWV;
         // ================= phase A: in-sweeps; QS window of this tile in flight ==================
-        stage_issue(QS + (int64_t)d.out_lo * 2 * D, bufB, d.out_cnt);
+        if constexpr (FIRST)
+            xstage_issue(d.out_lo, d.out_cnt);         // xbuf is free: last read before the barrier
+        else
+            stage_issue(QS + (int64_t)d.out_lo * 2 * D, bufB, d.out_cnt);
         // The last round is peeled (LR = true): it requests the first slice of phase B instead of
         // a next in-slice.  Written as one generic lambda so b_cur is DEFINED only there: a
         // conditional assignment inside the loop would keep it live across all rounds.
@@ -1029,13 +1248,26 @@ __global__ __launch_bounds__(1024) void k_iter2(
                 if (next >= 0) prefetchA(a_nxt, next);
             }
             float acc[d4];
-            const int64_t n = (int64_t)slice * SLICE + i16;
             if (slice >= 0) {
                 float Qn[d4];
-                a_cur.U.get(acc);
-                a_cur.Q.get(Qn);
+                if constexpr (FIRST) {                 // own Q and U from the hit's X row
+                    int woff = q * L::stride;
+                    asm volatile("" : "+v"(woff));
+                    const float *wl = lds + woff;
+                    float xo[F], h0[D];
+                    a_cur.x.get(xo);
+                    h0_of(wl, xo, h0);
+                    role_gemv<d4, D, F>(wl + L::o_m + 2 * L::m_st, h0, xo, Qn);
+                    if constexpr (XP)
+#pragma unroll
+                        for (int i = 0; i < d4; ++i) Qn[i] = __builtin_amdgcn_exp2f(Qn[i]);
+                    role_gemv<d4, D, F>(wl + L::o_m + 4 * L::m_st, h0, xo, acc);
+                } else {
+                    a_cur.U.get(acc);
+                    a_cur.Q.get(Qn);
+                }
                 const int len = __builtin_amdgcn_readfirstlane(a_cur.len);
-                sweep16<D, NC, XP, true>(a_cur.c, in_nbr16, in_off16, slice, i16, len, bufA, q, Qn, w2, b2, acc);
+                sweep16<D, NC, XP, !FIRST>(a_cur.c, in_nbr16, in_off16, slice, i16, len, bufA, q, Qn, w2, b2, acc);
             }
             if constexpr (!LR) {
                 if (next >= 0) {
@@ -1047,7 +1279,10 @@ __global__ __launch_bounds__(1024) void k_iter2(
         };
         for (int r = 0; r + 1 < rounds; ++r) roundA(r, std::false_type{});
         roundA(rounds - 1, std::true_type{});
-        stage_commit(bufB, QS + n_pad * 2 * D, d.out_cnt);   // also makes b_cur readable (vmcnt 0)
+        if constexpr (FIRST)
+            compute_window(bufB, d.out_cnt, WinB{});
+        else
+            stage_commit(bufB, d.out_cnt, WinB{});   // also makes b_cur readable (vmcnt 0)
         if (slice_a(d, 0) >= 0) arriveB(b_cur);
         __syncthreads();                               // bufB visible, bufA free
         // ================= phase B: out-sweeps, hit update, stores; next PR window in flight ======
@@ -1055,7 +1290,10 @@ __global__ __launch_bounds__(1024) void k_iter2(
         Desc dn = d;
         if (tnext < n_tiles) {
             dn = load_desc(tnext);
-            stage_issue(PR + (int64_t)dn.in_lo * 2 * D, bufA, dn.in_cnt);
+            if constexpr (FIRST)
+                xstage_issue(dn.in_lo, dn.in_cnt);
+            else
+                stage_issue(PR + (int64_t)dn.in_lo * 2 * D, bufA, dn.in_cnt);
         }
         auto roundB = [&](int r, auto lr) {
             constexpr bool LR = decltype(lr)::value;
@@ -1066,13 +1304,24 @@ __global__ __launch_bounds__(1024) void k_iter2(
             } else {
                 if (next >= 0) prefetchB(b_nxt, next);
             }
-            const int64_t n = (int64_t)slice * SLICE + i16;
             float xv[F], acc[d4];
             if (slice >= 0) {
                 float Pn[d4];
-                b_cur.P.get(Pn);
                 acc_get(r, acc);
                 b_cur.x.get(xv);
+                if constexpr (FIRST) {                 // own P from the hit's X row
+                    int woff = q * L::stride;
+                    asm volatile("" : "+v"(woff));
+                    const float *wl = lds + woff;
+                    float h0[D];
+                    h0_of(wl, xv, h0);
+                    role_gemv<d4, D, F>(wl + L::o_m + 0 * L::m_st, h0, xv, Pn);
+                    if constexpr (XP)
+#pragma unroll
+                        for (int i = 0; i < d4; ++i) Pn[i] = __builtin_amdgcn_exp2f(Pn[i]);
+                } else {
+                    b_cur.P.get(Pn);
+                }
                 const int len = __builtin_amdgcn_readfirstlane(b_cur.len);
                 sweep16<D, NC, XP, false>(b_cur.c, out_nbr16, out_off16, slice, i16, len, bufB, q, Pn, w2, b2, acc);
             }
@@ -1098,13 +1347,25 @@ __global__ __launch_bounds__(1024) void k_iter2(
 #pragma unroll
                 for (int i = 0; i < d4; ++i) hl[i] = tanh_f(hl[i]);
                 quad_allgather<d4>(hl, hn);
-emit_now<F, D, LAST, XP>(wl, hn, xv, n, q, PRn, QSn, U, Pc, Qc);
+                // stores: uniform row base + 32-bit lane offset (see lo_rec / lo_vec)
+                const int64_t n0 = (int64_t)__builtin_amdgcn_readfirstlane(slice) * SLICE;
+                auto at = [](float *base, unsigned off) {
+                    return reinterpret_cast<float *>(reinterpret_cast<char *>(base) + off);
+                };
+                if constexpr (LAST)
+                    emit_to<F, D, LAST, XP>(wl, hn, xv, at(Pc + n0 * D, lo_vec), at(Qc + n0 * D, lo_vec), nullptr);
+                else
+                    emit_to<F, D, LAST, XP>(wl, hn, xv, at(PRn + n0 * 2 * D, lo_rec), at(QSn + n0 * 2 * D, lo_rec),
+                                            at(U + n0 * D, lo_vec));
             }
         };
         for (int r = 0; r + 1 < rounds; ++r) roundB(r, std::false_type{});
         roundB(rounds - 1, std::true_type{});
         if (tnext >= n_tiles) break;
-        stage_commit(bufA, PR + n_pad * 2 * D, dn.in_cnt);   // also makes a_cur readable
+        if constexpr (FIRST)
+            compute_window(bufA, dn.in_cnt, WinA{});
+        else
+            stage_commit(bufA, dn.in_cnt, WinA{});   // also makes a_cur readable
         if (slice_a(dn, 0) >= 0) arriveA(a_cur);
         tile = tnext;
         d = dn;
@@ -1197,14 +1458,6 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
                    w.U, w.Pc, w.Qc, Np);
     float *PR = w.PRa, *PRn = w.PRb, *QS = w.QSa, *QSn = w.QSb;
     if (Np > 0) {
-        const int64_t g_need = (Np * 4 + 255) / 256;
-        const unsigned g = (unsigned)(g_need < 4096 ? g_need : 4096);   // 16 workgroups per CU, grid-stride
-        if (n_iters == 0)
-            GNN_LAUNCH("k_input4", (k_input4<F, D, true, XP>), g, 256, s, pl->X, *p, w.table, PR, QS,
-                       PRn, QSn, w.U, w.Pc, w.Qc, Np);
-        else
-            GNN_LAUNCH("k_input4", (k_input4<F, D, false, XP>), g, 256, s, pl->X, *p, w.table, PR, QS,
-                       PRn, QSn, w.U, w.Pc, w.Qc, Np);
         const int nt = (int)pl->n_tiles;
         const int tpx = (nt + 7) / 8;
         const size_t it_lds = (size_t)(L::total + (G::it_rec > 0 ? pl->iter_lds_records : 0) * 2 * D + 4) * sizeof(float);
@@ -1212,27 +1465,34 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
         if (!attr_done) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter<F, D, true, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter<F, D, false, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_edge<F, D, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
             attr_done = true;
         }
         const char *ab = getenv("GNN_ABLATE");   // timing diagnostics only (results invalid)
         const int ablate = ab ? atoi(ab) : 0;
         // persistent phase-split kernel when every tile runs in LDS mode and both windows fit LDS;
         // otherwise the general kernel
-        bool use2 = false;
-        size_t it2_lds = 0;
-        int capA = 0, grid2 = 0;
-        if constexpr (D <= 16) {
+        bool use2 = false, fuse_first = false;
+        size_t it2_lds = 0, it2_lds_first = 0;
+        int capA = 0, capB = 0, grid2 = 0;
+        if constexpr (G::iter2) {
             // window buffers in whole 1-KiB DMA pieces (= 128 / D records) plus one piece that
             // holds the NULL record and absorbs the last piece's overrun
             const int64_t rpp = 128 / D;                       // records per piece
             const int64_t capa = (pl->iter_lds_in + rpp - 1) / rpp * rpp + rpp;
             const int64_t capb = (pl->iter_lds_out + rpp - 1) / rpp * rpp + rpp;
-            use2 = G::iter2 && !getenv("GNN_NO_ITER2") && nt > 0 && pl->n_lds_tiles == nt &&
+            use2 = !getenv("GNN_NO_ITER2") && nt > 0 && pl->n_lds_tiles == nt &&
                    pl->in_nbr16 && pl->out_nbr16 && pl->in_off16 && pl->out_off16 && pl->sched_a && pl->sched_b;
             capA = (int)capa;
+            capB = (int)capb;
             it2_lds = (size_t)(L::total + (capa + capb) * 2 * D + 4) * sizeof(float);
             if (it2_lds > (size_t)G::lds_bytes) use2 = false;
+            // first iteration fused with the input network: + one buffer of X rows (256-byte pieces)
+            const int64_t xfl = ((capa > capb ? capa : capb) * F + 63) / 64 * 64;
+            it2_lds_first = it2_lds + (size_t)xfl * sizeof(float);
+            // (exp-product mode only: the plain-exp variant of the fused kernel does not fit the
+            // register budget without spills, and it is the rarely taken fallback anyway)
+            fuse_first = G::fuse_first && XP && use2 && n_iters >= 2 && it2_lds_first <= (size_t)G::lds_bytes &&
+                         !getenv("GNN_NO_FUSE_FIRST");
             static int n_cu = 0;
             if (!n_cu) {
                 int dev = 0;
@@ -1240,24 +1500,38 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
                 if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
                     n_cu = prop.multiProcessorCount;
                 if (n_cu <= 0) n_cu = 256;
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter2<F, D, true, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter2<F, D, false, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter2<F, D, true, XP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter2<F, D, false, XP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
+                if constexpr (XP && G::fuse_first)
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter2<F, D, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
             }
             grid2 = nt < n_cu ? nt : n_cu;
         }
+        if (!fuse_first) {
+            const int64_t g_need = (Np * 4 + 255) / 256;
+            const unsigned g = (unsigned)(g_need < 4096 ? g_need : 4096);   // 16 workgroups per CU, grid-stride
+            if (n_iters == 0)
+                GNN_LAUNCH("k_input4", (k_input4<F, D, true, XP>), g, 256, s, pl->X, *p, w.table, PR, QS,
+                           PRn, QSn, w.U, w.Pc, w.Qc, Np);
+            else
+                GNN_LAUNCH("k_input4", (k_input4<F, D, false, XP>), g, 256, s, pl->X, *p, w.table, PR, QS,
+                           PRn, QSn, w.U, w.Pc, w.Qc, Np);
+        }
         for (int t = 0; t < n_iters; ++t) {
-            if constexpr (D <= 16) {
+            if constexpr (G::iter2) {
                 if (use2) {
-                    if (t + 1 == n_iters)
-                        GNN_LAUNCH_SH("k_iter2", (k_iter2<F, D, true, XP>), grid2, 1024, it2_lds, s, pl->X, w.table,
-                                      pl->tiles, pl->in_off, pl->in_off16, pl->in_nbr16, pl->out_off,
-                                      pl->out_off16, pl->out_nbr16, pl->sched_a, pl->sched_b, PR, QS,
-                                      w.U, PRn, QSn, w.Pc, w.Qc, Np, nt, capA);
+#define GNN_IT2(LAST_, FIRST_, LDS_)                                                                   \
+    GNN_LAUNCH_SH("k_iter2", (k_iter2<F, D, LAST_, XP, FIRST_>), grid2, 1024, LDS_, s, pl->X, w.table, *p, \
+                  w.table, pl->tiles, pl->in_off, pl->in_off16, pl->in_nbr16, pl->out_off,             \
+                  pl->out_off16, pl->out_nbr16, pl->sched_a, pl->sched_b, PR, QS, w.U, PRn, QSn, w.Pc,  \
+                  w.Qc, Np, nt, capA, capB)
+                    if (XP && t == 0 && fuse_first) {
+                        if constexpr (XP && G::fuse_first) GNN_IT2(false, true, it2_lds_first);
+                    } else if (t + 1 == n_iters)
+                        GNN_IT2(true, false, it2_lds);
                     else
-                        GNN_LAUNCH_SH("k_iter2", (k_iter2<F, D, false, XP>), grid2, 1024, it2_lds, s, pl->X, w.table,
-                                      pl->tiles, pl->in_off, pl->in_off16, pl->in_nbr16, pl->out_off,
-                                      pl->out_off16, pl->out_nbr16, pl->sched_a, pl->sched_b, PR, QS,
-                                      w.U, PRn, QSn, w.Pc, w.Qc, Np, nt, capA);
+                        GNN_IT2(false, false, it2_lds);
+#undef GNN_IT2
                     float *t1 = PR; PR = PRn; PRn = t1;
                     float *t2 = QS; QS = QSn; QSn = t2;
                     continue;
@@ -1290,9 +1564,19 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
     return 0;
 }
 
+#ifdef GNN_QUICK      // compile-time experiments: one shape only
+#ifndef GNN_QUICK_F
+#define GNN_QUICK_F 3
+#endif
+#ifndef GNN_QUICK_D
+#define GNN_QUICK_D 8
+#endif
+#define SELL_FOR_EACH_SHAPE(X_) X_(GNN_QUICK_F, GNN_QUICK_D)
+#else
 #define SELL_FOR_EACH_SHAPE(X_)                                                          \
     X_(2, 4) X_(2, 8) X_(2, 16) X_(2, 32) X_(3, 4) X_(3, 8) X_(3, 16) X_(3, 32) X_(3, 64) \
     X_(11, 4) X_(11, 8) X_(11, 16)
+#endif
 
 }  // namespace
 

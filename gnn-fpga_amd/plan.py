@@ -291,6 +291,8 @@ class SellPlan:
 
         # -- final edge pass: chunks of the caller's segment order --------------------------
         CH = int(limits["chunk_segments"])
+        if E < 512 * CH:          # small batches: more, smaller chunks (same reasoning as the tiles)
+            CH = min(CH, max(1024, (E + 511) // 512))
         cb = _chunk_bounds(np.where(ok, gid[np.where(ok, src, 0)] * (int(level.max(initial=0)) + 1)
                                     + level[np.where(ok, src, 0)], -1), ok, E, CH)
         n_chunks = len(cb) - 1
@@ -328,7 +330,8 @@ class SellPlan:
         self.tile_hits_max = int(tpad.max(initial=0))
         self.max_list_steps = int(max(np.diff(in_off).max(initial=0), np.diff(out_off).max(initial=0))) // SLICE
 
-        Xp = np.zeros((n_pad + 1, X.shape[1]), dtype=np.float32)
+        # + 64 zero rows: the first-iteration kernel DMAs X windows in whole 256-byte pieces
+        Xp = np.zeros((n_pad + 1 + 64, X.shape[1]), dtype=np.float32)
         Xp[new_of_rank] = X[old_of_rank]
         t = torch.from_numpy
         self.X = t(Xp)

@@ -83,7 +83,8 @@ typedef struct gnn_grads {
  *   tile  descriptor, 8 ints: slice_begin, slice_end, in_lo, in_cnt, out_lo, out_cnt, mode, sched_base
  *   chunk descriptor, 8 ints: seg_begin, seg_end, src_lo, src_cnt, dst_lo, dst_cnt, mode, 0 */
 typedef struct gnn_plan {
-    const float *X;                      /* [n_pad+1, F] renumbered features, dummy/NULL rows zero */
+    const float *X;                      /* [n_pad+1+64, F] renumbered features; dummy, NULL and the 64
+                                            tail rows (window DMA overrun) are zero */
     const int32_t *src, *dst;            /* [n_segments] endpoints (window-relative or absolute)   */
     const int32_t *in_off, *in_nbr;      /* [n_pad/16+1], [in_off[last]]  segments ending at a hit -> start hit */
     const int32_t *out_off, *out_nbr;    /* [n_pad/16+1], [out_off[last]] segments starting at a hit -> end hit */

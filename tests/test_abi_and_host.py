@@ -157,7 +157,7 @@ def test_pipelined_kernels_never_spill():
     seen = 0
     for b in blocks:
         name = subprocess.run(["c++filt", b.split()[0]], capture_output=True, text=True).stdout
-        m = re.search(r"(k_iter2?)<(\d+), (\d+), (true|false), (true|false)>", name)
+        m = re.search(r"(k_iter2?)<(\d+), (\d+), (true|false), (true|false)(, (true|false))?>", name)
         if not m:
             continue
         F, D = int(m.group(2)), int(m.group(3))
@@ -171,4 +171,4 @@ def test_pipelined_kernels_never_spill():
             seen += 1
             assert agprs == 0, "%s<%d,%d> is pipelined but parks values in AGPRs" % (m.group(1), F, D)
             assert scratch == 0, "%s<%d,%d> is pipelined but spills %d bytes" % (m.group(1), F, D, scratch)
-    assert seen >= 32
+    assert seen >= 20 + 19          # k_iter: 5 shapes x 4 variants; k_iter2: 4 shapes x 4 + 3 fused-first
