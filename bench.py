@@ -155,6 +155,10 @@ def main():
         tot = {k: sum(v) for k, v in per.items()}
         dom = max(tot, key=tot.get)
         avg_ms = {k: sum(v) / len(v) for k, v in per.items()}
+        # the same, by position in the launch sequence of one step (first / middle / last iteration)
+        lps = len(prof.records) // args.steps
+        seq_ms = [[prof.records[i][0], round(sum(prof.records[j][1] for j in range(i, len(prof.records), lps))
+                                             / args.steps, 4)] for i in range(lps)] if lps else []
         n_tot, e_tot = batch.n_hits, batch.n_segments
         ab = algorithmic_bytes(n_tot, e_tot)
         achieved = ab[dom] / (avg_ms[dom] * 1e-3) / 1e9
@@ -193,6 +197,7 @@ def main():
                          "avg_launch_ms": avg_ms[dom],
                          "kernel_ms": {k: round(v, 4) for k, v in avg_ms.items()},
                          "launches_per_step": {k: len(v) // args.steps for k, v in per.items()},
+                         "launch_sequence_ms": seq_ms,
                          "forward_algorithmic_GBps": ab["forward"] / (ms_step * 1e-3) / 1e9,
                          "forward_frac": ab["forward"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }

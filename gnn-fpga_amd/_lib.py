@@ -61,6 +61,9 @@ SIGNATURES = {
     "gnn_forward_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
     "gnn_segclf_forward": (ctypes.c_int, [ctypes.POINTER(GnnGraph), ctypes.POINTER(GnnParams),
                                           _i32, _f, _f, _f, _f, _sz, _f]),
+    "gnn_events_supported": (ctypes.c_int, [_i32, _i32, _i64, _i64]),
+    "gnn_segclf_forward_events": (ctypes.c_int, [ctypes.POINTER(GnnGraph), ctypes.POINTER(GnnParams),
+                                                 _f, _f, _i64, _i32, _i32, _i32, _f, _f]),
     "gnn_segclf_forward_train": (ctypes.c_int, [ctypes.POINTER(GnnGraph),
                                                 ctypes.POINTER(GnnParams), _i32, _f, _f, _f, _sz, _f]),
     "gnn_backward_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
@@ -233,6 +236,29 @@ def segclf_forward(batch, weights, F, D, n_iters, out=None, workspace=None, trac
                                      Ht.data_ptr() if trace else None,
                                      workspace.data_ptr(), workspace.numel(), _stream()))
     return (out, et, Ht) if trace else out
+
+
+def events_supported(F, D, max_hits, max_segments):
+    """True if graphs of at most that size fit the one-workgroup-per-graph kernel."""
+    return bool(load().gnn_events_supported(F, D, max_hits, max_segments))
+
+
+def segclf_forward_events(batch, layout, weights, F, D, n_iters, out=None, params=None):
+    """Whole forward in one launch, one workgroup per graph (small events); `layout` is
+    `batch.event_layout()`.  Returns scores [n_segments], bit-identical to segclf_forward."""
+    dev = batch.X.device
+    if out is None:
+        out = torch.empty(batch.n_segments, dtype=torch.float32, device=dev)
+    g = getattr(batch, "_gstruct", None)
+    if g is None or batch._gstruct_dev != dev:     # device pointers are stable while the batch lives
+        g = batch._gstruct = graph_struct(batch)
+        batch._gstruct_dev = dev
+    p = params if params is not None else params_struct(weights, F, D)
+    _check(load().gnn_segclf_forward_events(
+        ctypes.byref(g), ctypes.byref(p), _dev(layout.hit_ptr, torch.int32, "hit_ptr"),
+        _dev(layout.seg_ptr, torch.int32, "seg_ptr"), batch.n_graphs, layout.max_hits,
+        layout.max_segments, n_iters, _dev(out, torch.float32, "out"), _stream()))
+    return out
 
 
 def segclf_forward_train(batch, weights, F, D, n_iters):

@@ -267,6 +267,292 @@ __global__ __launch_bounds__(kBlock) void k_node(
     if (PQ) store_pq<F, D>(hn, W1, b1, PQ + n * 2 * D);
 }
 
+// ---------------------------------------------------------------------------------------------
+// small events: the WHOLE forward of one graph in one workgroup, one launch for the batch
+// ---------------------------------------------------------------------------------------------
+// The per-module kernels above cost one launch per pass (2T + 2 launches, ~5 us each on the
+// stream): for the reference's muon graphs (tens of hits, gnn/prepareMuonGraphs.py) that is all
+// of the time.  Here a workgroup owns one graph of the block-diagonal batch: H (two buffers),
+// the P/Q rows and the edge scores live in LDS for all T iterations, hits and segments are dealt
+// to the lanes, a barrier separates the passes.  Same arithmetic, in the same order, as
+// k_input / k_edge / k_node (the parity tests compare them bit for bit).
+// Requires every segment of graph i to join hits of graph i and to lie in
+// [seg_ptr[i], seg_ptr[i+1]) (HitGraphBatch.event_layout checks this on the host).
+// sizes / LDS offsets (floats, 16-byte aligned) of the ten weight tensors in state_dict order
+template <int F, int D>
+struct EvWeights {
+    static constexpr int C = F + D;
+    static constexpr int size(int a)
+    {
+        return a == 0 ? D * F : a == 2 ? D * 2 * C : a == 5 ? 1 : a == 6 ? D * 3 * C : a == 8 ? D * D : D;
+    }
+    static constexpr int off(int a)
+    {
+        int o = 0;
+        for (int i = 0; i < a; ++i) o += (size(i) + 3) & ~3;
+        return o;
+    }
+    static constexpr int total = off(10);
+};
+
+struct EvW {
+    const float *__restrict__ Win, *__restrict__ bin, *__restrict__ W1, *__restrict__ b1,
+        *__restrict__ W2, *__restrict__ b2, *__restrict__ W3, *__restrict__ b3, *__restrict__ W4,
+        *__restrict__ b4;
+};
+
+template <int F, int D>
+__global__ __launch_bounds__(256) void k_event(
+    gnn_graph_t g, const float *__restrict__ Win, const float *__restrict__ bin,
+    const float *__restrict__ W1, const float *__restrict__ b1, const float *__restrict__ W2,
+    const float *__restrict__ b2, const float *__restrict__ W3, const float *__restrict__ b3,
+    const float *__restrict__ W4, const float *__restrict__ b4,
+    const int32_t *__restrict__ hit_ptr, const int32_t *__restrict__ seg_ptr, int n_iters,
+    float *__restrict__ e_out, int cap_hits, int cap_segments)
+{
+    constexpr int C = Shape<F, D>::C;
+    constexpr int LDH = Shape<F, D>::LDH;
+    constexpr int NT = 256, NWV = 4;
+    constexpr int RW = D / NWV;          // output rows of a D-row layer per wavefront
+    constexpr int RP = 2 * D / NWV;      // rows of the stacked [P; Q] per wavefront
+    static_assert(D % NWV == 0, "rows are dealt to 4 wavefronts");
+    extern __shared__ __attribute__((aligned(16))) float ev_lds[];
+    float *H = ev_lds, *Hn = H + cap_hits * LDH, *PQ = Hn + cap_hits * LDH,
+          *qb = PQ + cap_hits * 2 * D, *es = qb + cap_hits * D;
+    const int h0 = hit_ptr[blockIdx.x], nh = hit_ptr[blockIdx.x + 1] - h0;
+    const int s0 = seg_ptr[blockIdx.x], ns = seg_ptr[blockIdx.x + 1] - s0;
+    const float *__restrict__ X = g.X;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // The weights (953 floats at F = 11, D = 8) are copied to LDS once and read from there with
+    // broadcast ds_reads: a graph is a handful of wavefronts, nothing hides scalar-load latency
+    // (measured 38 us per launch on the s_load path).  A hit is a lane; the output rows of every
+    // layer are dealt to the 4 wavefronts (each loads a quarter of the weights and runs a quarter
+    // of the FMAs), layers meet through LDS.  Per row the arithmetic and its order are those of
+    // k_input / k_node, so the scores are bit-identical to the per-module kernels.
+    using W = EvWeights<F, D>;
+    float *wl = es + ((cap_segments + 3) & ~3);
+    {
+        const float *srcs[10] = {Win, bin, W1, b1, W2, b2, W3, b3, W4, b4};
+#pragma unroll
+        for (int a = 0; a < 10; ++a)
+            for (int i = threadIdx.x; i < W::size(a); i += NT) wl[W::off(a) + i] = srcs[a][i];
+    }
+    const EvW p = {wl + W::off(0), wl + W::off(1), wl + W::off(2), wl + W::off(3), wl + W::off(4),
+                   wl + W::off(5), wl + W::off(6), wl + W::off(7), wl + W::off(8), wl + W::off(9)};
+    // The graph's index arrays too, as LOCAL ids: the pull loops below chase eid -> score and
+    // nbr -> feature row per list entry, and from global memory every hop is a dependent
+    // round trip (measured: 2/3 of the launch).  One coalesced pass here instead.
+    int32_t *ip = reinterpret_cast<int32_t *>(wl + W::total), *op = ip + cap_hits + 1,
+            *ie = op + cap_hits + 1, *inb = ie + cap_segments, *oe = inb + cap_segments,
+            *onb = oe + cap_segments, *sl = onb + cap_segments, *dl = sl + cap_segments;
+    if (nh > 0) {
+        const int ib = g.in_ptr[h0], ob = g.out_ptr[h0];
+        for (int n = threadIdx.x; n <= nh; n += NT) {
+            ip[n] = g.in_ptr[h0 + n] - ib;
+            op[n] = g.out_ptr[h0 + n] - ob;
+        }
+        const int ni = g.in_ptr[h0 + nh] - ib, no = g.out_ptr[h0 + nh] - ob;
+        for (int k = threadIdx.x; k < ni; k += NT) {
+            ie[k] = g.in_eid[ib + k] - s0;
+            inb[k] = g.in_nbr[ib + k] - h0;
+        }
+        for (int k = threadIdx.x; k < no; k += NT) {
+            oe[k] = g.out_eid[ob + k] - s0;
+            onb[k] = g.out_nbr[ob + k] - h0;
+        }
+    }
+    {
+        for (int j = threadIdx.x; j < ns; j += NT) {
+            const int sg = g.src[s0 + j];
+            sl[j] = sg < 0 ? -1 : sg - h0;
+            dl[j] = sg < 0 ? -1 : g.dst[s0 + j] - h0;
+        }
+    }
+    __syncthreads();
+
+    // rows [wv*RP, (wv+1)*RP) of [P; Q] for every hit, from the full feature rows in `Hsrc`
+    auto pq_rows = [&](const float *Hsrc) {
+        for (int n = lane; n < nh; n += 64) {
+            float h[C];
+#pragma unroll
+            for (int k = 0; k < C; ++k) h[k] = Hsrc[n * LDH + k];
+#pragma unroll
+            for (int r = 0; r < RP; ++r) {
+                const int row = wv * RP + r, d = row % D;
+                const bool isq = row >= D;                   // wave-uniform
+                float acc = isq ? 0.0f : p.b1[d];
+#pragma unroll
+                for (int k = 0; k < C; ++k) acc = fmaf(p.W1[d * 2 * C + (isq ? C : 0) + k], h[k], acc);
+                PQ[n * 2 * D + row] = acc;
+            }
+        }
+    };
+
+    // input network + skip concat (k_input): rows of tanh(Win x + bin) per wavefront
+    for (int n = lane; n < nh; n += 64) {
+        float x[F];
+#pragma unroll
+        for (int k = 0; k < F; ++k) x[k] = X[(int64_t)(h0 + n) * F + k];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int d = wv * RW + r;
+            float acc = p.bin[d];
+#pragma unroll
+            for (int k = 0; k < F; ++k) acc = fmaf(p.Win[d * F + k], x[k], acc);
+            H[n * LDH + d] = tanh_f(acc);
+        }
+        if (wv == 0) {
+#pragma unroll
+            for (int k = 0; k < F; ++k) H[n * LDH + D + k] = x[k];
+#pragma unroll
+            for (int k = C; k < LDH; ++k) H[n * LDH + k] = 0.0f;
+        }
+    }
+    __syncthreads();
+    pq_rows(H);
+    __syncthreads();
+
+    for (int t = 0;; ++t) {
+        const bool last = (t == n_iters);
+        // edge pass (k_edge): one segment per lane of the workgroup
+        for (int j = threadIdx.x; j < ns; j += NT) {
+            const int s = sl[j], d = dl[j];
+            float z[D];
+            if (s >= 0) {
+                const float4 *pp = reinterpret_cast<const float4 *>(PQ + s * 2 * D);
+                const float4 *qq = reinterpret_cast<const float4 *>(PQ + d * 2 * D + D);
+#pragma unroll
+                for (int v = 0; v < D / 4; ++v) {
+                    const float4 a = pp[v], b = qq[v];
+                    z[4 * v] = a.x + b.x;
+                    z[4 * v + 1] = a.y + b.y;
+                    z[4 * v + 2] = a.z + b.z;
+                    z[4 * v + 3] = a.w + b.w;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < D; ++k) z[k] = p.b1[k];
+            }
+            float acc = p.b2[0];
+#pragma unroll
+            for (int k = 0; k < D; ++k) acc = fmaf(p.W2[k], tanh_f(z[k]), acc);
+            const float e = sigmoid_f(acc);
+            if (last)
+                e_out[s0 + j] = e;
+            else
+                es[j] = e;
+        }
+        if (last) break;
+        __syncthreads();
+        // node pass (k_node).  Every wavefront pulls the segment sums (cheap), then computes its
+        // rows of the first MLP layer.
+        for (int n = lane; n < nh; n += 64) {
+            float M[3 * LDH];
+#pragma unroll
+            for (int k = 0; k < 2 * LDH; ++k) M[k] = 0.0f;
+            {
+                const float4 *hp = reinterpret_cast<const float4 *>(H + n * LDH);
+#pragma unroll
+                for (int v = 0; v < LDH / 4; ++v) {
+                    const float4 a = hp[v];
+                    M[2 * LDH + 4 * v] = a.x;
+                    M[2 * LDH + 4 * v + 1] = a.y;
+                    M[2 * LDH + 4 * v + 2] = a.z;
+                    M[2 * LDH + 4 * v + 3] = a.w;
+                }
+            }
+            for (int k = ip[n], k1 = ip[n + 1]; k < k1; ++k) {
+                const float w = es[ie[k]];
+                const float4 *hp = reinterpret_cast<const float4 *>(H + inb[k] * LDH);
+#pragma unroll
+                for (int v = 0; v < LDH / 4; ++v) {
+                    const float4 a = hp[v];
+                    M[4 * v] = fmaf(w, a.x, M[4 * v]);
+                    M[4 * v + 1] = fmaf(w, a.y, M[4 * v + 1]);
+                    M[4 * v + 2] = fmaf(w, a.z, M[4 * v + 2]);
+                    M[4 * v + 3] = fmaf(w, a.w, M[4 * v + 3]);
+                }
+            }
+            for (int k = op[n], k1 = op[n + 1]; k < k1; ++k) {
+                const float w = es[oe[k]];
+                const float4 *hp = reinterpret_cast<const float4 *>(H + onb[k] * LDH);
+#pragma unroll
+                for (int v = 0; v < LDH / 4; ++v) {
+                    const float4 a = hp[v];
+                    M[LDH + 4 * v] = fmaf(w, a.x, M[LDH + 4 * v]);
+                    M[LDH + 4 * v + 1] = fmaf(w, a.y, M[LDH + 4 * v + 1]);
+                    M[LDH + 4 * v + 2] = fmaf(w, a.z, M[LDH + 4 * v + 2]);
+                    M[LDH + 4 * v + 3] = fmaf(w, a.w, M[LDH + 4 * v + 3]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const int d = wv * RW + r;
+                float acc = p.b3[d];
+#pragma unroll
+                for (int k = 0; k < C; ++k) acc = fmaf(p.W3[d * 3 * C + k], M[k], acc);
+#pragma unroll
+                for (int k = 0; k < C; ++k) acc = fmaf(p.W3[d * 3 * C + C + k], M[LDH + k], acc);
+#pragma unroll
+                for (int k = 0; k < C; ++k) acc = fmaf(p.W3[d * 3 * C + 2 * C + k], M[2 * LDH + k], acc);
+                qb[n * D + d] = tanh_f(acc);
+            }
+            if (wv == 0) {                                   // skip concat of X (model.py:154)
+#pragma unroll
+                for (int k = D; k < LDH; ++k) Hn[n * LDH + k] = M[2 * LDH + k];
+            }
+        }
+        __syncthreads();
+        for (int n = lane; n < nh; n += 64) {                // second layer: rows per wavefront
+            float q[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) q[k] = qb[n * D + k];
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const int d = wv * RW + r;
+                float acc = p.b4[d];
+#pragma unroll
+                for (int k = 0; k < D; ++k) acc = fmaf(p.W4[d * D + k], q[k], acc);
+                Hn[n * LDH + d] = tanh_f(acc);
+            }
+        }
+        __syncthreads();
+        pq_rows(Hn);                                         // nobody reads PQ or H in this step
+        __syncthreads();
+        float *tmp = H; H = Hn; Hn = tmp;
+    }
+}
+
+constexpr size_t kEventLdsMax = 128 * 1024;     // of the CU's 160 KB
+
+inline size_t event_lds_bytes(int F, int D, int64_t cap_hits, int64_t cap_segments)
+{
+    const int ldh = (F + D + 3) & ~3, C = F + D;
+    auto a4 = [](int x) { return (x + 3) & ~3; };
+    const int wfl = a4(D * F) + a4(D * 2 * C) + a4(1) + a4(D * 3 * C) + a4(D * D) + 5 * a4(D);   // EvWeights::total
+    return (size_t)(cap_hits * (2 * ldh + 3 * D) + ((cap_segments + 3) & ~3) + wfl +
+                    2 * (cap_hits + 1) + 6 * cap_segments) * sizeof(float);
+}
+
+template <int F, int D>
+int run_events(const gnn_graph_t *g, const gnn_params_t *p, const int32_t *hit_ptr,
+               const int32_t *seg_ptr, int64_t n_graphs, int cap_hits, int cap_segments,
+               int n_iters, float *e_out, hipStream_t s)
+{
+    if (n_graphs <= 0) return 0;
+    const size_t lds = event_lds_bytes(F, D, cap_hits, cap_segments);
+    static bool attr_done = false;     // dynamic LDS above 64 KB must be opted into, once
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_event<F, D>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEventLdsMax);
+        attr_done = true;
+    }
+    GNN_LAUNCH_SH("k_event", (k_event<F, D>), (unsigned)n_graphs, 256, lds, s, *g, p->Win, p->bin, p->W1,
+                  p->b1, p->W2, p->b2, p->W3, p->b3, p->W4, p->b4, hit_ptr, seg_ptr, n_iters, e_out,
+                  cap_hits, cap_segments);
+    return 0;
+}
+
 // bound of |P'|, |Q'| over all hits given |H'| <= 1 and per-feature max |X| (one wavefront)
 __global__ __launch_bounds__(64) void k_exp_bound(const float *__restrict__ W1,
                                                  const float *__restrict__ b1,
@@ -427,6 +713,31 @@ int gnn_shape_supported(int32_t F, int32_t D)
 int32_t gnn_h_stride(int32_t F, int32_t D)
 {
     return gnn_shape_supported(F, D) ? ((F + D + 3) & ~3) : 0;
+}
+
+int gnn_events_supported(int32_t F, int32_t D, int64_t max_hits, int64_t max_segments)
+{
+    if (!gnn_shape_supported(F, D) || max_hits < 0 || max_segments < 0) return 0;
+    return event_lds_bytes(F, D, max_hits, max_segments) <= kEventLdsMax;
+}
+
+int gnn_segclf_forward_events(const gnn_graph_t *g, const gnn_params_t *p, const int32_t *hit_ptr,
+                              const int32_t *seg_ptr, int64_t n_graphs, int32_t max_hits,
+                              int32_t max_segments, int32_t n_iters, float *e_out, void *stream)
+{
+    if (!g || !p || n_iters < 0 || n_graphs < 0 || max_hits < 0 || max_segments < 0)
+        return fail(GNN_ERR_BADARG, "gnn_segclf_forward_events: bad argument");
+    if (n_graphs > 0 && (!hit_ptr || !seg_ptr)) return fail(GNN_ERR_BADARG, "gnn_segclf_forward_events: graph offsets missing");
+    if (g->n_segments > 0 && (!e_out || !g->src || !g->dst)) return fail(GNN_ERR_BADARG, "gnn_segclf_forward_events: segment arrays missing");
+    if (g->n_hits > 0 && (!g->X || !g->in_ptr || !g->out_ptr)) return fail(GNN_ERR_BADARG, "gnn_segclf_forward_events: hit arrays missing");
+    if (!gnn_events_supported(p->F, p->D, max_hits, max_segments))
+        return fail(GNN_ERR_UNSUPPORTED, "events of up to %d hits / %d segments do not fit one workgroup's LDS at input_dim=%d hidden_dim=%d",
+                    max_hits, max_segments, p->F, p->D);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define X_(F_, D_) if (p->F == F_ && p->D == D_) return run_events<F_, D_>(g, p, hit_ptr, seg_ptr, n_graphs, max_hits, max_segments, n_iters, e_out, s);
+    GNN_FOR_EACH_SHAPE(X_)
+#undef X_
+    return fail(GNN_ERR_UNSUPPORTED, "no kernel for input_dim=%d hidden_dim=%d", p->F, p->D);
 }
 
 int gnn_input_fwd(const float *X, const float *Win, const float *bin, float *H, int64_t n_hits,

@@ -348,6 +348,30 @@ __device__ __forceinline__ void role_gemv(const float *w, const float *hn, const
     }
 }
 
+// role_gemv for two rows per lane, whole block requested from LDS up front and consumed by packed
+// FMAs (same order, same bits).  For code where every wave of the workgroup runs the same gemv
+// at the same time (nothing else to hide the LDS latency behind); costs 4 * ceil(NW / 4) registers.
+template <int KD, int KF>
+__device__ __forceinline__ void role_gemv_burst(const float *w, const float *hn, const float *x,
+                                                float *out)
+{
+    constexpr int NW = 2 + (KD + KF) * 2, NV = (NW + 3) / 4;   // last vector may be half padding
+    const f4_t *wv = reinterpret_cast<const f4_t *>(__builtin_assume_aligned(w, 16));
+    f4_t t[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) t[v] = wv[v];
+    f2_t acc = {t[0].x, t[0].y};                    // bias
+#pragma unroll
+    for (int j = 1; j < NW / 2; ++j) {              // pair j holds W[k][0..1], k = j - 1
+        const int k = j - 1;
+        const float in = k < KD ? hn[k < KD ? k : 0] : x[k >= KD ? k - KD : 0];
+        const f2_t wk = (j & 1) ? f2_t{t[j / 2].z, t[j / 2].w} : f2_t{t[j / 2].x, t[j / 2].y};
+        acc = wk * f2_t{in, in} + acc;
+    }
+    out[0] = acc.x;
+    out[1] = acc.y;
+}
+
 // This lane's chunk of the records the next pass gathers, computed from the new hit features
 // [hn (D) | x (F)]: PR = [P | R], QS = [Q | S], U; for the last iteration compact P and Q only.
 template <int F, int D, bool LAST, bool XP>
@@ -830,6 +854,12 @@ __device__ __forceinline__ void sweep16(int (&c)[NC], const int32_t *__restrict_
     }
 }
 
+#ifndef GNN_PIPE_A
+#define GNN_PIPE_A (!FIRST)
+#endif
+#ifndef GNN_PIPE_B
+#define GNN_PIPE_B false
+#endif
 // one message-passing iteration for one tile: edge scores + weighted aggregation + hit update
 // (+ records for the next pass).  One workgroup per tile; each wavefront takes 16-hit slices.
 template <int F, int D, bool LAST, bool XP>
@@ -1113,11 +1143,16 @@ __global__ __launch_bounds__(1024) void k_iter2(
 #pragma unroll
             for (int k = 0; k < F; ++k) x[k] = xbuf[h * F + k];
             h0_of(wl, x, hn);
-            role_gemv<d4, D, F>(wl + L::o_m + (2 * M) * L::m_st, hn, x, rec);
+            if constexpr (d4 == 2) {
+                role_gemv_burst<D, F>(wl + L::o_m + (2 * M) * L::m_st, hn, x, rec);
+                role_gemv_burst<D, F>(wl + L::o_m + (2 * M + 1) * L::m_st, hn, x, rec + d4);
+            } else {
+                role_gemv<d4, D, F>(wl + L::o_m + (2 * M) * L::m_st, hn, x, rec);
+                role_gemv<d4, D, F>(wl + L::o_m + (2 * M + 1) * L::m_st, hn, x, rec + d4);
+            }
             if constexpr (XP)
 #pragma unroll
                 for (int i = 0; i < d4; ++i) rec[i] = __builtin_amdgcn_exp2f(rec[i]);
-            role_gemv<d4, D, F>(wl + L::o_m + (2 * M + 1) * L::m_st, hn, x, rec + d4);
             store_vec<2 * d4>(buf + h * 2 * D + q * 2 * d4, rec);
         }
         put_null(buf, cnt, which);
@@ -1267,7 +1302,7 @@ __global__ __launch_bounds__(1024) void k_iter2(
                     a_cur.Q.get(Qn);
                 }
                 const int len = __builtin_amdgcn_readfirstlane(a_cur.len);
-                sweep16<D, NC, XP, !FIRST>(a_cur.c, in_nbr16, in_off16, slice, i16, len, bufA, q, Qn, w2, b2, acc);
+                sweep16<D, NC, XP, GNN_PIPE_A>(a_cur.c, in_nbr16, in_off16, slice, i16, len, bufA, q, Qn, w2, b2, acc);
             }
             if constexpr (!LR) {
                 if (next >= 0) {
@@ -1323,7 +1358,7 @@ __global__ __launch_bounds__(1024) void k_iter2(
                     b_cur.P.get(Pn);
                 }
                 const int len = __builtin_amdgcn_readfirstlane(b_cur.len);
-                sweep16<D, NC, XP, false>(b_cur.c, out_nbr16, out_off16, slice, i16, len, bufB, q, Pn, w2, b2, acc);
+                sweep16<D, NC, XP, GNN_PIPE_B>(b_cur.c, out_nbr16, out_off16, slice, i16, len, bufB, q, Pn, w2, b2, acc);
             }
             // the next slice's registers arrive here (in flight during the sweep); doing it before
             // the hit update keeps the two register sets from overlapping with the MLP's

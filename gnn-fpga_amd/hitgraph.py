@@ -39,6 +39,12 @@ def _csr_by(key, other, n_hits):
     return ptr.astype(_I32), eid, other[eid].astype(_I32)
 
 
+class _EventLayout:
+    """hit_ptr / seg_ptr [G+1] int32 tensors, max_hits, max_segments (HitGraphBatch.event_layout)."""
+    hit_ptr = seg_ptr = None
+    max_hits = max_segments = 0
+
+
 class HitGraphBatch:
     """A block-diagonal batch of hit graphs in index form (see module docstring)."""
 
@@ -90,6 +96,37 @@ class HitGraphBatch:
             self.plan.hidden_dim = hidden_dim
             self.plan.to(self.X.device)
         return self.plan
+
+    def event_layout(self):
+        """Per-graph layout for the one-workgroup-per-graph kernel (`_lib.segclf_forward_events`):
+        device copies of hit_ptr / seg_ptr and the largest graph's size, or None when the batch is
+        not block-diagonal in the sense that kernel needs (every segment of graph i inside
+        [seg_ptr[i], seg_ptr[i+1]) joins two hits of graph i; padded segments are fine).
+        Checked once, on the host."""
+        if getattr(self, "_event", None) is None:
+            hp, sp = self.hit_ptr, self.seg_ptr
+            ok = (hp[0] == 0 and sp[0] == 0 and hp[-1] == self.n_hits and
+                  sp[-1] == self.n_segments and np.all(np.diff(hp) >= 0) and np.all(np.diff(sp) >= 0)
+                  and self.n_hits < 2 ** 31 and self.n_segments < 2 ** 31)
+            if ok and self.n_segments:
+                src, dst = self.src.cpu().numpy(), self.dst.cpu().numpy()
+                gseg = np.repeat(np.arange(self.n_graphs), np.diff(sp))
+                lo, hi = hp[:-1][gseg], hp[1:][gseg]
+                pad = src < 0
+                ok = bool(np.all(pad | ((src >= lo) & (src < hi) & (dst >= lo) & (dst < hi))))
+            lay = None
+            if ok:
+                lay = _EventLayout()
+                lay.hit_ptr = torch.from_numpy(hp.astype(_I32))
+                lay.seg_ptr = torch.from_numpy(sp.astype(_I32))
+                lay.max_hits = int(np.diff(hp).max(initial=0))
+                lay.max_segments = int(np.diff(sp).max(initial=0))
+            self._event = (lay,)
+        lay = self._event[0]
+        if lay is not None and lay.hit_ptr.device != self.X.device:
+            lay.hit_ptr = lay.hit_ptr.to(self.X.device)
+            lay.seg_ptr = lay.seg_ptr.to(self.X.device)
+        return lay
 
     # -- constructors ------------------------------------------------------------------
     @classmethod

@@ -156,6 +156,7 @@ class SegmentClassifier(nn.Module):
                                         hidden_activation, masks_n)
         self._workspace = None
         self.use_plan = True      # False: per-module CSR kernels instead of the fused pipeline
+        self.use_events = True    # batches of small graphs: whole forward in one launch
         self.exp_product = True   # allow GNN_FLAG_EXP_PRODUCT when the bound check passes
         self._xp_cache = None     # (key, flag): the bound check synchronises, so it is cached
         self._w_cache = None      # (key, weights, GnnParams): rebuilt when a parameter changes
@@ -206,6 +207,16 @@ class SegmentClassifier(nn.Module):
         if not batch.X.is_cuda:
             raise _lib.GnnHipError("SegmentClassifier.forward needs tensors on a ROCm device; "
                                    "there is no CPU path")
+        # small events (muon graphs): one launch, one workgroup per graph, everything in LDS
+        # (up to ~1k graphs: beyond that the tiled pipeline's throughput wins, tools/latency_probe.py)
+        lay = batch.event_layout() if (self.use_events and not trace and batch.n_graphs <= 1024 and
+                                       _lib.shape_supported(F, D)) else None
+        if lay is not None and _lib.events_supported(F, D, lay.max_hits, lay.max_segments):
+            weights, pstruct = self._cached_weights()
+            e = _lib.segclf_forward_events(batch, lay, weights, F, D, self.n_iters, params=pstruct)
+            if batch.dense_shape:
+                e = e.view(batch.dense_shape[0], batch.dense_shape[2])
+            return e
         fused = not trace and self.use_plan and _lib.plan_shape_supported(F, D)
         if fused:
             plan = batch.build_plan(D)

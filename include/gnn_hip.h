@@ -147,6 +147,18 @@ int gnn_segclf_forward(const gnn_graph_t *g, const gnn_params_t *p, int32_t n_it
                        float *e_out, float *e_trace, float *H_trace,
                        void *workspace, size_t workspace_bytes, void *stream);
 
+/* Small events (the reference's muon graphs, gnn/prepareMuonGraphs.py: tens of hits): the same
+ * forward in ONE launch, one workgroup per graph of the block-diagonal batch, hit features and
+ * scores resident in LDS across all iterations (no workspace).  hit_ptr / seg_ptr [n_graphs+1]
+ * are device arrays of the graphs' first hit / segment; every segment in
+ * [seg_ptr[i], seg_ptr[i+1]) must join hits in [hit_ptr[i], hit_ptr[i+1]) (or be padded,
+ * src = dst = -1); max_hits / max_segments bound the graph sizes.  Bit-identical to
+ * gnn_segclf_forward.  gnn_events_supported: 1 if graphs of that size fit one workgroup. */
+int gnn_events_supported(int32_t F, int32_t D, int64_t max_hits, int64_t max_segments);
+int gnn_segclf_forward_events(const gnn_graph_t *g, const gnn_params_t *p, const int32_t *hit_ptr,
+                              const int32_t *seg_ptr, int64_t n_graphs, int32_t max_hits,
+                              int32_t max_segments, int32_t n_iters, float *e_out, void *stream);
+
 /* Training forward: like gnn_segclf_forward but keeps what the backward needs - the scores of
  * every edge pass e_all [(n_iters+1), n_segments] (the last row is the model output) and the hit
  * features of every iteration H_all [(n_iters+1), n_hits, ldh] (padded rows). */

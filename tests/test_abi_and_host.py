@@ -172,3 +172,25 @@ def test_pipelined_kernels_never_spill():
             assert agprs == 0, "%s<%d,%d> is pipelined but parks values in AGPRs" % (m.group(1), F, D)
             assert scratch == 0, "%s<%d,%d> is pipelined but spills %d bytes" % (m.group(1), F, D, scratch)
     assert seen >= 20 + 19          # k_iter: 5 shapes x 4 variants; k_iter2: 4 shapes x 4 + 3 fused-first
+
+
+def test_event_layout_checks_block_diagonality():
+    """HitGraphBatch.event_layout: per-graph offsets for the one-workgroup-per-graph kernel, and
+    None when a segment crosses a graph boundary (that kernel indexes LDS by local hit id)."""
+    graphs = [synth.muon_graph(seed=i) for i in range(5)]
+    b = HitGraphBatch.from_graphs(graphs)
+    lay = b.event_layout()
+    assert lay is not None and lay is b.event_layout()          # cached
+    assert lay.hit_ptr.dtype == torch.int32 and lay.hit_ptr.tolist() == b.hit_ptr.tolist()
+    assert lay.seg_ptr.tolist() == b.seg_ptr.tolist()
+    assert lay.max_hits == max(g.X.shape[0] for g in graphs)
+    assert lay.max_segments == max(g.src.shape[0] for g in graphs)
+    g = synth.layered_graph(60, 100, 3, seed=2)
+    assert HitGraphBatch(g.X, g.src, g.dst).event_layout() is not None      # one graph: trivially fine
+    assert HitGraphBatch(g.X, g.src, g.dst, hit_ptr=[0, 30, 60],
+                         seg_ptr=[0, 50, 100]).event_layout() is None
+    # padded segments (-1) are allowed anywhere
+    X, Ri, Ro = synth.to_dense(graphs[0], 40, 200)
+    pb = HitGraphBatch.from_dense(torch.from_numpy(X)[None], torch.from_numpy(Ri)[None],
+                                  torch.from_numpy(Ro)[None])
+    assert pb.event_layout() is not None and pb.event_layout().max_segments == 200

@@ -109,6 +109,7 @@ def test_megabatch_against_oracle(hip, F, D, T):
     m = SegmentClassifier(input_dim=F, hidden_dim=D, n_iters=T).cuda().eval()
     params = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
     batch = HitGraphBatch.from_graphs(graphs).cuda()
+    m.use_events = False                 # (the one-launch small-event path has its own tests)
     for use_plan in (True, False):       # fused pipeline, then per-module CSR kernels
         m.use_plan = use_plan
         with torch.no_grad():
@@ -254,6 +255,7 @@ def test_exp_product_bound_and_fallback(hip):
     g = synth.layered_graph(300, 1500, 3, seed=9)
     batch = HitGraphBatch.from_graphs([g]).cuda()
     m = SegmentClassifier(input_dim=3, hidden_dim=8, n_iters=2).cuda().eval()
+    m.use_events = False                                           # this is about the tiled pipeline
     with torch.no_grad():
         e = m(batch)
         assert m._xp_cache[1] == hip.GNN_FLAG_EXP_PRODUCT          # default init: tiny bound
@@ -287,6 +289,7 @@ def test_irregular_graphs_and_forced_global_mode(hip, F, D, T):
     graphs = [_random_graph(400, 3000, F, 1), _random_graph(37, 90, F, 2),
               synth.layered_graph(600, 5000, F, seed=3), _random_graph(5, 40, F, 4)]
     m = SegmentClassifier(input_dim=F, hidden_dim=D, n_iters=T).cuda().eval()
+    m.use_events = False
     params = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
     refs = [index_c.segment_classifier(g.X, g.src, g.dst, params, T) for g in graphs]
     for limits in ({"iter_records": 0, "edge_records": 0}, None):
@@ -353,3 +356,87 @@ def test_training_loop_like_estimator_fit_gen(hip):
         losses_ref.append(lr.item())
     assert losses[-1] < 0.8 * losses[0]
     assert np.abs(np.array(losses) - np.array(losses_ref)).max() < 2e-4
+
+
+# ---- small events: whole forward in one launch, one workgroup per graph -------------------------
+def _muon_batch(n_graphs, seed=0):
+    return [synth.muon_graph(seed=seed + i) for i in range(n_graphs)]
+
+
+@pytest.mark.parametrize("F,D,T,kind", [(11, 8, 3, "muon"), (3, 8, 3, "layered"), (2, 4, 2, "layered"),
+                                        (3, 16, 2, "layered"), (11, 16, 1, "muon")])
+def test_small_event_kernel_is_bit_identical_to_the_module_kernels(hip, F, D, T, kind):
+    """k_event (one workgroup per graph, H and scores resident in LDS) runs the same arithmetic
+    in the same order as k_input / k_edge / k_node: scores must be EQUAL, and within 1e-5 of the
+    C oracle; covers ragged sizes, a graph without segments and a graph without hits."""
+    from gnn_fpga_amd.model import SegmentClassifier
+    rng = np.random.default_rng(11)
+    if kind == "muon":
+        graphs = _muon_batch(37, seed=3)
+    else:
+        graphs = [synth.layered_graph(int(rng.integers(4, 150)), int(rng.integers(1, 600)), F,
+                                      seed=40 + i) for i in range(23)]
+    g0 = graphs[0]
+    graphs.insert(5, synth.HitGraph(g0.X[:7], np.zeros(0, np.int32), np.zeros(0, np.int32),
+                                    np.zeros(0, np.float32)))
+    graphs.insert(9, synth.HitGraph(g0.X[:0], np.zeros(0, np.int32), np.zeros(0, np.int32),
+                                    np.zeros(0, np.float32)))
+    torch.manual_seed(F * 10 + D)
+    m = SegmentClassifier(input_dim=F, hidden_dim=D, n_iters=T).cuda().eval()
+    batch = HitGraphBatch.from_graphs(graphs).cuda()
+    lay = batch.event_layout()
+    assert lay is not None and hip.events_supported(F, D, lay.max_hits, lay.max_segments)
+    with torch.no_grad():
+        m.use_events = True
+        e_ev = m(batch)
+        m.use_events, m.use_plan = False, False
+        e_csr = m(batch)
+    torch.cuda.synchronize()
+    assert torch.equal(e_ev, e_csr)
+    params = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    for g, eg in zip(graphs, batch.split_scores(e_ev.cpu().numpy())):
+        ref = index_c.segment_classifier(g.X, g.src, g.dst, params, T)
+        assert eg.shape == ref.shape
+        if ref.size:
+            assert np.abs(eg - ref).max() < TOL
+
+
+@pytest.mark.parametrize("name", BATCHES)
+def test_small_event_kernel_on_the_reference_padded_batches(hip, name):
+    """Zero-padded dense batches (gnn/trainSegmentClassifier.py:66-95) take the one-launch path
+    too: padded segments score sigmoid(W2 tanh(b1) + b2), like the reference."""
+    from gnn_fpga_amd.model import SegmentClassifier
+    fx = Fixture(name)
+    dev = torch.device("cuda:0")
+    Nmax = max(g.X.shape[0] for g in fx.graphs)
+    Emax = fx.scores.shape[1]
+    dense = [synth.to_dense(g, Nmax, Emax) for g in fx.graphs]
+    X, Ri, Ro = (torch.from_numpy(np.stack([d[i] for d in dense])).to(dev) for i in range(3))
+    m = SegmentClassifier(input_dim=fx.F, hidden_dim=fx.D, n_iters=fx.n_iters)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in fx.params.items()})
+    m.cuda().eval()
+    batch = HitGraphBatch.from_dense(X, Ri, Ro).to(dev)
+    lay = batch.event_layout()
+    assert lay is not None and hip.events_supported(fx.F, fx.D, lay.max_hits, lay.max_segments)
+    with torch.no_grad():
+        out = m(batch)
+    assert np.abs(out.cpu().numpy() - fx.scores).max() < TOL
+
+
+def test_small_event_path_declines_what_it_cannot_hold(hip):
+    """Large graphs and batches that are not block-diagonal fall through to the tiled pipeline."""
+    from gnn_fpga_amd.model import SegmentClassifier
+    big = synth.layered_graph(3000, 20000, 3, seed=1)
+    b = HitGraphBatch.from_graphs([big]).cuda()
+    lay = b.event_layout()
+    assert lay is not None and not hip.events_supported(3, 8, lay.max_hits, lay.max_segments)
+    # segments crossing graph boundaries: legal for the global kernels, not for one-graph-per-workgroup
+    g = synth.layered_graph(60, 100, 3, seed=2)
+    cross = HitGraphBatch(g.X, g.src, g.dst, hit_ptr=[0, 30, 60], seg_ptr=[0, 50, 100]).cuda()
+    assert cross.event_layout() is None
+    torch.manual_seed(0)
+    m = SegmentClassifier(input_dim=3, hidden_dim=8, n_iters=2).cuda().eval()
+    params = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        e = m(cross).cpu().numpy()
+    assert np.abs(e - index_c.segment_classifier(g.X, g.src, g.dst, params, 2)).max() < TOL

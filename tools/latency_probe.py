@@ -6,11 +6,13 @@ import torch
 from gnn_fpga_amd import HitGraphBatch, synth
 from gnn_fpga_amd.model import SegmentClassifier
 
-def probe(name, graphs, F, D, T, reps=200):
+def probe(name, graphs, F, D, T, reps=200, events=True):
     torch.manual_seed(0)
     m = SegmentClassifier(input_dim=F, hidden_dim=D, n_iters=T).cuda().eval()
+    m.use_events = events          # False: force the tiled pipeline (one-launch small-event path off)
     b = HitGraphBatch.from_graphs(graphs).cuda()
-    b.build_plan(D)
+    if not events:
+        b.build_plan(D)
     with torch.no_grad():
         for _ in range(10): m(b)
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -27,7 +29,13 @@ def probe(name, graphs, F, D, T, reps=200):
 
 probe("c3 single graph (10k/100k, F3 D8 T3)", [synth.layered_graph(10000, 100000, 3, seed=0)], 3, 8, 3)
 probe("c2 one muon graph (F11 D8 T3)", [synth.muon_graph(0)], 11, 8, 3)
+probe("c2 one muon graph, tiled pipeline", [synth.muon_graph(0)], 11, 8, 3, events=False)
 probe("c4 512 muon graphs (F11 D8 T3)", [synth.muon_graph(s) for s in range(512)], 11, 8, 3)
+probe("c4 512 muon graphs, tiled pipeline", [synth.muon_graph(s) for s in range(512)], 11, 8, 3, events=False)
+probe("c4/8: 64 muon graphs (one GPU's share)", [synth.muon_graph(s) for s in range(64)], 11, 8, 3)
+probe("16384 muon graphs", [synth.muon_graph(s) for s in range(16384)], 11, 8, 3, reps=50)
+probe("16384 muon graphs, tiled pipeline", [synth.muon_graph(s) for s in range(16384)], 11, 8, 3, reps=50, events=False)
+probe("toy2d 40 hits/144 segs (F2 D32 T10)", [synth.toy2d_graph(seed=0)], 2, 32, 10) if hasattr(synth, "toy2d_graph") else None
 probe("c2-scale 2k hits/10k segs (F11 D8 T3)", [synth.layered_graph(2000, 10000, 11, seed=0)], 11, 8, 3)
 probe("c1-scale 1k/5k (F2 D32 T10)", [synth.layered_graph(1000, 5000, 2, seed=0)], 2, 32, 10)
 probe("c5 fp32 50k/500k (F3 D64 T6)", [synth.layered_graph(50000, 500000, 3, seed=0)], 3, 64, 6, reps=5)
