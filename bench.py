@@ -161,19 +161,25 @@ def main():
                                              / args.steps, 4)] for i in range(lps)] if lps else []
         n_tot, e_tot = batch.n_hits, batch.n_segments
         ab = algorithmic_bytes(n_tot, e_tot)
-        achieved = ab[dom] / (avg_ms[dom] * 1e-3) / 1e9
+        # algorithmic bytes of the dominant kernel's launches in one step; when the input network
+        # is fused into the first iteration launch (no k_input4 launch), its bytes ride along
+        n_dom = len(per[dom]) // args.steps
+        ab_dom_step = n_dom * ab[dom]
+        if dom == "k_iter2" and "k_input4" not in per:
+            ab_dom_step += ab["k_input4"]
+        ab_dom = ab_dom_step / n_dom                       # average per launch
+        achieved = ab_dom / (avg_ms[dom] * 1e-3) / 1e9
         ms_step = elapsed / args.steps * 1e3
         traffic = None
         if args.pmc_traffic and os.path.exists(args.pmc_traffic) and G == 256:
             with open(args.pmc_traffic) as f:
                 pk = json.load(f)["kernels"]
-            # the dominant kernel has two template variants (last iteration writes less)
-            vals = [v["hbm_bytes_per_launch"] for k, v in pk.items() if k.startswith(dom + "<")]
-            if len(vals) == 2 and dom in ("k_iter", "k_iter2"):   # (T-1) regular launches + 1 last
-                v = sorted(vals)
-                traffic = (v[1] * (T - 1) + v[0]) / T
-            elif vals:
-                traffic = sum(vals) / len(vals)
+            # the dominant kernel has template variants (first / middle / last iteration move
+            # different amounts): launch-weighted mean over the profiled run
+            vs = [v for k, v in pk.items() if k.startswith(dom + "<")]
+            if vs:
+                traffic = (sum(v["hbm_bytes_per_launch"] * v.get("launches", 1) for v in vs) /
+                           sum(v.get("launches", 1) for v in vs))
         value = world * e_tot * args.steps / elapsed
         out = {
             "metric": "edges/sec (EdgeNet+NodeNet fwd) on 100k-edge TrackML graphs; % HBM roofline",
@@ -193,7 +199,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
-                         "algorithmic_bytes_per_launch": ab[dom],
+                         "algorithmic_bytes_per_launch": ab_dom,
                          "avg_launch_ms": avg_ms[dom],
                          "kernel_ms": {k: round(v, 4) for k, v in avg_ms.items()},
                          "launches_per_step": {k: len(v) // args.steps for k, v in per.items()},

@@ -24,6 +24,7 @@ for cname in ("FETCH_SIZE", "WRITE_SIZE"):
         acc.setdefault(short(r["Kernel_Name"]), []).append(float(r["Counter_Value"]))
     for k, v in acc.items():
         res.setdefault(k, {})[cname + "_KB_mean"] = sum(v) / len(v)
+        res[k]["launches"] = len(v)
 for v in res.values():
     v["hbm_bytes_per_launch"] = (2 * v.get("FETCH_SIZE_KB_mean", 0) + v.get("WRITE_SIZE_KB_mean", 0)) * 1024
 doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python3 bench.py "
