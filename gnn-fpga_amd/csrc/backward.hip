@@ -53,6 +53,22 @@ __device__ __forceinline__ void accum_outer(const float *L, const float *R, bool
     __syncthreads();
 }
 
+// same for wide right factors: the LDS staging area is capped at kOuterCap floats per item
+// (128 KB per workgroup), the columns of R are taken in chunks that fit beside L
+constexpr int kOuterCap = 128;
+template <int NL, int NR>
+constexpr int outer_lds_floats() { return kBlock * ((NL + NR) < kOuterCap ? (NL + NR) : kOuterCap); }
+
+template <int NL, int NR, int C0 = 0>
+__device__ __forceinline__ void accum_outer_wide(const float *L, const float *R, bool active,
+                                                 float *g, int ldg, int col0, float *lds)
+{
+    static_assert(NL < kOuterCap, "left factor too wide");
+    constexpr int CH = (NL + NR - C0 <= kOuterCap) ? NR - C0 : kOuterCap - NL;
+    accum_outer<NL, CH>(L, R + C0, active, g, ldg, col0 + C0, lds);
+    if constexpr (C0 + CH < NR) accum_outer_wide<NL, NR, C0 + CH>(L, R, active, g, ldg, col0, lds);
+}
+
 // P/Q rows from H (same as the forward's k_pq; kept local to this file)
 template <int F, int D>
 __global__ __launch_bounds__(kBlock) void kb_pq(const float *__restrict__ H, int ldh,
@@ -118,7 +134,7 @@ __global__ __launch_bounds__(kBlock) void k_pq_bwd(
     float *__restrict__ gb1, int64_t n_pad_edges_b1, int64_t n_hits)
 {
     constexpr int C = F + D;
-    __shared__ float lds[kBlock * (D + C)];
+    __shared__ float lds[outer_lds_floats<D, C>()];
     const int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool active = n < n_hits;
     float gP[D], gQ[D], h[C];
@@ -151,8 +167,8 @@ __global__ __launch_bounds__(kBlock) void k_pq_bwd(
         }
     }
     const float one = 1.0f;
-    accum_outer<D, C>(gP, h, active, gW1, 2 * C, 0, lds);
-    accum_outer<D, C>(gQ, h, active, gW1, 2 * C, C, lds);
+    accum_outer_wide<D, C>(gP, h, active, gW1, 2 * C, 0, lds);
+    accum_outer_wide<D, C>(gQ, h, active, gW1, 2 * C, C, lds);
     accum_outer<D, 1>(gP, &one, active, gb1, 1, 0, lds);
     (void)n_pad_edges_b1;
 }
@@ -185,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void k_node_bwd(
     float *__restrict__ gb3, float *__restrict__ gW4, float *__restrict__ gb4, int64_t n_hits)
 {
     constexpr int C = Shape<F, D>::C;
-    __shared__ float lds[kBlock * (D + 3 * C)];
+    __shared__ float lds[outer_lds_floats<D, 3 * C>()];
     const int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool active = n < n_hits;
     float M[3 * C], q[D], gr[D], gp[D];
@@ -239,9 +255,9 @@ __global__ __launch_bounds__(kBlock) void k_node_bwd(
         }
     }
     const float one = 1.0f;
-    accum_outer<D, 3 * C>(gp, M, active, gW3, 3 * C, 0, lds);
+    accum_outer_wide<D, 3 * C>(gp, M, active, gW3, 3 * C, 0, lds);
     accum_outer<D, 1>(gp, &one, active, gb3, 1, 0, lds);
-    accum_outer<D, D>(gr, q, active, gW4, D, 0, lds);
+    accum_outer_wide<D, D>(gr, q, active, gW4, D, 0, lds);
     accum_outer<D, 1>(gr, &one, active, gb4, 1, 0, lds);
 }
 
@@ -405,7 +421,8 @@ int backward_t(const gnn_graph_t *g, const gnn_params_t *p, int T, const float *
 }
 
 #define BWD_FOR_EACH_SHAPE(X_) \
-    X_(2, 4) X_(2, 8) X_(2, 16) X_(3, 4) X_(3, 8) X_(3, 16) X_(11, 4) X_(11, 8) X_(11, 16)
+    X_(2, 4) X_(2, 8) X_(2, 16) X_(2, 32) X_(3, 4) X_(3, 8) X_(3, 16) X_(3, 32) X_(3, 64) X_(11, 4) X_(11, 8) \
+    X_(11, 16)
 
 }  // namespace
 

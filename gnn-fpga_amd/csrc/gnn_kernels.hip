@@ -587,7 +587,8 @@ __global__ __launch_bounds__(kBlock) void k_unpad(const float *__restrict__ H, i
 // shape dispatch
 // ---------------------------------------------------------------------------------------------
 #define GNN_FOR_EACH_SHAPE(X_) \
-    X_(2, 4) X_(2, 8) X_(2, 16) X_(3, 4) X_(3, 8) X_(3, 16) X_(11, 4) X_(11, 8) X_(11, 16)
+    X_(2, 4) X_(2, 8) X_(2, 16) X_(2, 32) X_(3, 4) X_(3, 8) X_(3, 16) X_(3, 32) X_(3, 64) X_(11, 4) X_(11, 8) \
+    X_(11, 16)
 
 template <int F, int D>
 int run_input(const float *X, const float *Win, const float *bin, const float *W1,

@@ -171,15 +171,17 @@ __device__ __forceinline__ void write_null_rows(const gnn_params_t &p, float *PR
     }
 }
 
-// stand-alone pack (only needed when a batch has no hits at all: k_input4 normally does this)
+// stand-alone pack: for batches without hits, and for the large tables (Cfg::pack_first) that are
+// cheaper to build once than in every workgroup of k_input4
 template <int F, int D, bool XP>
 __global__ __launch_bounds__(256) void k_pack(gnn_params_t p, float *__restrict__ table,
                                               float *PRa, float *PRb, float *QSa, float *QSb,
                                               float *U, float *Pc, float *Qc, int64_t n_hits)
 {
     using L = TL<F, D>;
-    for (int idx = threadIdx.x; idx < L::total; idx += 256) table[idx] = table_entry<F, D>(p, idx);
-    write_null_rows<F, D, XP>(p, PRa, PRb, QSa, QSb, U, Pc, Qc, n_hits);
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < L::total; idx += gridDim.x * 256)
+        table[idx] = table_entry<F, D>(p, idx);
+    if (blockIdx.x == 0) write_null_rows<F, D, XP>(p, PRa, PRb, QSa, QSb, U, Pc, Qc, n_hits);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -307,6 +309,8 @@ struct Cfg {
     static constexpr bool pipelined = (D <= 8 && F <= 3) || (D == 4);
     // shapes whose persistent phase-split kernel (k_iter2) builds with zero scratch / AGPRs
     static constexpr bool iter2 = (D <= 8 && F <= 3);
+    // big weight tables are packed once by k_pack and copied, not rebuilt per workgroup
+    static constexpr bool pack_first = (TL<F, D>::total > 4096);
     // ... and whose first-iteration variant (input network fused in, FIRST) does as well
     static constexpr bool fuse_first = iter2 && !(F == 2 && D == 8);
 };
@@ -482,12 +486,16 @@ __global__ __launch_bounds__(256) void k_input4(const float *__restrict__ X, gnn
     // Every workgroup packs the weight table straight from the raw weights (a few L2-resident
     // loads per thread: cheaper than one more kernel boundary); workgroup 0 also publishes it
     // and the NULL rows for the kernels that follow.
-    for (int idx = threadIdx.x; idx < L::total; idx += 256) {
-        const float v = table_entry<F, D>(p, idx);
-        lds[idx] = v;
-        if (blockIdx.x == 0) table[idx] = v;
+    if constexpr (Cfg<F, D>::pack_first) {      // k_pack ran before: 105 KB of table at D = 64
+        stage4<256>(table, lds, L::total / 4);
+    } else {
+        for (int idx = threadIdx.x; idx < L::total; idx += 256) {
+            const float v = table_entry<F, D>(p, idx);
+            lds[idx] = v;
+            if (blockIdx.x == 0) table[idx] = v;
+        }
+        if (blockIdx.x == 0) write_null_rows<F, D, XP>(p, PRn, PRo, QSn, QSo, U, Pc, Qc, n_pad);
     }
-    if (blockIdx.x == 0) write_null_rows<F, D, XP>(p, PRn, PRo, QSn, QSo, U, Pc, Qc, n_pad);
     __syncthreads();
     const int q = threadIdx.x & 3;
     // grid-stride over 64-hit groups: the weight table is staged once per workgroup, not per
@@ -1488,9 +1496,9 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
     using G = Cfg<F, D>;
     const int64_t Np = pl->n_pad, E = pl->n_segments;
     Ws w = carve(ws, Np, L::total, D);
-    if (Np == 0)      // nothing for k_input4 to do: pack the table / NULL rows on their own
-        GNN_LAUNCH("k_pack", (k_pack<F, D, XP>), 1, 256, s, *p, w.table, w.PRa, w.PRb, w.QSa, w.QSb,
-                   w.U, w.Pc, w.Qc, Np);
+    if (Np == 0 || G::pack_first)   // no hits (nothing for k_input4 to do), or a big table
+        GNN_LAUNCH("k_pack", (k_pack<F, D, XP>), (L::total + 255) / 256, 256, s, *p, w.table, w.PRa, w.PRb,
+                   w.QSa, w.QSb, w.U, w.Pc, w.Qc, Np);
     float *PR = w.PRa, *PRn = w.PRb, *QS = w.QSa, *QSn = w.QSb;
     if (Np > 0) {
         const int nt = (int)pl->n_tiles;

@@ -440,3 +440,35 @@ def test_small_event_path_declines_what_it_cannot_hold(hip):
     with torch.no_grad():
         e = m(cross).cpu().numpy()
     assert np.abs(e - index_c.segment_classifier(g.X, g.src, g.dst, params, 2)).max() < TOL
+
+
+@pytest.mark.parametrize("F,D,T", [(2, 32, 3), (3, 64, 2), (3, 32, 2)])
+def test_wide_hidden_dims_train_and_submodules(hip, F, D, T):
+    """hidden_dim 32 (the reference's toy and ACTS notebooks) and 64 (mu200 notebook): the
+    per-module kernels, the small-event kernel and the backward kernels against the dense oracle
+    (forward) and autograd through it (all ten gradients)."""
+    from gnn_fpga_amd.model import SegmentClassifier
+    from oracle import dense_torch
+    g = synth.layered_graph(90, 260, F, seed=21)
+    torch.manual_seed(D)
+    m = SegmentClassifier(input_dim=F, hidden_dim=D, n_iters=T).cuda()
+    params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    batch = HitGraphBatch.from_graphs([g]).cuda()
+    Xd, Ri, Ro = (torch.from_numpy(a)[None] for a in synth.to_dense(g))
+    y = (torch.arange(batch.n_segments) % 2 == 0).float()
+    ref_e = dense_torch.segment_classifier(Xd, Ri, Ro, params, T)[0]
+    ref = torch.nn.BCELoss()(ref_e, y)
+    ref.backward()
+    m.eval()
+    with torch.no_grad():
+        for events, plan in ((True, True), (False, True), (False, False)):
+            m.use_events, m.use_plan = events, plan
+            e = m(batch)
+            assert np.abs(e.cpu().numpy() - ref_e.detach().numpy()).max() < TOL, (events, plan)
+    m.train()
+    loss = torch.nn.BCELoss()(m(batch), y.cuda())
+    loss.backward()
+    assert abs(loss.item() - ref.item()) < 1e-6
+    for k, p in m.named_parameters():
+        gk, r = p.grad.cpu().numpy(), params[k].grad.numpy()
+        assert np.abs(gk - r).max() < 1e-6 + 1e-4 * np.abs(r).max(), k
