@@ -20,6 +20,8 @@
 // No MFMA here by design: at D <= 16 the work is HBM/gather-bound integer-indexed traffic.
 #include "common.h"
 
+#include <type_traits>
+
 namespace gnn {
 
 thread_local char g_err[320] = "";
@@ -301,8 +303,15 @@ struct EvW {
         *__restrict__ b4;
 };
 
+template <int D>
+struct EvCfg {
+    // wavefronts per graph: the output rows of every layer are dealt to them
+    static constexpr int NWV = D >= 32 ? 16 : D >= 8 ? 8 : 4;
+    static constexpr int NT = 64 * NWV;
+};
+
 template <int F, int D>
-__global__ __launch_bounds__(256) void k_event(
+__global__ __launch_bounds__((EvCfg<D>::NT)) void k_event(
     gnn_graph_t g, const float *__restrict__ Win, const float *__restrict__ bin,
     const float *__restrict__ W1, const float *__restrict__ b1, const float *__restrict__ W2,
     const float *__restrict__ b2, const float *__restrict__ W3, const float *__restrict__ b3,
@@ -312,13 +321,13 @@ __global__ __launch_bounds__(256) void k_event(
 {
     constexpr int C = Shape<F, D>::C;
     constexpr int LDH = Shape<F, D>::LDH;
-    constexpr int NT = 256, NWV = 4;
+    constexpr int NT = EvCfg<D>::NT, NWV = EvCfg<D>::NWV;
     constexpr int RW = D / NWV;          // output rows of a D-row layer per wavefront
     constexpr int RP = 2 * D / NWV;      // rows of the stacked [P; Q] per wavefront
-    static_assert(D % NWV == 0, "rows are dealt to 4 wavefronts");
+    static_assert(D % NWV == 0 && RW >= 1, "rows are dealt to the wavefronts");
     extern __shared__ __attribute__((aligned(16))) float ev_lds[];
     float *H = ev_lds, *Hn = H + cap_hits * LDH, *PQ = Hn + cap_hits * LDH,
-          *qb = PQ + cap_hits * 2 * D, *es = qb + cap_hits * D;
+          *qb = PQ + cap_hits * 2 * D, *Mb = qb + cap_hits * D, *es = Mb + cap_hits * 2 * LDH;
     const int h0 = hit_ptr[blockIdx.x], nh = hit_ptr[blockIdx.x + 1] - h0;
     const int s0 = seg_ptr[blockIdx.x], ns = seg_ptr[blockIdx.x + 1] - s0;
     const float *__restrict__ X = g.X;
@@ -326,8 +335,9 @@ __global__ __launch_bounds__(256) void k_event(
     // The weights (953 floats at F = 11, D = 8) are copied to LDS once and read from there with
     // broadcast ds_reads: a graph is a handful of wavefronts, nothing hides scalar-load latency
     // (measured 38 us per launch on the s_load path).  A hit is a lane; the output rows of every
-    // layer are dealt to the 4 wavefronts (each loads a quarter of the weights and runs a quarter
-    // of the FMAs), layers meet through LDS.  Per row the arithmetic and its order are those of
+    // layer are dealt to the wavefronts (each reads its share of the weights and runs its share
+    // of the FMAs), layers meet through LDS.  Inputs stream through in 4-float pieces, so the
+    // register footprint does not grow with D.  Per row the arithmetic and its order are those of
     // k_input / k_node, so the scores are bit-identical to the per-module kernels.
     using W = EvWeights<F, D>;
     float *wl = es + ((cap_segments + 3) & ~3);
@@ -341,7 +351,7 @@ __global__ __launch_bounds__(256) void k_event(
                    wl + W::off(5), wl + W::off(6), wl + W::off(7), wl + W::off(8), wl + W::off(9)};
     // The graph's index arrays too, as LOCAL ids: the pull loops below chase eid -> score and
     // nbr -> feature row per list entry, and from global memory every hop is a dependent
-    // round trip (measured: 2/3 of the launch).  One coalesced pass here instead.
+    // round trip.  One coalesced pass here instead.
     int32_t *ip = reinterpret_cast<int32_t *>(wl + W::total), *op = ip + cap_hits + 1,
             *ie = op + cap_hits + 1, *inb = ie + cap_segments, *oe = inb + cap_segments,
             *onb = oe + cap_segments, *sl = onb + cap_segments, *dl = sl + cap_segments;
@@ -361,51 +371,56 @@ __global__ __launch_bounds__(256) void k_event(
             onb[k] = g.out_nbr[ob + k] - h0;
         }
     }
-    {
-        for (int j = threadIdx.x; j < ns; j += NT) {
-            const int sg = g.src[s0 + j];
-            sl[j] = sg < 0 ? -1 : sg - h0;
-            dl[j] = sg < 0 ? -1 : g.dst[s0 + j] - h0;
-        }
+    for (int j = threadIdx.x; j < ns; j += NT) {
+        const int sg = g.src[s0 + j];
+        sl[j] = sg < 0 ? -1 : sg - h0;
+        dl[j] = sg < 0 ? -1 : g.dst[s0 + j] - h0;
+    }
+    // input rows: X into the skip columns of H (k_input), zero padding
+    for (int i = threadIdx.x; i < nh * (LDH - D); i += NT) {
+        const int n = i / (LDH - D), k = i % (LDH - D);
+        H[n * LDH + D + k] = k < F ? X[(int64_t)(h0 + n) * F + k] : 0.0f;
     }
     __syncthreads();
 
+    // acc[r] += sum_j w[r][4c + j] * v[j] over one 4-float piece of the input (k ascending)
+    auto fma_piece = [&](float *acc, const float *wrow0, int ldw, int c, const float4 v, auto rows) {
+        constexpr int R = decltype(rows)::value;
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (4 * c + j < C)
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r] = fmaf(wrow0[r * ldw + 4 * c + j], vv[j], acc[r]);
+    };
+
     // rows [wv*RP, (wv+1)*RP) of [P; Q] for every hit, from the full feature rows in `Hsrc`
     auto pq_rows = [&](const float *Hsrc) {
+        const int row0 = wv * RP, d0 = row0 % D;
+        const bool isq = row0 >= D;                          // wave-uniform (RP divides D)
         for (int n = lane; n < nh; n += 64) {
-            float h[C];
+            float acc[RP];
 #pragma unroll
-            for (int k = 0; k < C; ++k) h[k] = Hsrc[n * LDH + k];
+            for (int r = 0; r < RP; ++r) acc[r] = isq ? 0.0f : p.b1[d0 + r];
 #pragma unroll
-            for (int r = 0; r < RP; ++r) {
-                const int row = wv * RP + r, d = row % D;
-                const bool isq = row >= D;                   // wave-uniform
-                float acc = isq ? 0.0f : p.b1[d];
+            for (int c = 0; c < LDH / 4; ++c)
+                fma_piece(acc, p.W1 + d0 * 2 * C + (isq ? C : 0), 2 * C, c,
+                          *reinterpret_cast<const float4 *>(Hsrc + n * LDH + 4 * c),
+                          std::integral_constant<int, RP>{});
 #pragma unroll
-                for (int k = 0; k < C; ++k) acc = fmaf(p.W1[d * 2 * C + (isq ? C : 0) + k], h[k], acc);
-                PQ[n * 2 * D + row] = acc;
-            }
+            for (int r = 0; r < RP; ++r) PQ[n * 2 * D + row0 + r] = acc[r];
         }
     };
 
-    // input network + skip concat (k_input): rows of tanh(Win x + bin) per wavefront
+    // input network (k_input): rows of tanh(Win x + bin) per wavefront
     for (int n = lane; n < nh; n += 64) {
-        float x[F];
-#pragma unroll
-        for (int k = 0; k < F; ++k) x[k] = X[(int64_t)(h0 + n) * F + k];
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
             const int d = wv * RW + r;
             float acc = p.bin[d];
 #pragma unroll
-            for (int k = 0; k < F; ++k) acc = fmaf(p.Win[d * F + k], x[k], acc);
+            for (int k = 0; k < F; ++k) acc = fmaf(p.Win[d * F + k], H[n * LDH + D + k], acc);
             H[n * LDH + d] = tanh_f(acc);
-        }
-        if (wv == 0) {
-#pragma unroll
-            for (int k = 0; k < F; ++k) H[n * LDH + D + k] = x[k];
-#pragma unroll
-            for (int k = C; k < LDH; ++k) H[n * LDH + k] = 0.0f;
         }
     }
     __syncthreads();
@@ -417,25 +432,22 @@ __global__ __launch_bounds__(256) void k_event(
         // edge pass (k_edge): one segment per lane of the workgroup
         for (int j = threadIdx.x; j < ns; j += NT) {
             const int s = sl[j], d = dl[j];
-            float z[D];
-            if (s >= 0) {
-                const float4 *pp = reinterpret_cast<const float4 *>(PQ + s * 2 * D);
-                const float4 *qq = reinterpret_cast<const float4 *>(PQ + d * 2 * D + D);
-#pragma unroll
-                for (int v = 0; v < D / 4; ++v) {
-                    const float4 a = pp[v], b = qq[v];
-                    z[4 * v] = a.x + b.x;
-                    z[4 * v + 1] = a.y + b.y;
-                    z[4 * v + 2] = a.z + b.z;
-                    z[4 * v + 3] = a.w + b.w;
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < D; ++k) z[k] = p.b1[k];
-            }
             float acc = p.b2[0];
 #pragma unroll
-            for (int k = 0; k < D; ++k) acc = fmaf(p.W2[k], tanh_f(z[k]), acc);
+            for (int v = 0; v < D / 4; ++v) {
+                float4 z;
+                if (s >= 0) {
+                    const float4 a = reinterpret_cast<const float4 *>(PQ + s * 2 * D)[v];
+                    const float4 b = reinterpret_cast<const float4 *>(PQ + d * 2 * D + D)[v];
+                    z = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+                } else {
+                    z = make_float4(p.b1[4 * v], p.b1[4 * v + 1], p.b1[4 * v + 2], p.b1[4 * v + 3]);
+                }
+                acc = fmaf(p.W2[4 * v], tanh_f(z.x), acc);
+                acc = fmaf(p.W2[4 * v + 1], tanh_f(z.y), acc);
+                acc = fmaf(p.W2[4 * v + 2], tanh_f(z.z), acc);
+                acc = fmaf(p.W2[4 * v + 3], tanh_f(z.w), acc);
+            }
             const float e = sigmoid_f(acc);
             if (last)
                 e_out[s0 + j] = e;
@@ -444,77 +456,61 @@ __global__ __launch_bounds__(256) void k_event(
         }
         if (last) break;
         __syncthreads();
-        // node pass (k_node).  Every wavefront pulls the segment sums (cheap), then computes its
-        // rows of the first MLP layer.
+        // node pass (k_node).  Step 1: the segment sums mi, mo of every hit, one (hit, part, 4-float
+        // piece) per thread, into LDS (pull over the local CSR, ascending segment id).
+        for (int i = threadIdx.x; i < nh * 2 * (LDH / 4); i += NT) {
+            const int n = i / (2 * (LDH / 4)), part = (i / (LDH / 4)) & 1, c = i % (LDH / 4);
+            const int32_t *el = part ? oe : ie, *nl = part ? onb : inb;
+            float4 m = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            for (int k = part ? op[n] : ip[n], k1 = part ? op[n + 1] : ip[n + 1]; k < k1; ++k) {
+                const float w = es[el[k]];
+                const float4 a = *reinterpret_cast<const float4 *>(H + nl[k] * LDH + 4 * c);
+                m.x = fmaf(w, a.x, m.x);
+                m.y = fmaf(w, a.y, m.y);
+                m.z = fmaf(w, a.z, m.z);
+                m.w = fmaf(w, a.w, m.w);
+            }
+            *reinterpret_cast<float4 *>(Mb + n * 2 * LDH + part * LDH + 4 * c) = m;
+        }
+        __syncthreads();
+        // Step 2: first layer, rows per wavefront; M = [mi | mo | h] streams through in pieces
         for (int n = lane; n < nh; n += 64) {
-            float M[3 * LDH];
+            const int d0 = wv * RW;
+            float acc[RW];
 #pragma unroll
-            for (int k = 0; k < 2 * LDH; ++k) M[k] = 0.0f;
-            {
-                const float4 *hp = reinterpret_cast<const float4 *>(H + n * LDH);
+            for (int r = 0; r < RW; ++r) acc[r] = p.b3[d0 + r];
+#pragma unroll 1
+            for (int part = 0; part < 3; ++part) {
+                const float *mrow = part == 2 ? H + n * LDH : Mb + n * 2 * LDH + part * LDH;
 #pragma unroll
-                for (int v = 0; v < LDH / 4; ++v) {
-                    const float4 a = hp[v];
-                    M[2 * LDH + 4 * v] = a.x;
-                    M[2 * LDH + 4 * v + 1] = a.y;
-                    M[2 * LDH + 4 * v + 2] = a.z;
-                    M[2 * LDH + 4 * v + 3] = a.w;
-                }
-            }
-            for (int k = ip[n], k1 = ip[n + 1]; k < k1; ++k) {
-                const float w = es[ie[k]];
-                const float4 *hp = reinterpret_cast<const float4 *>(H + inb[k] * LDH);
-#pragma unroll
-                for (int v = 0; v < LDH / 4; ++v) {
-                    const float4 a = hp[v];
-                    M[4 * v] = fmaf(w, a.x, M[4 * v]);
-                    M[4 * v + 1] = fmaf(w, a.y, M[4 * v + 1]);
-                    M[4 * v + 2] = fmaf(w, a.z, M[4 * v + 2]);
-                    M[4 * v + 3] = fmaf(w, a.w, M[4 * v + 3]);
-                }
-            }
-            for (int k = op[n], k1 = op[n + 1]; k < k1; ++k) {
-                const float w = es[oe[k]];
-                const float4 *hp = reinterpret_cast<const float4 *>(H + onb[k] * LDH);
-#pragma unroll
-                for (int v = 0; v < LDH / 4; ++v) {
-                    const float4 a = hp[v];
-                    M[LDH + 4 * v] = fmaf(w, a.x, M[LDH + 4 * v]);
-                    M[LDH + 4 * v + 1] = fmaf(w, a.y, M[LDH + 4 * v + 1]);
-                    M[LDH + 4 * v + 2] = fmaf(w, a.z, M[LDH + 4 * v + 2]);
-                    M[LDH + 4 * v + 3] = fmaf(w, a.w, M[LDH + 4 * v + 3]);
-                }
+                for (int c = 0; c < LDH / 4; ++c)
+                    fma_piece(acc, p.W3 + d0 * 3 * C + part * C, 3 * C, c,
+                              *reinterpret_cast<const float4 *>(mrow + 4 * c), std::integral_constant<int, RW>{});
             }
 #pragma unroll
-            for (int r = 0; r < RW; ++r) {
-                const int d = wv * RW + r;
-                float acc = p.b3[d];
-#pragma unroll
-                for (int k = 0; k < C; ++k) acc = fmaf(p.W3[d * 3 * C + k], M[k], acc);
-#pragma unroll
-                for (int k = 0; k < C; ++k) acc = fmaf(p.W3[d * 3 * C + C + k], M[LDH + k], acc);
-#pragma unroll
-                for (int k = 0; k < C; ++k) acc = fmaf(p.W3[d * 3 * C + 2 * C + k], M[2 * LDH + k], acc);
-                qb[n * D + d] = tanh_f(acc);
-            }
-            if (wv == 0) {                                   // skip concat of X (model.py:154)
-#pragma unroll
-                for (int k = D; k < LDH; ++k) Hn[n * LDH + k] = M[2 * LDH + k];
-            }
+            for (int r = 0; r < RW; ++r) qb[n * D + d0 + r] = tanh_f(acc[r]);
+        }
+        for (int i = threadIdx.x; i < nh * (LDH - D); i += NT) {   // skip concat of X (model.py:154)
+            const int n = i / (LDH - D), k = D + i % (LDH - D);
+            Hn[n * LDH + k] = H[n * LDH + k];
         }
         __syncthreads();
         for (int n = lane; n < nh; n += 64) {                // second layer: rows per wavefront
-            float q[D];
+            const int d0 = wv * RW;
+            float acc[RW];
 #pragma unroll
-            for (int k = 0; k < D; ++k) q[k] = qb[n * D + k];
+            for (int r = 0; r < RW; ++r) acc[r] = p.b4[d0 + r];
 #pragma unroll
-            for (int r = 0; r < RW; ++r) {
-                const int d = wv * RW + r;
-                float acc = p.b4[d];
+            for (int c = 0; c < D / 4; ++c) {
+                const float4 v = *reinterpret_cast<const float4 *>(qb + n * D + 4 * c);
+                const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                for (int k = 0; k < D; ++k) acc = fmaf(p.W4[d * D + k], q[k], acc);
-                Hn[n * LDH + d] = tanh_f(acc);
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < RW; ++r) acc[r] = fmaf(p.W4[(d0 + r) * D + 4 * c + j], vv[j], acc[r]);
             }
+#pragma unroll
+            for (int r = 0; r < RW; ++r) Hn[n * LDH + d0 + r] = tanh_f(acc[r]);
         }
         __syncthreads();
         pq_rows(Hn);                                         // nobody reads PQ or H in this step
@@ -530,7 +526,7 @@ inline size_t event_lds_bytes(int F, int D, int64_t cap_hits, int64_t cap_segmen
     const int ldh = (F + D + 3) & ~3, C = F + D;
     auto a4 = [](int x) { return (x + 3) & ~3; };
     const int wfl = a4(D * F) + a4(D * 2 * C) + a4(1) + a4(D * 3 * C) + a4(D * D) + 5 * a4(D);   // EvWeights::total
-    return (size_t)(cap_hits * (2 * ldh + 3 * D) + ((cap_segments + 3) & ~3) + wfl +
+    return (size_t)(cap_hits * (4 * ldh + 3 * D) + ((cap_segments + 3) & ~3) + wfl +
                     2 * (cap_hits + 1) + 6 * cap_segments) * sizeof(float);
 }
 
@@ -547,7 +543,7 @@ int run_events(const gnn_graph_t *g, const gnn_params_t *p, const int32_t *hit_p
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEventLdsMax);
         attr_done = true;
     }
-    GNN_LAUNCH_SH("k_event", (k_event<F, D>), (unsigned)n_graphs, 256, lds, s, *g, p->Win, p->bin, p->W1,
+    GNN_LAUNCH_SH("k_event", (k_event<F, D>), (unsigned)n_graphs, EvCfg<D>::NT, lds, s, *g, p->Win, p->bin, p->W1,
                   p->b1, p->W2, p->b2, p->W3, p->b3, p->W4, p->b4, hit_ptr, seg_ptr, n_iters, e_out,
                   cap_hits, cap_segments);
     return 0;
