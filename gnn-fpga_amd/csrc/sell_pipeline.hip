@@ -319,12 +319,56 @@ struct Cfg {
 // { bias[d4], W[KD+KF][d4] } sits 16-byte aligned in LDS; it is fetched with ds_read_b128
 // into registers in chunks of 8 floats before the FMAs consume it (larger chunks cost registers
 // the prefetching kernels do not have).
-template <int D4, int KD, int KF>
+template <int D4, int KD, int KF, bool PK = true>
 __device__ __forceinline__ void role_gemv(const float *w, const float *hn, const float *x,
                                           float *out)
 {
     constexpr int NW = D4 + (KD + KF) * D4;
     constexpr int CH = 8;
+#ifndef GNN_NO_GEMV_PK
+    if constexpr (PK && D4 >= 8 && D4 % 4 == 0) {
+        // wide layers (D >= 32, where 256 VGPRs are available): rows (i, i+1) of an input k are neighbours in the block, so one
+        // v_pk_fma_f32 does two of the lane's D4 FMAs per input (same order per row, same bits);
+        // the block is still fetched 16 bytes at a time, 8 floats ahead of their use
+        const f4_t *wv = reinterpret_cast<const f4_t *>(__builtin_assume_aligned(w, 16));
+        // (compiler barrier: without it the scheduler pulls the LDS reads of several blocks to
+        // the front and spills - k_input4 at D = 64 went to 3.4 KB of scratch per lane)
+        asm volatile("" ::: "memory");
+        f2_t o2[D4 / 2];
+#pragma unroll
+        for (int v = 0; v < D4 / 4; ++v) {
+            const f4_t t = wv[v];
+            o2[2 * v] = f2_t{t.x, t.y};
+            o2[2 * v + 1] = f2_t{t.z, t.w};
+        }
+        // software pipeline: the D4 weights of input k + 1 are requested before those of input k
+        // are consumed (one wave per SIMD at D = 64: nothing else hides the LDS latency)
+        f4_t cur[D4 / 4], nxt[D4 / 4];
+#pragma unroll
+        for (int v = 0; v < D4 / 4; ++v) cur[v] = wv[D4 / 4 + v];
+#pragma unroll
+        for (int k = 0; k < KD + KF; ++k) {
+            if (k + 1 < KD + KF)
+#pragma unroll
+                for (int v = 0; v < D4 / 4; ++v) nxt[v] = wv[(D4 + (k + 1) * D4) / 4 + v];
+            const float in = k < KD ? hn[k < KD ? k : 0] : x[k >= KD ? k - KD : 0];
+            const f2_t in2 = {in, in};
+#pragma unroll
+            for (int v = 0; v < D4 / 4; ++v) {
+                o2[2 * v] = f2_t{cur[v].x, cur[v].y} * in2 + o2[2 * v];
+                o2[2 * v + 1] = f2_t{cur[v].z, cur[v].w} * in2 + o2[2 * v + 1];
+            }
+#pragma unroll
+            for (int v = 0; v < D4 / 4; ++v) cur[v] = nxt[v];
+        }
+#pragma unroll
+        for (int i = 0; i < D4 / 2; ++i) {
+            out[2 * i] = o2[i].x;
+            out[2 * i + 1] = o2[i].y;
+        }
+        return;
+    }
+#endif
     const float4 *w4 = reinterpret_cast<const float4 *>(__builtin_assume_aligned(w, 16));
 #pragma unroll
     for (int c0 = 0; c0 < NW; c0 += CH) {
@@ -421,7 +465,7 @@ struct Records {
 
 // Same records, computed and stored piecewise (P|R, then Q|S, then U): shorter live ranges than
 // Records for callers that may issue the stores right away (k_iter2: its prefetch has arrived).
-template <int F, int D, bool LAST, bool XP>
+template <int F, int D, bool LAST, bool XP, bool PK = true>
 __device__ __forceinline__ void emit_to(const float *wl, const float *hn, const float *x,
                                         float *__restrict__ pr_dst, float *__restrict__ qs_dst,
                                         float *__restrict__ u_dst)
@@ -430,30 +474,30 @@ __device__ __forceinline__ void emit_to(const float *wl, const float *hn, const 
     constexpr int d4 = D / 4;
     {
         float pr[LAST ? d4 : 2 * d4];
-        role_gemv<d4, D, F>(wl + L::o_m + 0 * L::m_st, hn, x, pr);
+        role_gemv<d4, D, F, PK>(wl + L::o_m + 0 * L::m_st, hn, x, pr);
         if constexpr (XP)
 #pragma unroll
             for (int i = 0; i < d4; ++i) pr[i] = __builtin_amdgcn_exp2f(pr[i]);
-        if constexpr (!LAST) role_gemv<d4, D, F>(wl + L::o_m + 1 * L::m_st, hn, x, pr + d4);
+        if constexpr (!LAST) role_gemv<d4, D, F, PK>(wl + L::o_m + 1 * L::m_st, hn, x, pr + d4);
         store_vec<LAST ? d4 : 2 * d4>(pr_dst, pr);
     }
     {
         float qs[LAST ? d4 : 2 * d4];
-        role_gemv<d4, D, F>(wl + L::o_m + 2 * L::m_st, hn, x, qs);
+        role_gemv<d4, D, F, PK>(wl + L::o_m + 2 * L::m_st, hn, x, qs);
         if constexpr (XP)
 #pragma unroll
             for (int i = 0; i < d4; ++i) qs[i] = __builtin_amdgcn_exp2f(qs[i]);
-        if constexpr (!LAST) role_gemv<d4, D, F>(wl + L::o_m + 3 * L::m_st, hn, x, qs + d4);
+        if constexpr (!LAST) role_gemv<d4, D, F, PK>(wl + L::o_m + 3 * L::m_st, hn, x, qs + d4);
         store_vec<LAST ? d4 : 2 * d4>(qs_dst, qs);
     }
     if constexpr (!LAST) {
         float u[d4];
-        role_gemv<d4, D, F>(wl + L::o_m + 4 * L::m_st, hn, x, u);
+        role_gemv<d4, D, F, PK>(wl + L::o_m + 4 * L::m_st, hn, x, u);
         store_vec<d4>(u_dst, u);
     }
 }
 
-template <int F, int D, bool LAST, bool XP>
+template <int F, int D, bool LAST, bool XP, bool PK = true>
 __device__ __forceinline__ void emit_now(const float *wl, const float *hn, const float *x,
                                          int64_t n, int q, float *__restrict__ PRn,
                                          float *__restrict__ QSn, float *__restrict__ U,
@@ -461,9 +505,9 @@ __device__ __forceinline__ void emit_now(const float *wl, const float *hn, const
 {
     constexpr int d4 = D / 4;
     if constexpr (LAST)
-        emit_to<F, D, LAST, XP>(wl, hn, x, Pc + n * D + q * d4, Qc + n * D + q * d4, nullptr);
+        emit_to<F, D, LAST, XP, PK>(wl, hn, x, Pc + n * D + q * d4, Qc + n * D + q * d4, nullptr);
     else
-        emit_to<F, D, LAST, XP>(wl, hn, x, PRn + n * 2 * D + q * 2 * d4, QSn + n * 2 * D + q * 2 * d4,
+        emit_to<F, D, LAST, XP, PK>(wl, hn, x, PRn + n * 2 * D + q * 2 * d4, QSn + n * 2 * D + q * 2 * d4,
                                 U + n * D + q * d4);
 }
 
@@ -514,7 +558,8 @@ __global__ __launch_bounds__(256) void k_input4(const float *__restrict__ X, gnn
         for (int i = 0; i < d4; ++i) hl[i] = tanh_f(hl[i]);
         float hn[D];
         quad_allgather<d4>(hl, hn);
-        emit_now<F, D, LAST, XP>(wl, hn, x, n, q, PRn, QSn, U, Pc, Qc);
+        // (scalar-FMA form here: with the packed one the scheduler hoists LDS reads into spills)
+        emit_now<F, D, LAST, XP, false>(wl, hn, x, n, q, PRn, QSn, U, Pc, Qc);
     }
 }
 
@@ -692,9 +737,9 @@ __device__ __forceinline__ void score4(const float (*rec)[2 * D4], const float *
 {
     float part[4];
 #ifndef GNN_NO_PK
-    constexpr bool use_pk = (D4 == 2);
+    constexpr bool use_pk = (D4 == 2), use_pk_wide = (D4 >= 8 && D4 % 2 == 0);   // D >= 32: 256 VGPRs to work with
 #else
-    constexpr bool use_pk = false;   // ablation builds
+    constexpr bool use_pk = false, use_pk_wide = false;   // ablation builds
 #endif
     if constexpr (use_pk) {
         // packed fp32 (v_pk_fma_f32 / v_pk_mul_f32: two lanes of math per issue slot): the two
@@ -719,6 +764,28 @@ __device__ __forceinline__ void score4(const float (*rec)[2 * D4], const float *
         const f2_t p01 = wa * f2_t{r[0][0], r[1][0]} + wb * f2_t{r[0][1], r[1][1]};
         const f2_t p23 = wa * f2_t{r[2][0], r[3][0]} + wb * f2_t{r[2][1], r[3][1]};
         part[0] = p01.x; part[1] = p01.y; part[2] = p23.x; part[3] = p23.y;
+    } else if constexpr (use_pk_wide) {
+        // wide records (D >= 16): the same packed-fp32 form over dimension pairs
+        const f2_t one2 = {1.0f, 1.0f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f2_t pj = {0.0f, 0.0f};
+#pragma unroll
+            for (int i = 0; i < D4; i += 2) {
+                const f2_t rj = {rec[j][i], rec[j][i + 1]}, o2 = {own[i], own[i + 1]};
+                f2_t a;
+                if constexpr (XP) {
+                    a = rj * o2 + one2;
+                } else {
+                    const f2_t z = rj + o2;
+                    const f2_t ex = {__builtin_amdgcn_exp2f(z.x), __builtin_amdgcn_exp2f(z.y)};
+                    a = ex + one2;
+                }
+                const f2_t r = {__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)};
+                pj = f2_t{w2[i], w2[i + 1]} * r + pj;
+            }
+            part[j] = pj.x + pj.y;
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -742,10 +809,23 @@ __device__ __forceinline__ void score4(const float (*rec)[2 * D4], const float *
     const float e = r_f(mine + b2);
     const float e4[4] = {quad_bcast_f<0>(e), quad_bcast_f<1>(e), quad_bcast_f<2>(e),
                          quad_bcast_f<3>(e)};
+    if constexpr (use_pk_wide) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) {
+            const f2_t e2 = {e4[j], e4[j]};
 #pragma unroll
-        for (int i = 0; i < D4; ++i) acc[i] = fmaf(e4[j], rec[j][D4 + i], acc[i]);
+            for (int i = 0; i < D4; i += 2) {
+                const f2_t a2 = f2_t{rec[j][D4 + i], rec[j][D4 + i + 1]} * e2 + f2_t{acc[i], acc[i + 1]};
+                acc[i] = a2.x;
+                acc[i + 1] = a2.y;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < D4; ++i) acc[i] = fmaf(e4[j], rec[j][D4 + i], acc[i]);
+    }
 }
 
 // walk one list: the first MAXC chunks were prefetched into `pre`, the rest (rare) streams from
