@@ -150,6 +150,17 @@ def graph_struct(batch):
     return g
 
 
+def cached_graph_struct(batch):
+    """graph_struct(batch), built once per (batch, device): the tensors of a batch are never
+    replaced in place, so their device pointers are stable while the batch lives."""
+    dev = batch.X.device
+    g = getattr(batch, "_gstruct", None)
+    if g is None or batch._gstruct_dev != dev:
+        g = batch._gstruct = graph_struct(batch)
+        batch._gstruct_dev = dev
+    return g
+
+
 def params_struct(weights, F, D, flags=0):
     """weights: the ten effective (masked) tensors in state_dict order."""
     p = GnnParams()
@@ -249,10 +260,7 @@ def segclf_forward_events(batch, layout, weights, F, D, n_iters, out=None, param
     dev = batch.X.device
     if out is None:
         out = torch.empty(batch.n_segments, dtype=torch.float32, device=dev)
-    g = getattr(batch, "_gstruct", None)
-    if g is None or batch._gstruct_dev != dev:     # device pointers are stable while the batch lives
-        g = batch._gstruct = graph_struct(batch)
-        batch._gstruct_dev = dev
+    g = cached_graph_struct(batch)
     p = params if params is not None else params_struct(weights, F, D)
     _check(load().gnn_segclf_forward_events(
         ctypes.byref(g), ctypes.byref(p), _dev(layout.hit_ptr, torch.int32, "hit_ptr"),
@@ -269,7 +277,7 @@ def segclf_forward_train(batch, weights, F, D, n_iters):
     e_all = torch.empty((n_iters + 1, E), dtype=torch.float32, device=dev)
     H_all = torch.empty((n_iters + 1, N, ldh), dtype=torch.float32, device=dev)
     ws = torch.empty(workspace_bytes(N, E, F, D), dtype=torch.uint8, device=dev)
-    g = graph_struct(batch)
+    g = cached_graph_struct(batch)
     p = params_struct(weights, F, D)
     _check(load().gnn_segclf_forward_train(ctypes.byref(g), ctypes.byref(p), n_iters,
                                            e_all.data_ptr(), H_all.data_ptr(), ws.data_ptr(),
@@ -280,13 +288,18 @@ def segclf_forward_train(batch, weights, F, D, n_iters):
 def segclf_backward(batch, weights, F, D, n_iters, e_all, H_all, grad_out):
     """Gradients of the ten (effective) weight tensors, in state_dict order."""
     dev = batch.X.device
-    grads = [torch.zeros_like(w) for w in weights]
+    # one zero-filled buffer, ten views (one memset launch instead of ten)
+    flat = torch.zeros(sum(w.numel() for w in weights), dtype=torch.float32, device=dev)
+    grads, o = [], 0
+    for w in weights:
+        grads.append(flat[o:o + w.numel()].view_as(w))
+        o += w.numel()
     gs = GnnGrads()
     for name, t in zip(("Win", "bin", "W1", "b1", "W2", "b2", "W3", "b3", "W4", "b4"), grads):
         setattr(gs, name, t.data_ptr())
     need = int(load().gnn_backward_workspace_bytes(batch.n_hits, batch.n_segments, F, D))
     ws = torch.empty(need, dtype=torch.uint8, device=dev)
-    g = graph_struct(batch)
+    g = cached_graph_struct(batch)
     p = params_struct(weights, F, D)
     _check(load().gnn_segclf_backward(ctypes.byref(g), ctypes.byref(p), n_iters,
                                       _dev(e_all, torch.float32, "e_all"),

@@ -54,3 +54,47 @@ def allreduce_step(params, loss_sum, count, group=None):
             p.grad.copy_(g)
         o += n
     return mean_loss
+
+
+class GradBucket:
+    """The same step without per-parameter work: every `p.grad` is a VIEW into one flat float32
+    buffer `[all gradients | loss numerator | element count]`, so a step is zero() - backward -
+    ONE all-reduce of the buffer - one in-place divide.  Nothing is concatenated or copied back
+    and nothing synchronises with the host (the mean loss comes back as a 0-d tensor).
+
+        bucket = GradBucket(model.parameters())
+        bucket.zero(); loss_sum.backward(); mean = bucket.allreduce(loss_sum.detach(), n); opt.step()
+    """
+
+    def __init__(self, params):
+        self.params = [p for p in params]
+        if not self.params:
+            raise ValueError("no parameters")
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(n + 2, dtype=torch.float32, device=dev)
+        o = 0
+        for p in self.params:
+            if p.dtype != torch.float32 or p.device != dev:
+                raise ValueError("GradBucket needs float32 parameters on one device")
+            p.grad = self.flat[o:o + p.numel()].view_as(p)
+            o += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def allreduce(self, loss_sum, count, group=None):
+        """loss_sum: LOCAL loss sum (tensor or number); count: local element count.  After the
+        call p.grad = d(global mean loss)/dp on every rank; returns the global mean loss (0-d)."""
+        tail = self.flat[-2:]
+        if torch.is_tensor(loss_sum):
+            tail[0].copy_(loss_sum.detach().reshape(()))
+        else:
+            tail[0].fill_(float(loss_sum))
+        tail[1].fill_(float(count))            # fill kernels, not host copies: capturable
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        total = tail[1].clamp_min(1.0)
+        mean = (tail[0] / total).clone()
+        self.flat[:-2].div_(total)
+        return mean

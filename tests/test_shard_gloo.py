@@ -51,9 +51,21 @@ def _worker(rank, world, port, out_dir):
         ls.backward()
         loss_sum += float(ls)
         count += n
+    local = {k: p.grad.clone() for k, p in params.items()}
     mean_loss = shard.allreduce_step(params.values(), loss_sum, count)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), loss=mean_loss,
              **{k: p.grad.numpy() for k, p in params.items()})
+    # the flat-bucket form of the same step must give the same numbers
+    want = {k: p.grad.clone() for k, p in params.items()}
+    bucket = shard.GradBucket(params.values())
+    bucket.zero()
+    for k, p in params.items():
+        p.grad.add_(local[k])                       # what backward() would accumulate
+    mean2 = bucket.allreduce(torch.tensor(loss_sum), count)
+    assert abs(float(mean2) - mean_loss) < 1e-6
+    for k, p in params.items():
+        assert torch.allclose(p.grad, want[k], rtol=1e-6, atol=1e-9), k
+        assert p.grad.data_ptr() >= bucket.flat.data_ptr()          # still a view of the bucket
     dist.destroy_process_group()
 
 
