@@ -69,6 +69,7 @@ SIGNATURES = {
     "gnn_backward_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
     "gnn_segclf_backward": (ctypes.c_int, [ctypes.POINTER(GnnGraph), ctypes.POINTER(GnnParams),
                                            _i32, _f, _f, _f, ctypes.POINTER(GnnGrads), _f, _sz, _f]),
+    "gnn_bce_loss": (ctypes.c_int, [_f, _f, _i64, ctypes.c_float, _f, _f, _f, _f]),
     "gnn_plan_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
     "gnn_segclf_forward_plan": (ctypes.c_int, [ctypes.POINTER(GnnPlan), ctypes.POINTER(GnnParams),
                                                _i32, _f, _f, _sz, _f]),
@@ -307,6 +308,19 @@ def segclf_backward(batch, weights, F, D, n_iters, e_all, H_all, grad_out):
                                       _dev(grad_out, torch.float32, "grad_out"),
                                       ctypes.byref(gs), ws.data_ptr(), ws.numel(), _stream()))
     return grads
+
+
+def bce_loss(e, y, scale, want_grad=True):
+    """(loss [1], dLoss/de [n] or None): nn.BCELoss value and gradient in one pass (HIP)."""
+    n = e.numel()
+    dev = e.device
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    grad = torch.empty(n, dtype=torch.float32, device=dev) if want_grad else None
+    ws = torch.empty(256, dtype=torch.float32, device=dev)          # GNN_BCE_WORKSPACE_BYTES
+    _check(load().gnn_bce_loss(_dev(e, torch.float32, "scores"), _dev(y, torch.float32, "targets"), n,
+                               float(scale), loss.data_ptr(), grad.data_ptr() if want_grad else None,
+                               ws.data_ptr(), _stream()))
+    return loss, grad
 
 
 def plan_shape_supported(F, D):

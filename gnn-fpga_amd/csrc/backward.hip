@@ -420,6 +420,43 @@ int backward_t(const gnn_graph_t *g, const gnn_params_t *p, int T, const float *
     return 0;
 }
 
+// ---- fused BCE loss (value + gradient in one pass over the scores) ----------------------------
+// torch.nn.BCELoss semantics (the loss of gnn/estimator.py:57): logs clamped at -100,
+// d/de = (e - y) / max(e (1 - e), 1e-12).  Every workgroup sums a fixed set of elements in a fixed
+// order and writes one partial; k_bce_final adds the partials in index order: deterministic.
+constexpr int kBceBlocks = 256;
+
+__global__ __launch_bounds__(kBlock) void k_bce(const float *__restrict__ e, const float *__restrict__ y,
+                                                int64_t n, float scale, float *__restrict__ grad_e,
+                                                float *__restrict__ partial)
+{
+    __shared__ float red[kBlock];
+    float acc = 0.0f;
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += (int64_t)gridDim.x * kBlock) {
+        const float ej = e[j], yj = y[j];
+        const float l1 = fmaxf(logf(ej), -100.0f), l0 = fmaxf(log1pf(-ej), -100.0f);
+        acc -= yj * l1 + (1.0f - yj) * l0;
+        if (grad_e) grad_e[j] = scale * (ej - yj) / fmaxf(ej * (1.0f - ej), 1e-12f);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = kBlock / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(64) void k_bce_final(const float *__restrict__ partial, int n_partial,
+                                                  float scale, float *__restrict__ loss)
+{
+    if (threadIdx.x == 0) {
+        float s = 0.0f;
+        for (int i = 0; i < n_partial; ++i) s += partial[i];
+        loss[0] = s * scale;
+    }
+}
+
 #define BWD_FOR_EACH_SHAPE(X_) \
     X_(2, 4) X_(2, 8) X_(2, 16) X_(2, 32) X_(3, 4) X_(3, 8) X_(3, 16) X_(3, 32) X_(3, 64) X_(11, 4) X_(11, 8) \
     X_(11, 16)
@@ -427,6 +464,16 @@ int backward_t(const gnn_graph_t *g, const gnn_params_t *p, int T, const float *
 }  // namespace
 
 namespace gnn {
+
+int bce_loss(const float *e, const float *y, int64_t n, float scale, float *loss, float *grad_e,
+             float *partial, hipStream_t s)
+{
+    const int64_t need = (n + kBlock - 1) / kBlock;
+    const int blocks = (int)(need < 1 ? 1 : need < kBceBlocks ? need : kBceBlocks);
+    GNN_LAUNCH("k_bce", k_bce, blocks, kBlock, s, e, y, n, scale, grad_e, partial);
+    GNN_LAUNCH("k_bce_final", k_bce_final, 1, 64, s, partial, blocks, scale, loss);
+    return 0;
+}
 
 size_t backward_workspace_bytes(int64_t N, int64_t E, int F, int D)
 {

@@ -63,6 +63,8 @@ int sell_shape_supported(int F, int D);
 int sell_limits(int F, int D, int32_t *out4);
 
 // backward.hip
+int bce_loss(const float *e, const float *y, int64_t n, float scale, float *loss, float *grad_e,
+             float *partial, hipStream_t s);
 size_t backward_workspace_bytes(int64_t n_hits, int64_t n_segments, int F, int D);
 int backward(const gnn_graph_t *g, const gnn_params_t *p, int T, const float *e_all,
              const float *H_all, const float *grad_out, const gnn_grads_t *gr, void *ws,

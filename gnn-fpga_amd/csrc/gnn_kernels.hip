@@ -861,6 +861,15 @@ int gnn_segclf_backward(const gnn_graph_t *g, const gnn_params_t *p, int32_t n_i
                     static_cast<hipStream_t>(stream));
 }
 
+int gnn_bce_loss(const float *e, const float *y, int64_t n, float scale, float *loss_out,
+                 float *grad_e, void *workspace, void *stream)
+{
+    if (n < 0 || !loss_out || !workspace || (n > 0 && (!e || !y)))
+        return fail(GNN_ERR_BADARG, "gnn_bce_loss: bad argument");
+    return bce_loss(e, y, n, scale, loss_out, grad_e, static_cast<float *>(workspace),
+                    static_cast<hipStream_t>(stream));
+}
+
 size_t gnn_plan_workspace_bytes(int64_t n_pad, int64_t n_segments, int32_t F, int32_t D)
 {
     if (n_pad < 0 || n_segments < 0) return 0;

@@ -171,6 +171,17 @@ int gnn_segclf_forward_train(const gnn_graph_t *g, const gnn_params_t *p, int32_
  * gnn/model.py:140-156 as triggered by loss.backward() in gnn/estimator.py:58.  Adds into
  * `grads` (zero them first).  Workspace size from gnn_backward_workspace_bytes. */
 size_t gnn_backward_workspace_bytes(int64_t n_hits, int64_t n_segments, int32_t F, int32_t D);
+
+/* The reference's loss, nn.BCELoss()(scores, targets) (gnn/trainSegmentClassifier.py:164,
+ * gnn/estimator.py:57), value and gradient in one pass over the scores:
+ *   loss_out[0] = scale * sum_j -( y_j max(log e_j, -100) + (1 - y_j) max(log(1 - e_j), -100) )
+ *   grad_e[j]   = scale * (e_j - y_j) / max(e_j (1 - e_j), 1e-12)        (NULL to skip)
+ * scale = 1/n for the reference's "mean" reduction (n counts padded segments too, like the
+ * reference's mean over B x E_max), 1 for "sum".  Same clamps as torch; deterministic (fixed
+ * summation order).  workspace: GNN_BCE_WORKSPACE_BYTES of device scratch. */
+#define GNN_BCE_WORKSPACE_BYTES 1024
+int gnn_bce_loss(const float *e, const float *y, int64_t n, float scale, float *loss_out,
+                 float *grad_e, void *workspace, void *stream);
 int gnn_segclf_backward(const gnn_graph_t *g, const gnn_params_t *p, int32_t n_iters,
                         const float *e_all, const float *H_all, const float *grad_out,
                         const gnn_grads_t *grads, void *workspace, size_t workspace_bytes,

@@ -472,3 +472,55 @@ def test_wide_hidden_dims_train_and_submodules(hip, F, D, T):
     for k, p in m.named_parameters():
         gk, r = p.grad.cpu().numpy(), params[k].grad.numpy()
         assert np.abs(gk - r).max() < 1e-6 + 1e-4 * np.abs(r).max(), k
+
+
+@pytest.mark.parametrize("reduction", ["mean", "sum"])
+def test_fused_bce_loss_matches_torch(hip, reduction):
+    """gnn_fpga_amd.loss.BCELoss (one HIP pass: value + gradient) against torch.nn.BCELoss on the
+    same device tensors (fp32 reference of the same op): value, gradient, torch's clamps at
+    scores of exactly 0 and 1, empty input, 2-D [B, E] shape like the reference's batches."""
+    from gnn_fpga_amd.loss import BCELoss
+    torch.manual_seed(2)
+    dev = torch.device("cuda:0")
+    for shape in ((100003,), (4, 250), (1,)):
+        e = torch.rand(shape, device=dev)
+        y = (torch.rand(shape, device=dev) < 0.3).float()
+        flat = e.view(-1)
+        if flat.numel() > 10:
+            flat[0], flat[1], flat[2], flat[3] = 0.0, 1.0, 0.0, 1.0      # exact 0 / 1 scores
+            y.view(-1)[0:4] = torch.tensor([0.0, 1.0, 1.0, 0.0], device=dev)
+        e1 = e.clone().requires_grad_(True)
+        e2 = e.clone().requires_grad_(True)
+        l1 = BCELoss(reduction)(e1, y)
+        l2 = torch.nn.BCELoss(reduction=reduction)(e2, y)
+        (3.0 * l1).backward()
+        (3.0 * l2).backward()
+        assert l1.shape == l2.shape == ()
+        assert abs(l1.item() - l2.item()) <= 2e-6 * max(1.0, abs(l2.item()))
+        assert torch.allclose(e1.grad, e2.grad, rtol=1e-5, atol=1e-12)
+    with pytest.raises(Exception):
+        BCELoss()(torch.rand(4), torch.rand(4))                           # CPU tensors: no fallback
+
+
+def test_training_step_with_fused_loss_matches_reference(hip):
+    """Estimator.training_step (gnn/estimator.py:51-59) with both the model and the loss on the HIP
+    path: loss value and all ten gradients against the reference-generated fixture."""
+    from gnn_fpga_amd.loss import BCELoss
+    from gnn_fpga_amd.model import SegmentClassifier
+    fx = Fixture(BATCHES[0])
+    dev = torch.device("cuda:0")
+    Nmax = max(g.X.shape[0] for g in fx.graphs)
+    Emax = fx.scores.shape[1]
+    dense = [synth.to_dense(g, Nmax, Emax) for g in fx.graphs]
+    X, Ri, Ro = (torch.from_numpy(np.stack([d[i] for d in dense])).to(dev) for i in range(3))
+    y = torch.from_numpy(fx.y).to(dev)
+    m = SegmentClassifier(input_dim=fx.F, hidden_dim=fx.D, n_iters=fx.n_iters)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in fx.params.items()})
+    m.cuda().train()
+    m.zero_grad()
+    loss = BCELoss()(m([X, Ri, Ro]), y)
+    loss.backward()
+    assert abs(loss.item() - fx.loss) < 1e-6
+    for k, p in m.named_parameters():
+        g, r = p.grad.cpu().numpy(), fx.grads[k]
+        assert np.abs(g - r).max() < 1e-6 + 1e-4 * np.abs(r).max(), k
