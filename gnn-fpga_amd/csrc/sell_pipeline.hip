@@ -1142,7 +1142,12 @@ __global__ __launch_bounds__(1024) void k_iter2(
     } else {
         stage4<NT>(table, lds, L::total / 4);        // visible after the first barrier
     }
-    int tile = blockIdx.x;
+    // XCD-aware start tile: workgroups are dealt round-robin to the 8 XCDs, so XCD x takes a
+    // CONTIGUOUS run of the grid's tiles.  Neighbouring tiles are neighbouring levels of one
+    // graph: level l's PR rows are the in-window of tile l+1 and the own-P rows of tile l, its QS
+    // rows the out-window of tile l-1 and the own-Q rows of tile l - all in one L2 now.
+    int tile = (gridDim.x & 7) ? (int)blockIdx.x
+                               : (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
     if (tile >= n_tiles) return;
 
     struct Desc { int s_begin, s_end, in_lo, in_cnt, out_lo, out_cnt, sbase; };
