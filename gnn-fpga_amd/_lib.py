@@ -17,6 +17,7 @@ GNN_ERR_UNSUPPORTED = -10001
 GNN_ERR_BADARG = -10002
 GNN_ERR_WORKSPACE = -10003
 GNN_FLAG_EXP_PRODUCT = 1
+GNN_FLAG_BF16_MLP = 2
 
 _f = ctypes.c_void_p          # device pointers travel as integers
 _i32, _i64, _sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t

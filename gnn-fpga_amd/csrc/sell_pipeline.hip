@@ -512,6 +512,210 @@ __device__ __forceinline__ void emit_now(const float *wl, const float *hn, const
 }
 
 // ---------------------------------------------------------------------------------------------
+// bf16 matrix-core form of the hit update for wide hidden layers (opt-in, GNN_FLAG_BF16_MLP)
+// ---------------------------------------------------------------------------------------------
+// At D = 64 the hit update is a [16 hits x 67] x [67 x 384] product per slice: GEMM-shaped, and
+// 16x cheaper on v_mfma_f32_16x16x32_bf16 than on the fp32 vector pipe.  Operands are rounded to
+// bf16 (weights once, activations - tanh outputs in [-1, 1] and X - per use), accumulation is
+// fp32, records stay fp32.  Not bit-compatible with the fp32 path (scores move by ~1e-3, see
+// DESIGN.md), hence opt-in.
+//
+// Orientation: rows = output features (A operand = weights), columns = the 16 hits of the slice
+// (B operand = activations).  Lane l then holds, for hit l & 15, the 4 output features
+// 16 T + 4 (l >> 4) + r of tile T - i.e. 4 consecutive floats of a record row (one 16-byte store),
+// and exactly the features it must supply as B operand of the NEXT product (k-slot j of step s
+// <-> feature 16 (2 s + j / 4) + 4 (l >> 4) + j % 4), so the two chained products need no data
+// movement in between.  The weights are packed once per forward into A fragments in that k order
+// (k_pack16): one 16-byte LDS read per MFMA.  Lane maps checked by tools/mfma_layout_check.hip.
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned short bf16_rne(float f)
+{
+    const unsigned u = __float_as_uint(f);
+    return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+
+template <int F, int D>
+struct BL {                     // bf16 table layout, in 4-byte words
+    static_assert(D % 32 == 0 && F <= 8, "matrix-core path: D = 32 or 64, X in one k-step");
+    static constexpr int C = F + D, d4 = D / 4;
+    static constexpr int NT1 = D / 16, KS1 = D / 32;            // W4: tiles, k-steps
+    static constexpr int KS2 = D / 32 + 1;                      // records: hn steps + the X step
+    static constexpr int NT2N = 5 * D / 16, NT2L = 2 * D / 16;  // record tiles (all five / P, Q only)
+    static constexpr int o_t4 = 0;                              // [NT1][KS1][64 lanes][8 bf16]
+    static constexpr int o_tmn = o_t4 + NT1 * KS1 * 256;        // [NT2N][KS2][64][8]
+    static constexpr int o_tml = o_tmn + NT2N * KS2 * 256;      // [NT2L][KS2][64][8]
+    static constexpr int o_b4 = o_tml + NT2L * KS2 * 256;       // [D] f32
+    static constexpr int o_bmn = o_b4 + D;                      // [5D] f32, output order
+    static constexpr int o_bml = o_bmn + 5 * D;                 // [2D] f32
+    static constexpr int total = o_bml + 2 * D;
+    // what one kernel variant keeps in LDS: [T4 | Tm(variant) | b4 | bm(variant)]
+    template <bool LAST> static constexpr int tm_words() { return (LAST ? NT2L : NT2N) * KS2 * 256; }
+    template <bool LAST> static constexpr int lds_words() { return NT1 * KS1 * 256 + tm_words<LAST>() + D + (LAST ? 2 : 5) * D; }
+    static constexpr int tr_stride = D + 4;                     // transpose scratch row (floats)
+};
+
+// row `o` of the record product in OUTPUT order -> (weight row pointer of length C, bias, scale)
+template <int F, int D>
+__device__ __forceinline__ float record_weight(const gnn_params_t &p, bool last, int o, int k, bool bias)
+{
+    constexpr int C = F + D, d4 = D / 4;
+    int m, d;                                  // m: 0 P, 1 R, 2 Q, 3 S, 4 U (table_entry's blocks)
+    if (last) {
+        m = o < D ? 0 : 2;
+        d = o % D;
+    } else if (o >= 4 * D) {
+        m = 4;
+        d = o - 4 * D;
+    } else {
+        const int row = o / (2 * D), pos = o % (2 * D), c = pos / (2 * d4), w = pos % (2 * d4);
+        m = 2 * row + (w >= d4);
+        d = c * d4 + w % d4;
+    }
+    if (bias) return m == 0 ? kTwoLog2e * p.b1[d] : m == 4 ? p.b3[d] : 0.0f;
+    switch (m) {
+    case 0: return kTwoLog2e * p.W1[d * 2 * C + k];
+    case 1: return p.W3[d * 3 * C + k];
+    case 2: return kTwoLog2e * p.W1[d * 2 * C + C + k];
+    case 3: return p.W3[d * 3 * C + C + k];
+    default: return p.W3[d * 3 * C + 2 * C + k];
+    }
+}
+
+template <int F, int D>
+__global__ __launch_bounds__(256) void k_pack16(gnn_params_t p, unsigned *__restrict__ t16)
+{
+    using B = BL<F, D>;
+    unsigned short *h = reinterpret_cast<unsigned short *>(t16);
+    float *f = reinterpret_cast<float *>(t16);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 2 * B::o_b4; i += gridDim.x * 256) {
+        // halfword i of the fragment area: [tile][step][lane][j]
+        const int j = i & 7, l = (i >> 3) & 63, g = l >> 4, frag = i >> 9;
+        float v;
+        if (i < 2 * B::o_tmn) {                                   // W4
+            const int T = frag / B::KS1, st = frag % B::KS1;
+            v = p.W4[(16 * T + (l & 15)) * D + 16 * (2 * st + j / 4) + 4 * g + j % 4];
+        } else {
+            const bool last = i >= 2 * B::o_tml;
+            const int fr = frag - (last ? B::o_tml : B::o_tmn) / 256;
+            const int T = fr / B::KS2, st = fr % B::KS2, o = 16 * T + (l & 15);
+            int k;
+            if (st < B::KS2 - 1)
+                k = 16 * (2 * st + j / 4) + 4 * g + j % 4;      // an hn input
+            else
+                k = (8 * g + j < F) ? D + 8 * g + j : -1;       // an X input (or zero padding)
+            v = k < 0 ? 0.0f : record_weight<F, D>(p, last, o, k, false);
+        }
+        h[i] = bf16_rne(v);
+    }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 8 * D; i += gridDim.x * 256) {
+        float v;
+        if (i < D) v = p.b4[i];
+        else if (i < 6 * D) v = record_weight<F, D>(p, false, i - D, 0, true);
+        else v = record_weight<F, D>(p, true, i - 6 * D, 0, true);
+        f[B::o_b4 + i] = v;
+    }
+}
+
+// bf16 B fragment of k-step `st` from this lane's fp32 features v[t][r] (t = tile, r = 0..3)
+template <int NTILE>
+__device__ __forceinline__ bf16x8_t act_frag(const float (*v)[4], int st)
+{
+    bf16x8_t b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = (short)bf16_rne(v[2 * st + j / 4][j % 4]);
+    return b;
+}
+
+// Hit update + records of one slice on the matrix cores.  `tb`: LDS [T4 | Tm | b4 | bm] (BL);
+// `tr`: this wave's transpose scratch [16][D + 4]; acc / xv in the sweep's lane layout
+// (lane = hit * 4 + q holds dims [q d4, (q + 1) d4) of its hit).
+template <int F, int D, bool LAST, bool XP>
+__device__ __forceinline__ void mfma_tail(const unsigned *tb, float *tr, const float *acc,
+                                          const float *xv, int lane, int64_t n0,
+                                          float *__restrict__ PRn, float *__restrict__ QSn,
+                                          float *__restrict__ U, float *__restrict__ Pc,
+                                          float *__restrict__ Qc)
+{
+    using B = BL<F, D>;
+    constexpr int d4 = D / 4, NT1 = B::NT1, KS1 = B::KS1, KS2 = B::KS2;
+    constexpr int NT2 = LAST ? B::NT2L : B::NT2N;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const bf16x8_t *T4 = reinterpret_cast<const bf16x8_t *>(tb);
+    const bf16x8_t *Tm = T4 + NT1 * KS1 * 64;
+    const float *b4 = reinterpret_cast<const float *>(tb + NT1 * KS1 * 256 + B::template tm_words<LAST>());
+    const float *bm = b4 + D;
+    // 1. q = tanh(acc) and X to the matrix-core lane layout, through the wave's own scratch
+    {
+        const int hit = lane >> 2, q = lane & 3;
+#pragma unroll
+        for (int i = 0; i < d4; i += 4)
+            *reinterpret_cast<f4v *>(tr + hit * B::tr_stride + q * d4 + i) =
+                f4v{tanh_f(acc[i]), tanh_f(acc[i + 1]), tanh_f(acc[i + 2]), tanh_f(acc[i + 3])};
+        if (q == 0)
+#pragma unroll
+            for (int k = 0; k < F; ++k) tr[hit * B::tr_stride + D + k] = xv[k];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // own wave's LDS writes have landed
+    const int hit = lane & 15, g = lane >> 4;
+    float v[NT1][4];
+#pragma unroll
+    for (int t = 0; t < NT1; ++t) {
+        const f4v r = *reinterpret_cast<const f4v *>(tr + hit * B::tr_stride + 16 * t + 4 * g);
+        v[t][0] = r.x; v[t][1] = r.y; v[t][2] = r.z; v[t][3] = r.w;
+    }
+    bf16x8_t xb;                                                   // the X step's B fragment
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xb[j] = 0;
+    if (g == 0)
+#pragma unroll
+        for (int j = 0; j < F; ++j) xb[j] = (short)bf16_rne(tr[hit * B::tr_stride + D + j]);
+    // 2. hl = tanh(W4 q + b4)
+    bf16x8_t qb[KS1];
+#pragma unroll
+    for (int st = 0; st < KS1; ++st) qb[st] = act_frag<NT1>(v, st);
+#pragma unroll
+    for (int T = 0; T < NT1; ++T) {
+        f4v c = *reinterpret_cast<const f4v *>(b4 + 16 * T + 4 * g);
+#pragma unroll
+        for (int st = 0; st < KS1; ++st)
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(T4[(T * KS1 + st) * 64 + lane], qb[st], c, 0, 0, 0);
+        v[T][0] = tanh_f(c.x); v[T][1] = tanh_f(c.y); v[T][2] = tanh_f(c.z); v[T][3] = tanh_f(c.w);
+    }
+    // 3. records = Wm [hl | x] + bias, tile by tile, stored as 16-byte pieces of the record rows
+    bf16x8_t hb[KS1];
+#pragma unroll
+    for (int st = 0; st < KS1; ++st) hb[st] = act_frag<NT1>(v, st);
+    const int64_t n = n0 + hit;
+#pragma unroll
+    for (int T = 0; T < NT2; ++T) {
+        f4v c = *reinterpret_cast<const f4v *>(bm + 16 * T + 4 * g);
+#pragma unroll
+        for (int st = 0; st < KS2; ++st)
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Tm[(T * KS2 + st) * 64 + lane],
+                                                        st < KS1 ? hb[st < KS1 ? st : 0] : xb, c, 0, 0, 0);
+        const int o = 16 * T + 4 * g;                              // first of this lane's 4 outputs
+        float *dst;
+        bool expo;                                                 // a P / Q position: 2^x in XP mode
+        if constexpr (LAST) {
+            dst = (o < D ? Pc + n * D + o : Qc + n * D + (o - D));
+            expo = true;
+        } else if (o >= 4 * D) {
+            dst = U + n * D + (o - 4 * D);
+            expo = false;
+        } else {
+            dst = (o < 2 * D ? PRn + n * 2 * D + o : QSn + n * 2 * D + (o - 2 * D));
+            expo = (o % (2 * d4)) < d4;
+        }
+        if (XP && expo) {
+            c.x = __builtin_amdgcn_exp2f(c.x); c.y = __builtin_amdgcn_exp2f(c.y);
+            c.z = __builtin_amdgcn_exp2f(c.z); c.w = __builtin_amdgcn_exp2f(c.w);
+        }
+        *reinterpret_cast<f4v *>(dst) = c;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
 // input network (model.py:144-146) + records of iteration 0.  4 lanes per hit, over the padded
@@ -950,7 +1154,7 @@ __device__ __forceinline__ void sweep16(int (&c)[NC], const int32_t *__restrict_
 #endif
 // one message-passing iteration for one tile: edge scores + weighted aggregation + hit update
 // (+ records for the next pass).  One workgroup per tile; each wavefront takes 16-hit slices.
-template <int F, int D, bool LAST, bool XP>
+template <int F, int D, bool LAST, bool XP, bool BF = false>
 __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_iter(
     const float *__restrict__ X, const float *__restrict__ table,
     const int32_t *__restrict__ tiles, const int32_t *__restrict__ in_off,
@@ -958,16 +1162,28 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_iter(
     const int32_t *__restrict__ out_nbr, const float *__restrict__ PR,
     const float *__restrict__ QS, float *__restrict__ U, float *__restrict__ PRn,
     float *__restrict__ QSn, float *__restrict__ Pc, float *__restrict__ Qc, int64_t n_pad,
-    int tiles_per_xcd, int n_tiles, int ablate)
+    int tiles_per_xcd, int n_tiles, int ablate, const unsigned *__restrict__ t16)
 {
     using L = TL<F, D>;
     using G = Cfg<F, D>;
     constexpr int d4 = L::d4, NT = G::NT;
     // dynamic LDS: [weight table | record windows]; sized by the host from the plan, so batches
     // of small graphs (small windows) get several workgroups per CU
+    // (BF: [bf16 A fragments + biases | per-wave transpose scratch], see mfma_tail)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *lds = smem, *win = smem + L::total;
-    stage4<NT>(table, lds, L::total / 4);
+    if constexpr (BF) {
+        using B = BL<F, D>;
+        unsigned *tb = reinterpret_cast<unsigned *>(smem);
+        constexpr int n1 = B::NT1 * B::KS1 * 256, nm = B::template tm_words<LAST>();
+        for (int i = threadIdx.x; i < n1; i += NT) tb[i] = t16[B::o_t4 + i];
+        for (int i = threadIdx.x; i < nm; i += NT) tb[n1 + i] = t16[(LAST ? B::o_tml : B::o_tmn) + i];
+        for (int i = threadIdx.x; i < D; i += NT) tb[n1 + nm + i] = t16[B::o_b4 + i];
+        for (int i = threadIdx.x; i < (LAST ? 2 : 5) * D; i += NT)
+            tb[n1 + nm + D + i] = t16[(LAST ? B::o_bml : B::o_bmn) + i];
+    } else {
+        stage4<NT>(table, lds, L::total / 4);
+    }
 
     // XCD-affine renumbering (matters for global-mode tiles only): blockIdx is dealt round-robin
     // over the 8 XCDs, so give each residue class a contiguous range of tiles.
@@ -1040,9 +1256,10 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_iter(
     __syncthreads();
     if (slice >= 0) arrive(cur);
     float w2[d4];
+    const float *w2src = BF ? table : lds;              // BF keeps no fp32 table in LDS
 #pragma unroll
-    for (int i = 0; i < d4; ++i) w2[i] = lds[q * L::stride + L::o_w2 + i];
-    const float b2 = lds[L::o_b2];                      // scaled output bias
+    for (int i = 0; i < d4; ++i) w2[i] = w2src[q * L::stride + L::o_w2 + i];
+    const float b2 = w2src[L::o_b2];                    // scaled output bias
 
     // While `cur` is processed (LDS-mode tiles issue no VMEM instruction there) the loads of
     // `nxt` stay in flight; arrive(nxt) waits for them a whole slice after issue, and this slice's
@@ -1073,22 +1290,30 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_iter(
                 sweep<D, XP>(cur.cout, out_nbr + cur.ob + q * SLICE + i16, cur.ol, (int)n_pad, QS, q, Pn, w2, b2, acc);
             }
             // hit update: H' = tanh(W4 tanh(acc) + b4)                  (model.py:94-98,125)
-            float ql[d4], qa[D];
+            if constexpr (BF) {
+                using B = BL<F, D>;
+                float *tr = smem + B::template lds_words<LAST>() + (threadIdx.x >> 6) * 16 * B::tr_stride;
+                mfma_tail<F, D, LAST, XP>(reinterpret_cast<const unsigned *>(smem), tr, acc, xv, lane,
+                                          (int64_t)slice * SLICE, PRn, QSn, U, Pc, Qc);
+            } else {
+                float ql[d4], qa[D];
 #pragma unroll
-            for (int i = 0; i < d4; ++i) ql[i] = tanh_f(acc[i]);
-            quad_allgather<d4>(ql, qa);
-            float hl[d4];
-            role_gemv<d4, D, 0>(wl + L::o_4, qa, qa, hl);
+                for (int i = 0; i < d4; ++i) ql[i] = tanh_f(acc[i]);
+                quad_allgather<d4>(ql, qa);
+                float hl[d4];
+                role_gemv<d4, D, 0>(wl + L::o_4, qa, qa, hl);
 #pragma unroll
-            for (int i = 0; i < d4; ++i) hl[i] = tanh_f(hl[i]);
-            float hn[D];
-            quad_allgather<d4>(hl, hn);
-            if (!(ablate & 4)) rec.compute(wl, hn, xv);
+                for (int i = 0; i < d4; ++i) hl[i] = tanh_f(hl[i]);
+                float hn[D];
+                quad_allgather<d4>(hl, hn);
+                if (!(ablate & 4)) rec.compute(wl, hn, xv);
+            }
         }
         if constexpr (G::pipelined)
             if (next >= 0) arrive(nxt);
         cur = nxt;
-        if (slice >= 0 && !(ablate & 16)) rec.store(n, q, PRn, QSn, U, Pc, Qc);
+        if constexpr (!BF)
+            if (slice >= 0 && !(ablate & 16)) rec.store(n, q, PRn, QSn, U, Pc, Qc);
         slice = next;
     }
 }
@@ -1552,10 +1777,11 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_edge(
 // ---------------------------------------------------------------------------------------------
 struct Ws {
     float *table, *PRa, *PRb, *QSa, *QSb, *U, *Pc, *Qc;
+    unsigned *t16;               // bf16 A fragments + biases of the matrix-core hit update (BL)
     size_t bytes;
 };
 
-Ws carve(char *b, int64_t n_pad, int table_floats, int D)
+Ws carve(char *b, int64_t n_pad, int table_floats, int D, int t16_words = 0)
 {
     Ws w;
     size_t off = 0;
@@ -1569,8 +1795,16 @@ Ws carve(char *b, int64_t n_pad, int table_floats, int D)
     w.table = take((size_t)table_floats);
     w.PRa = take(rec); w.PRb = take(rec); w.QSa = take(rec); w.QSb = take(rec);
     w.U = take(vec); w.Pc = take(vec); w.Qc = take(vec);
+    w.t16 = reinterpret_cast<unsigned *>(take((size_t)t16_words));
     w.bytes = off;
     return w;
+}
+
+template <int F, int D>
+constexpr int t16_words()
+{
+    if constexpr (D % 32 == 0 && F <= 8) return BL<F, D>::total;
+    else return 0;
 }
 
 template <int F, int D, bool XP>
@@ -1580,7 +1814,12 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
     using L = TL<F, D>;
     using G = Cfg<F, D>;
     const int64_t Np = pl->n_pad, E = pl->n_segments;
-    Ws w = carve(ws, Np, L::total, D);
+    Ws w = carve(ws, Np, L::total, D, t16_words<F, D>());
+    constexpr bool can_bf = t16_words<F, D>() > 0;
+    const bool bf = can_bf && (p->flags & GNN_FLAG_BF16_MLP) && n_iters > 0;
+    if constexpr (can_bf)
+        if (bf && Np > 0)
+            GNN_LAUNCH("k_pack16", (k_pack16<F, D>), 64, 256, s, *p, w.t16);
     if (Np == 0 || G::pack_first)   // no hits (nothing for k_input4 to do), or a big table
         GNN_LAUNCH("k_pack", (k_pack<F, D, XP>), (L::total + 255) / 256, 256, s, *p, w.table, w.PRa, w.PRb,
                    w.QSa, w.QSb, w.U, w.Pc, w.Qc, Np);
@@ -1665,14 +1904,39 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
                     continue;
                 }
             }
-            if (t + 1 == n_iters)
+            bool launched = false;
+            if constexpr (can_bf) {
+                if (bf) {           // matrix-core hit update (bf16 operands, fp32 accumulate)
+                    using B = BL<F, D>;
+                    const size_t trw = (size_t)(G::NT / 64) * 16 * B::tr_stride;
+                    static bool bf_attr = false;
+                    if (!bf_attr) {
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter<F, D, true, XP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter<F, D, false, XP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
+                        bf_attr = true;
+                    }
+                    if (t + 1 == n_iters)
+                        GNN_LAUNCH_SH("k_iter", (k_iter<F, D, true, XP, true>), 8 * tpx, G::NT,
+                                      (B::template lds_words<true>() + trw) * 4, s, pl->X, w.table, pl->tiles,
+                                      pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PR, QS, w.U, PRn, QSn,
+                                      w.Pc, w.Qc, Np, tpx, nt, ablate, w.t16);
+                    else
+                        GNN_LAUNCH_SH("k_iter", (k_iter<F, D, false, XP, true>), 8 * tpx, G::NT,
+                                      (B::template lds_words<false>() + trw) * 4, s, pl->X, w.table, pl->tiles,
+                                      pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PR, QS, w.U, PRn, QSn,
+                                      w.Pc, w.Qc, Np, tpx, nt, ablate, w.t16);
+                    launched = true;
+                }
+            }
+            if (launched) {
+            } else if (t + 1 == n_iters)
                 GNN_LAUNCH_SH("k_iter", (k_iter<F, D, true, XP>), 8 * tpx, G::NT, it_lds, s, pl->X, w.table,
                            pl->tiles, pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PR, QS, w.U,
-                           PRn, QSn, w.Pc, w.Qc, Np, tpx, nt, ablate);
+                           PRn, QSn, w.Pc, w.Qc, Np, tpx, nt, ablate, w.t16);
             else
                 GNN_LAUNCH_SH("k_iter", (k_iter<F, D, false, XP>), 8 * tpx, G::NT, it_lds, s, pl->X, w.table,
                            pl->tiles, pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PR, QS, w.U,
-                           PRn, QSn, w.Pc, w.Qc, Np, tpx, nt, ablate);
+                           PRn, QSn, w.Pc, w.Qc, Np, tpx, nt, ablate, w.t16);
             float *t1 = PR; PR = PRn; PRn = t1;
             float *t2 = QS; QS = QSn; QSn = t2;
         }
@@ -1736,7 +2000,7 @@ int sell_limits(int F, int D, int32_t *out4)
 size_t sell_workspace_bytes(int64_t n_pad, int64_t n_segments, int F, int D)
 {
     (void)n_segments;
-#define X_(F_, D_) if (F == F_ && D == D_) return carve(nullptr, n_pad, TL<F_, D_>::total, D).bytes + 256;
+#define X_(F_, D_) if (F == F_ && D == D_) return carve(nullptr, n_pad, TL<F_, D_>::total, D, t16_words<F_, D_>()).bytes + 256;
     SELL_FOR_EACH_SHAPE(X_)
 #undef X_
     return 0;

@@ -158,6 +158,8 @@ class SegmentClassifier(nn.Module):
         self.use_plan = True      # False: per-module CSR kernels instead of the fused pipeline
         self.use_events = True    # batches of small graphs: whole forward in one launch
         self.exp_product = True   # allow GNN_FLAG_EXP_PRODUCT when the bound check passes
+        self.mlp_bf16 = False     # hidden_dim 32 / 64: hit update on the matrix cores (bf16 operands,
+                                  # fp32 accumulate; scores move by ~1e-3 - opt-in, GNN_FLAG_BF16_MLP)
         self._xp_cache = None     # (key, flag): the bound check synchronises, so it is cached
         self._w_cache = None      # (key, weights, GnnParams): rebuilt when a parameter changes
 
@@ -230,7 +232,8 @@ class SegmentClassifier(nn.Module):
             weights, pstruct = self._cached_weights()
             res = _lib.segclf_forward_plan(plan, weights, F, D, self.n_iters,
                                            workspace=self._workspace,
-                                           flags=self._exp_product_flag(plan, weights),
+                                           flags=(self._exp_product_flag(plan, weights) |
+                                                  (_lib.GNN_FLAG_BF16_MLP if self.mlp_bf16 else 0)),
                                            params=pstruct)
         else:         # CSR kernels, one per reference module (csrc/gnn_kernels.hip); traces
             res = _lib.segclf_forward(batch, self.effective_weights(), F, D, self.n_iters,

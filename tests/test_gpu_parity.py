@@ -524,3 +524,35 @@ def test_training_step_with_fused_loss_matches_reference(hip):
     for k, p in m.named_parameters():
         g, r = p.grad.cpu().numpy(), fx.grads[k]
         assert np.abs(g - r).max() < 1e-6 + 1e-4 * np.abs(r).max(), k
+
+
+TOL_BF16 = 5e-3     # bf16 operands in the hit update (GNN_FLAG_BF16_MLP): stated separately from the
+                    # fp32 path's 1e-5 ("1e-5 does not apply to bf16"); measured max 6e-4, mean 8e-5
+
+
+@pytest.mark.parametrize("F,D,T", [(3, 64, 6), (3, 32, 3), (2, 32, 2), (3, 64, 1)])
+def test_bf16_matrix_core_hit_update(hip, F, D, T):
+    """Opt-in matrix-core path for hidden_dim 32 / 64 (v_mfma_f32_16x16x32_bf16, fp32 accumulate):
+    deterministic, really a different path, and within TOL_BF16 of both the fp32 kernels and the
+    C oracle (a wrong lane map or k order in the packed weight fragments gives errors of order
+    0.1, not 1e-3; tools/mfma_layout_check.hip pins the instruction's maps with exact integers)."""
+    from gnn_fpga_amd.model import SegmentClassifier
+    torch.manual_seed(D + T)
+    graphs = [synth.layered_graph(700, 4000, F, seed=60 + i) for i in range(3)]
+    m = SegmentClassifier(input_dim=F, hidden_dim=D, n_iters=T).cuda().eval()
+    m.use_events = False
+    params = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    batch = HitGraphBatch.from_graphs(graphs).cuda()
+    with torch.no_grad():
+        e32 = m(batch)
+        m.mlp_bf16 = True
+        e16 = m(batch)
+        e16_again = m(batch)
+    torch.cuda.synchronize()
+    assert torch.equal(e16, e16_again)                         # deterministic
+    assert not torch.equal(e16, e32)                           # the flag really selects another path
+    d = (e16 - e32).abs().max().item()
+    assert d < TOL_BF16, d
+    for g, eg in zip(graphs, batch.split_scores(e16.cpu().numpy())):
+        ref = index_c.segment_classifier(g.X, g.src, g.dst, params, T)
+        assert np.abs(eg - ref).max() < TOL_BF16
