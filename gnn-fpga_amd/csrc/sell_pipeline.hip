@@ -627,6 +627,13 @@ __device__ __forceinline__ bf16x8_t act_frag(const float (*v)[4], int st)
     return b;
 }
 
+template <int F, int D, bool LAST, bool XP>
+__device__ __forceinline__ void mfma_records(const bf16x8_t *Tm, const float *bm,
+                                             const float (*v)[4], bf16x8_t xb, int lane, int64_t n0,
+                                             float *__restrict__ PRn, float *__restrict__ QSn,
+                                             float *__restrict__ U, float *__restrict__ Pc,
+                                             float *__restrict__ Qc);
+
 // Hit update + records of one slice on the matrix cores.  `tb`: LDS [T4 | Tm | b4 | bm] (BL);
 // `tr`: this wave's transpose scratch [16][D + 4]; acc / xv in the sweep's lane layout
 // (lane = hit * 4 + q holds dims [q d4, (q + 1) d4) of its hit).
@@ -682,7 +689,24 @@ __device__ __forceinline__ void mfma_tail(const unsigned *tb, float *tr, const f
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(T4[(T * KS1 + st) * 64 + lane], qb[st], c, 0, 0, 0);
         v[T][0] = tanh_f(c.x); v[T][1] = tanh_f(c.y); v[T][2] = tanh_f(c.z); v[T][3] = tanh_f(c.w);
     }
-    // 3. records = Wm [hl | x] + bias, tile by tile, stored as 16-byte pieces of the record rows
+    mfma_records<F, D, LAST, XP>(Tm, bm, v, xb, lane, n0, PRn, QSn, U, Pc, Qc);
+}
+
+// records = Wm [hl | x] + bias, tile by tile, stored as 16-byte pieces of the record rows.
+// v: this lane's features of hl in the matrix-core layout (hit = lane & 15, features
+// 16 t + 4 (lane >> 4) + r), xb: the X step's B fragment.
+template <int F, int D, bool LAST, bool XP>
+__device__ __forceinline__ void mfma_records(const bf16x8_t *Tm, const float *bm,
+                                             const float (*v)[4], bf16x8_t xb, int lane, int64_t n0,
+                                             float *__restrict__ PRn, float *__restrict__ QSn,
+                                             float *__restrict__ U, float *__restrict__ Pc,
+                                             float *__restrict__ Qc)
+{
+    using B = BL<F, D>;
+    constexpr int d4 = D / 4, NT1 = B::NT1, KS1 = B::KS1, KS2 = B::KS2;
+    constexpr int NT2 = LAST ? B::NT2L : B::NT2N;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const int hit = lane & 15, g = lane >> 4;
     bf16x8_t hb[KS1];
 #pragma unroll
     for (int st = 0; st < KS1; ++st) hb[st] = act_frag<NT1>(v, st);
@@ -720,6 +744,67 @@ __device__ __forceinline__ void mfma_tail(const unsigned *tb, float *tr, const f
 // ---------------------------------------------------------------------------------------------
 // input network (model.py:144-146) + records of iteration 0.  4 lanes per hit, over the padded
 // hit range (dummy hits have X = 0 and are never gathered).
+// BF: records on the matrix cores (bf16 operands), H0 itself stays fp32; needs k_pack and
+// k_pack16 to have run (weight table / fragments are read from global memory)
+template <int F, int D, bool LAST, bool XP>
+__global__ __launch_bounds__(256) void k_input4_bf(const float *__restrict__ X,
+                                                   const float *__restrict__ table,
+                                                   const unsigned *__restrict__ t16,
+                                                   float *__restrict__ PRn, float *__restrict__ QSn,
+                                                   float *__restrict__ U, float *__restrict__ Pc,
+                                                   float *__restrict__ Qc, int64_t n_pad)
+{
+    using L = TL<F, D>;
+    using B = BL<F, D>;
+    constexpr int d4 = L::d4, NT1 = B::NT1;
+    constexpr int nm = B::template tm_words<LAST>(), nb = (LAST ? 2 : 5) * D;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float smem_in[];
+    unsigned *tb = reinterpret_cast<unsigned *>(smem_in);           // [Tm | bm]
+    for (int i = threadIdx.x; i < nm; i += 256) tb[i] = t16[(LAST ? B::o_tml : B::o_tmn) + i];
+    for (int i = threadIdx.x; i < nb; i += 256) tb[nm + i] = t16[(LAST ? B::o_bml : B::o_bmn) + i];
+    __syncthreads();
+    const bf16x8_t *Tm = reinterpret_cast<const bf16x8_t *>(tb);
+    const float *bm = reinterpret_cast<const float *>(tb + nm);
+    float *tr = smem_in + nm + nb + (threadIdx.x >> 6) * 16 * B::tr_stride;
+    const int lane = threadIdx.x & 63, q = lane & 3;
+    for (int64_t n = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 2; n < n_pad;
+         n += (int64_t)gridDim.x * 64) {
+        float x[F], hl[d4];
+#pragma unroll
+        for (int k = 0; k < F; ++k) x[k] = X[n * F + k];
+        role_gemv<d4, 0, F, false>(table + q * L::stride + L::o_in, x, x, hl);   // in-MLP, fp32
+        {   // H0 = tanh(.) and X to the matrix-core lane layout through the wave's scratch
+            const int hit = lane >> 2;
+#pragma unroll
+            for (int i = 0; i < d4; i += 4)
+                *reinterpret_cast<f4v *>(tr + hit * B::tr_stride + q * d4 + i) =
+                    f4v{tanh_f(hl[i]), tanh_f(hl[i + 1]), tanh_f(hl[i + 2]), tanh_f(hl[i + 3])};
+            if (q == 0)
+#pragma unroll
+                for (int k = 0; k < F; ++k) tr[hit * B::tr_stride + D + k] = x[k];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int hit = lane & 15, g = lane >> 4;
+        float v[NT1][4];
+#pragma unroll
+        for (int t = 0; t < NT1; ++t) {
+            const f4v r = *reinterpret_cast<const f4v *>(tr + hit * B::tr_stride + 16 * t + 4 * g);
+            v[t][0] = r.x; v[t][1] = r.y; v[t][2] = r.z; v[t][3] = r.w;
+        }
+        bf16x8_t xb;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xb[j] = 0;
+        if (g == 0)
+#pragma unroll
+            for (int j = 0; j < F; ++j) xb[j] = (short)bf16_rne(tr[hit * B::tr_stride + D + j]);
+        // first hit of this wave's 16 (n is this lane's hit in the 4-lanes-per-hit layout)
+        const int64_t n0 = n - (lane >> 2);
+        mfma_records<F, D, LAST, XP>(Tm, bm, v, xb, lane, n0, PRn, QSn, U, Pc, Qc);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // scratch is rewritten next round
+    }
+}
+
 template <int F, int D, bool LAST, bool XP>
 __global__ __launch_bounds__(256) void k_input4(const float *__restrict__ X, gnn_params_t p,
                                                 float *__restrict__ table,
@@ -1874,7 +1959,23 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
             }
             grid2 = nt < n_cu ? nt : n_cu;
         }
-        if (!fuse_first) {
+        bool input_done = false;
+        if constexpr (can_bf) {
+            if (bf && G::pack_first) {      // records of iteration 0 on the matrix cores too
+                using B = BL<F, D>;
+                const size_t lds_in = (size_t)(B::template tm_words<false>() + 5 * D + 4 * 16 * B::tr_stride) * 4;
+                static bool in_attr = false;
+                if (!in_attr) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_input4_bf<F, D, false, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
+                    in_attr = true;
+                }
+                const int64_t g_need = (Np * 4 + 255) / 256;
+                GNN_LAUNCH_SH("k_input4", (k_input4_bf<F, D, false, XP>), (unsigned)(g_need < 512 ? g_need : 512), 256,
+                              lds_in, s, pl->X, w.table, w.t16, PR, QS, w.U, w.Pc, w.Qc, Np);
+                input_done = true;
+            }
+        }
+        if (!fuse_first && !input_done) {
             const int64_t g_need = (Np * 4 + 255) / 256;
             const unsigned g = (unsigned)(g_need < 4096 ? g_need : 4096);   // 16 workgroups per CU, grid-stride
             if (n_iters == 0)

@@ -166,8 +166,11 @@ class SellPlan:
         # small batches: shrink the tiles so that there are a few hundred workgroups to spread
         # over the CUs (a 10k-hit graph would otherwise be 10 workgroups); windows stay whole
         # levels, so this costs staging traffic that only matters once the chip is full anyway
-        if n < 512 * tile_hits:
-            tile_hits = max(64, ((n + 511) // 512 + SLICE - 1) // SLICE * SLICE)
+        # (wide shapes - no LDS windows, one workgroup per CU, a 70-100 KB weight table to stage per
+        # workgroup - want one tile per CU rather than two)
+        want = 512 if int(limits["iter_records"]) > 0 else 256
+        if n < want * tile_hits:
+            tile_hits = max(64, ((n + want - 1) // want + SLICE - 1) // SLICE * SLICE)
         ok = src >= 0
         vs, vd = src[ok], dst[ok]
         deg_in = np.bincount(vd, minlength=n)

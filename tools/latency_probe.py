@@ -6,10 +6,11 @@ import torch
 from gnn_fpga_amd import HitGraphBatch, synth
 from gnn_fpga_amd.model import SegmentClassifier
 
-def probe(name, graphs, F, D, T, reps=200, events=True):
+def probe(name, graphs, F, D, T, reps=200, events=True, bf16=False):
     torch.manual_seed(0)
     m = SegmentClassifier(input_dim=F, hidden_dim=D, n_iters=T).cuda().eval()
     m.use_events = events          # False: force the tiled pipeline (one-launch small-event path off)
+    m.mlp_bf16 = bf16              # True: hit update on the matrix cores (bf16 operands), D = 32 / 64
     b = HitGraphBatch.from_graphs(graphs).cuda()
     if not events:
         b.build_plan(D)
@@ -39,3 +40,6 @@ probe("toy2d 40 hits/144 segs (F2 D32 T10)", [synth.toy2d_graph(seed=0)], 2, 32,
 probe("c2-scale 2k hits/10k segs (F11 D8 T3)", [synth.layered_graph(2000, 10000, 11, seed=0)], 11, 8, 3)
 probe("c1-scale 1k/5k (F2 D32 T10)", [synth.layered_graph(1000, 5000, 2, seed=0)], 2, 32, 10)
 probe("c5 fp32 50k/500k (F3 D64 T6)", [synth.layered_graph(50000, 500000, 3, seed=0)], 3, 64, 6, reps=5)
+probe("c5 bf16 matrix-core hit update (F3 D64 T6)", [synth.layered_graph(50000, 500000, 3, seed=0)], 3, 64, 6, reps=5, bf16=True)
+probe("c5 x 8 graphs, bf16 hit update", [synth.layered_graph(50000, 500000, 3, seed=s) for s in range(8)], 3, 64, 6, reps=3, bf16=True)
+probe("c5 x 8 graphs, fp32", [synth.layered_graph(50000, 500000, 3, seed=s) for s in range(8)], 3, 64, 6, reps=3)
