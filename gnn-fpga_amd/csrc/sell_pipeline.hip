@@ -242,20 +242,6 @@ typedef float f4_t __attribute__((ext_vector_type(4)));
 template <int N>
 __device__ __forceinline__ void store_vec(float *__restrict__ dst, const float *src)
 {
-#ifdef GNN_NT_STORE     // experiment: streaming stores for the records
-    if constexpr (N == 1) {
-        __builtin_nontemporal_store(src[0], dst);
-    } else if constexpr (N == 2) {
-        f2_t v = {src[0], src[1]};
-        __builtin_nontemporal_store(v, reinterpret_cast<f2_t *>(dst));
-    } else {
-#pragma unroll
-        for (int i = 0; i < N / 4; ++i) {
-            f4_t v = {src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]};
-            __builtin_nontemporal_store(v, reinterpret_cast<f4_t *>(dst) + i);
-        }
-    }
-#else
     if constexpr (N == 1) {
         dst[0] = src[0];
     } else if constexpr (N == 2) {
@@ -267,7 +253,6 @@ __device__ __forceinline__ void store_vec(float *__restrict__ dst, const float *
             reinterpret_cast<float4 *>(dst)[i] =
                 make_float4(src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
     }
-#endif
 }
 
 // copy n4 float4s global -> LDS with the whole workgroup (no barrier); 8 loads in flight per
@@ -1231,12 +1216,6 @@ __device__ __forceinline__ void sweep16(int (&c)[NC], const int32_t *__restrict_
     }
 }
 
-#ifndef GNN_PIPE_A
-#define GNN_PIPE_A (!FIRST)
-#endif
-#ifndef GNN_PIPE_B
-#define GNN_PIPE_B false
-#endif
 // one message-passing iteration for one tile: edge scores + weighted aggregation + hit update
 // (+ records for the next pass).  One workgroup per tile; each wavefront takes 16-hit slices.
 template <int F, int D, bool LAST, bool XP, bool BF = false>
@@ -1705,7 +1684,7 @@ __global__ __launch_bounds__(1024) void k_iter2(
                     a_cur.Q.get(Qn);
                 }
                 const int len = __builtin_amdgcn_readfirstlane(a_cur.len);
-                sweep16<D, NC, XP, GNN_PIPE_A>(a_cur.c, in_nbr16, in_off16, slice, i16, len, bufA, q, Qn, w2, b2, acc);
+                sweep16<D, NC, XP, !FIRST>(a_cur.c, in_nbr16, in_off16, slice, i16, len, bufA, q, Qn, w2, b2, acc);
             }
             if constexpr (!LR) {
                 if (next >= 0) {
@@ -1761,7 +1740,7 @@ __global__ __launch_bounds__(1024) void k_iter2(
                     b_cur.P.get(Pn);
                 }
                 const int len = __builtin_amdgcn_readfirstlane(b_cur.len);
-                sweep16<D, NC, XP, GNN_PIPE_B>(b_cur.c, out_nbr16, out_off16, slice, i16, len, bufB, q, Pn, w2, b2, acc);
+                sweep16<D, NC, XP, false>(b_cur.c, out_nbr16, out_off16, slice, i16, len, bufB, q, Pn, w2, b2, acc);
             }
             // the next slice's registers arrive here (in flight during the sweep); doing it before
             // the hit update keeps the two register sets from overlapping with the MLP's
