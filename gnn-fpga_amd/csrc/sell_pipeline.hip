@@ -568,9 +568,22 @@ __device__ __forceinline__ float record_weight(const gnn_params_t &p, bool last,
 }
 
 template <int F, int D>
-__global__ __launch_bounds__(256) void k_pack16(gnn_params_t p, unsigned *__restrict__ t16)
+__global__ __launch_bounds__(256) void k_pack16(gnn_params_t p, unsigned *__restrict__ t16,
+                                                float *PRa, float *PRb, float *QSa, float *QSb,
+                                                int64_t n_pad, int xp)
 {
     using B = BL<F, D>;
+    if (blockIdx.x == 0 && threadIdx.x < 2 * D) {       // bf16 NULL records (cf. write_null_rows)
+        constexpr int d4 = D / 4;
+        const int t = threadIdx.x, c = t / (2 * d4), w = t % (2 * d4);
+        float pv = (w < d4) ? kTwoLog2e * p.b1[c * d4 + w] : 0.0f;
+        if (xp && w < d4) pv = __builtin_amdgcn_exp2f(pv);
+        const float qv = (xp && w < d4) ? 1.0f : 0.0f;
+        unsigned short *a = reinterpret_cast<unsigned short *>(PRa), *b = reinterpret_cast<unsigned short *>(PRb);
+        unsigned short *cq = reinterpret_cast<unsigned short *>(QSa), *dq = reinterpret_cast<unsigned short *>(QSb);
+        a[n_pad * 2 * D + t] = b[n_pad * 2 * D + t] = bf16_rne(pv);
+        cq[n_pad * 2 * D + t] = dq[n_pad * 2 * D + t] = bf16_rne(qv);
+    }
     unsigned short *h = reinterpret_cast<unsigned short *>(t16);
     float *f = reinterpret_cast<float *>(t16);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < 2 * B::o_b4; i += gridDim.x * 256) {
@@ -720,7 +733,16 @@ __device__ __forceinline__ void mfma_records(const bf16x8_t *Tm, const float *bm
             c.x = __builtin_amdgcn_exp2f(c.x); c.y = __builtin_amdgcn_exp2f(c.y);
             c.z = __builtin_amdgcn_exp2f(c.z); c.w = __builtin_amdgcn_exp2f(c.w);
         }
-        *reinterpret_cast<f4v *>(dst) = c;
+        if (!LAST && o < 4 * D) {
+            // gather records travel as bf16 (row = 2D halfwords, same position order): half the
+            // bytes per list step, half the registers per record group
+            unsigned *row = reinterpret_cast<unsigned *>(o < 2 * D ? PRn : QSn) + n * D + (o % (2 * D)) / 2;
+            *reinterpret_cast<uint2 *>(row) =
+                make_uint2((unsigned)bf16_rne(c.x) | ((unsigned)bf16_rne(c.y) << 16),
+                           (unsigned)bf16_rne(c.z) | ((unsigned)bf16_rne(c.w) << 16));
+        } else {
+            *reinterpret_cast<f4v *>(dst) = c;
+        }
     }
 }
 
@@ -997,6 +1019,44 @@ struct Recs {
     }
 };
 
+// bf16 records (matrix-core path): a lane's piece of a record is D/4 dwords, each two bf16
+// ([P pairs | R pairs]); kept packed until scored, so a record group is half the registers of the
+// fp32 form and the sweep can hold two groups (the next one in flight while this one is scored).
+__device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xFFFF0000u); }
+
+template <int D>
+struct Recs16 {
+    unsigned r[4][D / 4];
+    __device__ __forceinline__ void read(int cur, const unsigned *REC, int q)
+    {
+        constexpr int d4 = D / 4;
+        const int nb[4] = {quad_bcast_i<0>(cur), quad_bcast_i<1>(cur), quad_bcast_i<2>(cur),
+                           quad_bcast_i<3>(cur)};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(REC + (int64_t)nb[j] * D + q * d4);
+#pragma unroll
+            for (int v = 0; v < d4 / 4; ++v) {
+                const uint4 t = src[v];
+                r[j][4 * v] = t.x; r[j][4 * v + 1] = t.y; r[j][4 * v + 2] = t.z; r[j][4 * v + 3] = t.w;
+            }
+        }
+    }
+    // this lane's piece of record j as floats: [P(d4) | R(d4)]
+    __device__ __forceinline__ void unpack(float (*out)[2 * (D / 4)]) const
+    {
+        constexpr int d4 = D / 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < d4; ++i) {
+                out[j][2 * i] = bf_lo(r[j][i]);
+                out[j][2 * i + 1] = bf_hi(r[j][i]);
+            }
+    }
+};
+
 // Score the 4 segments of a chunk and add their weighted R|S halves.
 //   part_j = sum over this lane's dims of w2'_i r(P_i + Q_i)       (4 partial sums per lane)
 //   a 4x4 transpose-add inside the quad leaves lane j with the full pre-activation of segment j,
@@ -1128,6 +1188,45 @@ __device__ __forceinline__ void sweep(const int *pre, const int32_t *__restrict_
     for (int k = 4 * MAXC; k < len; k += 4) {
         a.read(fix(lst[k * SLICE], len - k), REC, q);
         score4<d4, XP>(a.r, own, w2, b2, q, acc);
+    }
+}
+
+// the same walk over bf16 records, software-pipelined over the step groups
+template <int D, bool XP>
+__device__ __forceinline__ void sweep_r16(const int *pre, const int32_t *__restrict__ lst, int len,
+                                          int null_idx, const unsigned *REC, int q, const float *own,
+                                          const float *w2, float b2, float *acc)
+{
+    constexpr int d4 = D / 4;
+    if (len <= 0) return;
+    auto fix = [&](int cur, int rem) {
+        const int lim = rem < 4 ? rem : 4;
+        return (q < lim) ? cur : null_idx;
+    };
+    auto index_of = [&](int c) {                 // list entries of group c (4 steps)
+        int cur = 0;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i)
+            if (c == i) cur = pre[i];
+        if (c >= MAXC) cur = lst[4 * c * SLICE];
+        return fix(cur, len - 4 * c);
+    };
+    const int ng = (len + 3) >> 2;
+    Recs16<D> a, b;
+    a.read(index_of(0), REC, q);
+    for (int c = 0; c < ng; c += 2) {
+        if (c + 1 < ng) b.read(index_of(c + 1), REC, q);
+        {
+            float f[4][2 * d4];
+            a.unpack(f);
+            score4<d4, XP>(f, own, w2, b2, q, acc);
+        }
+        if (c + 1 < ng) {
+            if (c + 2 < ng) a.read(index_of(c + 2), REC, q);
+            float f[4][2 * d4];
+            b.unpack(f);
+            score4<d4, XP>(f, own, w2, b2, q, acc);
+        }
     }
 }
 
@@ -1266,7 +1365,8 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_iter(
     struct Pre {
         int il, ol, ib, ob;          // list lengths and offsets: wave-uniform (SGPRs)
         int cin[MAXC], cout[MAXC];
-        AVec<d4> Pn, Qn, acc;
+        AVec<BF ? d4 / 2 : d4> Pn, Qn;      // BF: bf16 pairs
+        AVec<d4> acc;
         AVec<F> x;
     };
     auto prefetch = [&](Pre &p, int slice) {
@@ -1289,8 +1389,13 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_iter(
 #undef GNN_PF
         static_assert(MAXC == 6, "prefetch is written out for 6 chunks");
         const int64_t n = (int64_t)slice * SLICE + i16;
-        p.Pn.load(PR + n * 2 * D + q * 2 * d4);      // own P chunk
-        p.Qn.load(QS + n * 2 * D + q * 2 * d4);      // own Q chunk
+        if constexpr (BF) {                          // bf16 rows: D dwords per hit
+            p.Pn.load(PR + n * D + q * d4);
+            p.Qn.load(QS + n * D + q * d4);
+        } else {
+            p.Pn.load(PR + n * 2 * D + q * 2 * d4);  // own P chunk
+            p.Qn.load(QS + n * 2 * D + q * 2 * d4);  // own Q chunk
+        }
         p.acc.load(U + n * D + q * d4);              // W3[:, 2C:] H_n + b3
         p.x.load(X + n * F);                         // skip concat input (model.py:154)
     };
@@ -1343,8 +1448,24 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_iter(
             asm volatile("" : "+v"(woff));
             const float *wl = lds + woff;
             float acc[d4], Pn[d4], Qn[d4], xv[F];
-            cur.acc.get(acc); cur.Pn.get(Pn); cur.Qn.get(Qn); cur.x.get(xv);
+            cur.acc.get(acc); cur.x.get(xv);
+            if constexpr (BF) {
+                float pp[d4 / 2], qq[d4 / 2];
+                cur.Pn.get(pp); cur.Qn.get(qq);
+#pragma unroll
+                for (int i = 0; i < d4 / 2; ++i) {
+                    Pn[2 * i] = bf_lo(__float_as_uint(pp[i])); Pn[2 * i + 1] = bf_hi(__float_as_uint(pp[i]));
+                    Qn[2 * i] = bf_lo(__float_as_uint(qq[i])); Qn[2 * i + 1] = bf_hi(__float_as_uint(qq[i]));
+                }
+            } else {
+                cur.Pn.get(Pn); cur.Qn.get(Qn);
+            }
             if (ablate & 2) {
+            } else if constexpr (BF) {
+                sweep_r16<D, XP>(cur.cin, in_nbr + cur.ib + q * SLICE + i16, cur.il, (int)n_pad,
+                                 reinterpret_cast<const unsigned *>(PR), q, Qn, w2, b2, acc);
+                sweep_r16<D, XP>(cur.cout, out_nbr + cur.ob + q * SLICE + i16, cur.ol, (int)n_pad,
+                                 reinterpret_cast<const unsigned *>(QS), q, Pn, w2, b2, acc);
             } else if (G::it_rec > 0 && mode) {
                 // segments ending here: P[start] + Q[n], adds e * R[start]; then starting here
                 sweep<D, XP>(cur.cin, in_nbr + cur.ib + q * SLICE + i16, cur.il, in_cnt, winA, q, Qn, w2, b2, acc);
@@ -1883,7 +2004,8 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
     const bool bf = can_bf && (p->flags & GNN_FLAG_BF16_MLP) && n_iters > 0;
     if constexpr (can_bf)
         if (bf && Np > 0)
-            GNN_LAUNCH("k_pack16", (k_pack16<F, D>), 64, 256, s, *p, w.t16);
+            GNN_LAUNCH("k_pack16", (k_pack16<F, D>), 64, 256, s, *p, w.t16, w.PRa, w.PRb, w.QSa, w.QSb, Np,
+                       XP ? 1 : 0);
     if (Np == 0 || G::pack_first)   // no hits (nothing for k_input4 to do), or a big table
         GNN_LAUNCH("k_pack", (k_pack<F, D, XP>), (L::total + 255) / 256, 256, s, *p, w.table, w.PRa, w.PRb,
                    w.QSa, w.QSb, w.U, w.Pc, w.Qc, Np);

@@ -58,8 +58,9 @@ typedef struct gnn_params {
 /* hidden_dim 32 / 64 only (ignored elsewhere): run the hit update (gnn/model.py:120-125, and the
  * per-hit halves of the next edge / node layers) on the matrix cores with bf16 operands and fp32
  * accumulation (v_mfma_f32_16x16x32_bf16).  Weights are rounded to bf16 once per forward,
- * activations per use; the stored records and everything per segment stay fp32.  NOT within the
- * 1e-5 parity bound of the fp32 path: scores move by ~1e-3 (tests state the bound). */
+ * activations per use; the per-hit gather records travel as bf16, everything per segment is
+ * computed in fp32.  NOT within the 1e-5 parity bound of the fp32 path: scores move by ~1e-3
+ * (tests state the bound). */
 #define GNN_FLAG_BF16_MLP 2
 
 /* One block-diagonal batch of hit graphs in index form (replaces the dense Ri/Ro of
