@@ -98,10 +98,17 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run "
                          "--nproc-per-node %d" % (args.gpus, world, args.gpus))
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # GNN_BENCH_REHEARSE=1: rehearsal of the N > 1 code path on a box with fewer GPUs than ranks
+    # (ranks share devices, gloo instead of RCCL); the numbers of such a run mean nothing
+    rehearse = os.environ.get("GNN_BENCH_REHEARSE") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from gnn_fpga_amd import HitGraphBatch, _lib, synth
     from gnn_fpga_amd.model import SegmentClassifier
