@@ -28,11 +28,13 @@
 // per lane role in consumption order (table_entry; 2.6 KB at F=3, D=8) and live in LDS; the 4
 // roles read 4 distinct addresses per instruction (broadcast, conflict-free).
 //
-// Kernels: k_input4 (input network, first records, packs the weight table), k_iter2 (persistent
-// phase-split iteration kernel: the fast path, see its comment), k_iter (general iteration
-// kernel: any supported shape, global-gather tiles), k_edge (final edge pass), k_pack (table only,
-// for batches without hits).  Activation scales are folded into the weights and an optional
-// exp-product mode trades v_exp for a multiply (score4).
+// Kernels: k_iter2 (persistent phase-split iteration kernel: the fast path, see its comment; its
+// FIRST variant also runs the input network, so the fast path is T launches of k_iter2 + k_edge),
+// k_iter (general iteration kernel: any supported shape, global-gather tiles; with BF the hit
+// update runs on the matrix cores and the records travel as bf16, see mfma_tail), k_input4
+// (input network + first records where the first iteration cannot be fused), k_edge (final edge
+// pass), k_pack / k_pack16 (weight tables).  Activation scales are folded into the weights and an
+// optional exp-product mode trades v_exp for a multiply (score4).
 //
 // LDS-staged windows: plan.py orders hits by (graph, topological level) and cuts them into
 // tiles of <= 1280 hits (smaller for small batches), one workgroup each.  All start hits of a tile's incoming segments lie
