@@ -295,11 +295,11 @@ struct Cfg {
     // D >= 32 sits at the 256-register cap: the allocator parks values in AGPRs there.
     static constexpr bool pipelined = (D <= 8 && F <= 3) || (D == 4);
     // shapes whose persistent phase-split kernel (k_iter2) builds with zero scratch / AGPRs
-    static constexpr bool iter2 = (D <= 8 && F <= 3);
+    static constexpr bool iter2 = (D <= 8);
     // big weight tables are packed once by k_pack and copied, not rebuilt per workgroup
     static constexpr bool pack_first = (TL<F, D>::total > 4096);
     // ... and whose first-iteration variant (input network fused in, FIRST) does as well
-    static constexpr bool fuse_first = iter2 && !(F == 2 && D == 8);
+    static constexpr bool fuse_first = iter2 && F <= 3 && !(F == 2 && D == 8);
 };
 
 // out[i] = bias[i] + sum_k W[k][i] * in[k]  for this lane's d4 rows.  The block
@@ -1665,7 +1665,10 @@ __global__ __launch_bounds__(1024) void k_iter2(
 
     // ---- per-slice prefetch (one slice ahead), split by phase -------------------------------------
     struct PreA0 { int len; int c[NC]; AVec<d4> Q, U; };            // in-list, own Q, acc init
-    struct PreB0 { int len; int c[NC]; AVec<d4> P; AVec<F> x; };     // out-list, own P, X row
+    // wide X rows (F = 11, the muon schema) are not prefetched a slice ahead - two sets of F
+    // registers do not fit - but read at the start of the round that uses them (XPRE = false)
+    constexpr bool XPRE = F <= 4;
+    struct PreB0 { int len; int c[NC]; AVec<d4> P; AVec<XPRE ? F : 0> x; };   // out-list, own P, X row
     struct PreX { int len; int c[NC]; AVec<F> x; };                  // FIRST: own values come from x
     using PreA = std::conditional_t<FIRST, PreX, PreA0>;
     using PreB = std::conditional_t<FIRST, PreX, PreB0>;
@@ -1702,7 +1705,7 @@ __global__ __launch_bounds__(1024) void k_iter2(
         static_assert(NC == 3, "prefetch is written out for 3 words (24 steps)");
         const int64_t n0 = (int64_t)slice * SLICE;
         if constexpr (!FIRST) p.P.load_s(PR + n0 * 2 * D, lo_rec);
-        p.x.load_s(X + n0 * F, lo_x);
+        if constexpr (XPRE || FIRST) p.x.load_s(X + n0 * F, lo_x);
     };
     auto arriveA = [&](PreA &p) {
         a_wait_all();
@@ -1718,7 +1721,7 @@ __global__ __launch_bounds__(1024) void k_iter2(
         a_wait_all();
         a_fence(p.c);
         if constexpr (!FIRST) p.P.fence();
-        p.x.fence();
+        if constexpr (XPRE || FIRST) p.x.fence();
     };
 
     // Partial sums of the (at most MAXR) slices a wavefront owns in a tile stay in registers
@@ -1848,7 +1851,13 @@ __global__ __launch_bounds__(1024) void k_iter2(
             if (slice >= 0) {
                 float Pn[d4];
                 acc_get(r, acc);
-                b_cur.x.get(xv);
+                if constexpr (XPRE || FIRST) {
+                    b_cur.x.get(xv);
+                } else {                                   // plain loads, consumed after the sweep
+                    const float *xr = X + ((int64_t)__builtin_amdgcn_readfirstlane(slice) * SLICE + i16) * F;
+#pragma unroll
+                    for (int k = 0; k < F; ++k) xv[k] = xr[k];
+                }
                 if constexpr (FIRST) {                 // own P from the hit's X row
                     int woff = q * L::stride;
                     asm volatile("" : "+v"(woff));
