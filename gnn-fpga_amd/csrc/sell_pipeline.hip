@@ -1949,22 +1949,39 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_edge(
         __syncthreads();
     }
     const float b2 = W2[D];
-    for (int j = e0 + (int)threadIdx.x; j < e1; j += NT) {
-        float p[D], qq[D];
-        if (G::ed_rec > 0 && mode) {
-            const unsigned w = (unsigned)sd16[j];           // both window-relative endpoints
-            load_vec<D>(winA + (w & 0xFFFFu) * D, p);
-            load_vec<D>(winB + (w >> 16) * D, qq);
-        } else {
-            const int s = src[j], d = dst[j];
-            load_vec<D>(Pc + (int64_t)s * D, p);
-            load_vec<D>(Qc + (int64_t)d * D, qq);
-        }
+    auto score = [&](const float *p, const float *qq) {
         float acc = b2;
 #pragma unroll
         for (int k = 0; k < D; ++k)
             acc = fmaf(W2[k], XP ? __builtin_amdgcn_rcpf(fmaf(p[k], qq[k], 1.0f)) : r_f(p[k] + qq[k]), acc);
-        e[j] = r_f(acc);
+        return r_f(acc);
+    };
+    if (G::ed_rec > 0 && mode) {
+        // LDS mode: a lane's endpoint words are requested 8 at a time (one round trip to memory
+        // per 8 segments instead of one per segment), then scored from the LDS windows
+        constexpr int B8 = 8;
+        for (int j0 = e0 + (int)threadIdx.x; j0 < e1; j0 += B8 * NT) {
+            unsigned w[B8];
+#pragma unroll
+            for (int u = 0; u < B8; ++u) w[u] = (j0 + u * NT < e1) ? (unsigned)sd16[j0 + u * NT] : 0u;
+#pragma unroll
+            for (int u = 0; u < B8; ++u) {
+                if (j0 + u * NT < e1) {
+                    float p[D], qq[D];
+                    load_vec<D>(winA + (w[u] & 0xFFFFu) * D, p);
+                    load_vec<D>(winB + (w[u] >> 16) * D, qq);
+                    e[j0 + u * NT] = score(p, qq);
+                }
+            }
+        }
+    } else {
+        for (int j = e0 + (int)threadIdx.x; j < e1; j += NT) {
+            float p[D], qq[D];
+            const int s = src[j], d = dst[j];
+            load_vec<D>(Pc + (int64_t)s * D, p);
+            load_vec<D>(Qc + (int64_t)d * D, qq);
+            e[j] = score(p, qq);
+        }
     }
 }
 
