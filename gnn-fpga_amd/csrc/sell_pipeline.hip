@@ -1530,7 +1530,7 @@ __global__ __launch_bounds__(1024) void k_iter2(
     const int32_t *__restrict__ sched_b, const float *__restrict__ PR,
     const float *__restrict__ QS, float *__restrict__ U, float *__restrict__ PRn,
     float *__restrict__ QSn, float *__restrict__ Pc, float *__restrict__ Qc, int64_t n_pad,
-    int n_tiles, int capA, int capB)
+    int n_tiles, int capA, int capB, int xbuf_floats)
 {
     using L = TL<F, D>;
     constexpr int d4 = L::d4, NT = 1024, NWV = NT / 64, NC = 3;   // NC words = 24 list steps
@@ -1551,6 +1551,37 @@ __global__ __launch_bounds__(1024) void k_iter2(
         if (blockIdx.x == 0)
             write_null_rows<F, D, XP>(p, PRn, const_cast<float *>(PR), QSn, const_cast<float *>(QS),
                                       U, Pc, Qc, n_pad);
+        if constexpr (D == 8) {
+            // A fragments (fp32, v_mfma_f32_16x16x4_f32) of the window products, see compute_window:
+            // mt[0..64)        H0:   lane (row, g) -> Win[row][g]              (row < 8, g < F)
+            // mt[64 + 256 M + 64 s + lane]  records M (0: [P|R], 1: [Q|S]), k-step s:
+            //                   lane (row = record position, g) -> weight of input slot (s, g):
+            //                   g = 0: H0[s], g = 1: H0[4 + s], g = 2: x[s], g = 3: none
+            // mb[0..16) H0 bias (bin | 0), mb[16 + 16 M + row] record biases
+            float *mt = xbuf + xbuf_floats, *mb = mt + 64 + 2 * 256;
+            constexpr int C = F + D;
+            for (int i = tid; i < 64 + 2 * 256 + 48; i += NT) {
+                float v = 0.0f;
+                if (i < 64) {
+                    const int row = i & 15, g = i >> 4;
+                    if (row < 8 && g < F) v = p.Win[row * F + g];
+                } else if (i < 64 + 512) {
+                    const int j = i - 64, M = j >> 8, st = (j >> 6) & 3, row = j & 15, g = (j >> 4) & 3;
+                    const int k = g == 0 ? st : g == 1 ? 4 + st : (g == 2 && st < F) ? D + st : -1;
+                    const int c = row >> 2, w = row & 3, d = 2 * c + (w & 1);
+                    if (k >= 0)
+                        v = (w < 2) ? kTwoLog2e * p.W1[d * 2 * C + M * C + k] : p.W3[d * 3 * C + M * C + k];
+                } else {
+                    const int j = i - 64 - 512;
+                    if (j < 8) v = p.bin[j];
+                    else if (j >= 16 && j < 32) {                   // [P|R] biases: P = scaled b1
+                        const int row = j - 16, c = row >> 2, w = row & 3;
+                        if (w < 2) v = kTwoLog2e * p.b1[2 * c + w];
+                    }
+                }
+                (i < 64 + 512 ? mt : mb - 64 - 512)[i] = v;
+            }
+        }
     } else {
         stage4<NT>(table, lds, L::total / 4);        // visible after the first barrier
     }
@@ -1618,7 +1649,8 @@ __global__ __launch_bounds__(1024) void k_iter2(
     // The X rows of a window (cnt * F floats, 12 KB) arrive by LDS-DMA one phase ahead, like the
     // record windows of the later iterations; between the phases every quad turns rows into
     // records: H0 = [tanh(Win x + bin) | x] (model.py:144-146), then [P | R] (M = 0) or [Q | S]
-    // (M = 1) with the same role_gemv blocks k_input4 / emit_now use - same bits.
+    // (M = 1): at D = 8 as two small fp32 matrix-core products per 16 hits, else with the
+    // role_gemv blocks k_input4 / emit_now use.
     auto xstage_issue = [&](int lo, int cnt) {
         const int pieces = (cnt * F + 63) / 64;                        // 256-byte pieces
         unsigned lb = (unsigned)lane * 4u;
@@ -1640,6 +1672,47 @@ __global__ __launch_bounds__(1024) void k_iter2(
         constexpr int M = decltype(which)::value;
         a_wait_all();                                  // this wave's DMA pieces have landed
         __syncthreads();                               // ... and everybody else's
+        if constexpr (D == 8) {
+            // On the matrix cores, exact fp32 (v_mfma_f32_16x16x4_f32 is a k-ordered fmaf chain):
+            // rows = the 16 floats of a record in LDS position order, columns = 16 window hits.
+            // Lane l supplies input slot l >> 4 of hit l & 15 per k-step and receives positions
+            // 4 (l >> 4) .. + 3 of that hit's record - one 16-byte LDS store.  5 MFMAs per 16 hits
+            // instead of ~100 vector instructions per lane.
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            const float *mt = xbuf + xbuf_floats, *mb = mt + 64 + 2 * 256;
+            const int hit = lane & 15, g = lane >> 4;
+            const float a0 = mt[lane];
+            float ar[4];
+#pragma unroll
+            for (int st = 0; st < 4; ++st) ar[st] = mt[64 + 256 * M + 64 * st + lane];
+            const f4v bias0 = *reinterpret_cast<const f4v *>(mb + 4 * g);
+            const f4v biasr = *reinterpret_cast<const f4v *>(mb + 16 + 16 * M + 4 * g);
+            for (int h0i = wv * 16; h0i < cnt; h0i += NWV * 16) {
+                const int h = h0i + hit;
+                const bool live = h < cnt;
+                float xs[F];
+#pragma unroll
+                for (int k = 0; k < F; ++k) xs[k] = live ? xbuf[h * F + k] : 0.0f;
+                float b0 = 0.0f;
+#pragma unroll
+                for (int k = 0; k < F; ++k) b0 = (g == k) ? xs[k] : b0;
+                f4v hq = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, bias0, 0, 0, 0);
+                const float hh[4] = {tanh_f(hq.x), tanh_f(hq.y), tanh_f(hq.z), tanh_f(hq.w)};
+                f4v c = biasr;
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const float b = g < 2 ? hh[st] : (g == 2 && st < F) ? xs[st < F ? st : 0] : 0.0f;
+                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[st], b, c, 0, 0, 0);
+                }
+                if constexpr (XP) {                    // positions 4g, 4g+1 are P (Q) entries
+                    c.x = __builtin_amdgcn_exp2f(c.x);
+                    c.y = __builtin_amdgcn_exp2f(c.y);
+                }
+                if (live) *reinterpret_cast<f4v *>(buf + h * 2 * D + 4 * g) = c;
+            }
+            put_null(buf, cnt, which);
+            return;
+        }
         for (int h = tid >> 2; h < cnt; h += NT / 4) {
             int woff = q * L::stride;
             asm volatile("" : "+v"(woff));
@@ -2054,7 +2127,7 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
         // otherwise the general kernel
         bool use2 = false, fuse_first = false;
         size_t it2_lds = 0, it2_lds_first = 0;
-        int capA = 0, capB = 0, grid2 = 0;
+        int capA = 0, capB = 0, grid2 = 0, xbuf_floats = 0;
         if constexpr (G::iter2) {
             // window buffers in whole 1-KiB DMA pieces (= 128 / D records) plus one piece that
             // holds the NULL record and absorbs the last piece's overrun
@@ -2069,7 +2142,9 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
             if (it2_lds > (size_t)G::lds_bytes) use2 = false;
             // first iteration fused with the input network: + one buffer of X rows (256-byte pieces)
             const int64_t xfl = ((capa > capb ? capa : capb) * F + 63) / 64 * 64;
-            it2_lds_first = it2_lds + (size_t)xfl * sizeof(float);
+            xbuf_floats = (int)xfl;
+            // + the fp32 A fragments / biases of the matrix-core window products (D = 8)
+            it2_lds_first = it2_lds + (size_t)(xfl + (D == 8 ? 64 + 512 + 48 : 0)) * sizeof(float);
             // (exp-product mode only: the plain-exp variant of the fused kernel does not fit the
             // register budget without spills, and it is the rarely taken fallback anyway)
             fuse_first = G::fuse_first && XP && use2 && n_iters >= 2 && it2_lds_first <= (size_t)G::lds_bytes &&
@@ -2121,7 +2196,7 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
     GNN_LAUNCH_SH("k_iter2", (k_iter2<F, D, LAST_, XP, FIRST_>), grid2, 1024, LDS_, s, pl->X, w.table, *p, \
                   w.table, pl->tiles, pl->in_off, pl->in_off16, pl->in_nbr16, pl->out_off,             \
                   pl->out_off16, pl->out_nbr16, pl->sched_a, pl->sched_b, PR, QS, w.U, PRn, QSn, w.Pc,  \
-                  w.Qc, Np, nt, capA, capB)
+                  w.Qc, Np, nt, capA, capB, xbuf_floats)
                     if (XP && t == 0 && fuse_first) {
                         if constexpr (XP && G::fuse_first) GNN_IT2(false, true, it2_lds_first);
                     } else if (t + 1 == n_iters)
