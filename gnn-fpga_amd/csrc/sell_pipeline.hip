@@ -1506,6 +1506,78 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_iter(
 }
 
 // ---------------------------------------------------------------------------------------------
+// exact-fp32 matrix-core products of k_iter2 (D = 8): v_mfma_f32_16x16x4_f32 is a k-ordered fmaf
+// chain, so moving the per-hit MLPs there changes no tolerance - and frees the vector pipe.
+// ---------------------------------------------------------------------------------------------
+// Orientation as in mfma_tail: rows = 16 output positions (A = weights), columns = 16 hits
+// (B = activations); lane l supplies ONE input value per k-step for hit l & 15 (input slot
+// l >> 4 of that step) and receives output rows 4 (l >> 4) .. + 3.  With the 8 hit features
+// living as rows 0..7 of such a result (lane groups 0 and 1), the slot -> input map is
+//   step s < 4:  group 0: feature s, group 1: feature 4 + s, group 2: x[s], group 3: x[4 + s]
+//   step 4:      group g: x[8 + g]                                   (F = 11 only)
+template <int F, int D>
+struct MT {
+    static_assert(D == 8, "fp32 matrix-core tables are laid out for D = 8");
+    static constexpr int C = F + D;
+    static constexpr int NS = F <= 8 ? 4 : 5;          // k-steps of a record product
+    static constexpr int o_h0 = 0;                     // [64]       input network, 1 step (FIRST)
+    static constexpr int o_t = 64;                     // 3 x [NS][64]: PR, QS, U  (LAST: P|Q, -, -)
+    static constexpr int t_sz = NS * 64;
+    static constexpr int o_w4 = o_t + 3 * t_sz;        // [2][64]: slot (s, g) = feature 2 g + s
+    static constexpr int o_b = o_w4 + 128;             // biases: h0, T0, T1, T2, W4 (16 each)
+    static constexpr int total = o_b + 5 * 16;
+    // input index k in [0, C) of slot (s, g), or -1
+    static constexpr int slot_k(int s, int g)
+    {
+        if (s < 4) {
+            if (g == 0) return s;
+            if (g == 1) return 4 + s;
+            const int xi = (g == 2) ? s : 4 + s;
+            return xi < F ? D + xi : -1;
+        }
+        return 8 + g < F ? D + 8 + g : -1;
+    }
+};
+
+// one entry of the tables above from the raw weights; `last`: T0 holds [P(8) | Q(8)]
+template <int F, int D>
+__device__ __forceinline__ float mt_entry(const gnn_params_t &p, int i, bool last)
+{
+    using M = MT<F, D>;
+    constexpr int C = F + D;
+    if (i < 64) {                                               // input network
+        const int row = i & 15, g = i >> 4;
+        return (row < 8 && g < F && g < 4) ? p.Win[row * F + g] : 0.0f;
+    }
+    if (i < M::o_w4) {                                          // record products
+        const int j = i - M::o_t, T = j / M::t_sz, st = (j % M::t_sz) >> 6, row = j & 15, g = (j >> 4) & 3;
+        const int k = M::slot_k(st, g);
+        if (k < 0) return 0.0f;
+        if (last) {
+            if (T > 0) return 0.0f;
+            return kTwoLog2e * p.W1[(row & 7) * 2 * C + (row >> 3) * C + k];
+        }
+        if (T == 2) return row < 8 ? p.W3[row * 3 * C + 2 * C + k] : 0.0f;          // U
+        const int c = row >> 2, w = row & 3, d = 2 * c + (w & 1);                 // [P|R] / [Q|S] chunk order
+        return (w < 2) ? kTwoLog2e * p.W1[d * 2 * C + T * C + k] : p.W3[d * 3 * C + T * C + k];
+    }
+    if (i < M::o_b) {                                           // W4
+        const int j = i - M::o_w4, st = j >> 6, row = j & 15, g = (j >> 4) & 3;
+        return row < 8 ? p.W4[row * D + 2 * g + st] : 0.0f;
+    }
+    const int j = i - M::o_b, which = j >> 4, row = j & 15;     // biases
+    switch (which) {
+    case 0: return row < 8 ? p.bin[row] : 0.0f;
+    case 1:
+        if (last) return row < 8 ? kTwoLog2e * p.b1[row] : 0.0f;
+        return (row & 3) < 2 ? kTwoLog2e * p.b1[2 * (row >> 2) + (row & 1)] : 0.0f;
+    case 2: return 0.0f;
+    case 3: return (!last && row < 8) ? p.b3[row] : 0.0f;
+    default: return row < 8 ? p.b4[row] : 0.0f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_iter2: persistent, phase-split variant of k_iter for batches whose tiles all run in LDS mode
 // ---------------------------------------------------------------------------------------------
 // k_iter holds both record windows of a tile in LDS (128 KB at 1000 hits/level, D = 8), so a CU
@@ -1551,40 +1623,12 @@ __global__ __launch_bounds__(1024) void k_iter2(
         if (blockIdx.x == 0)
             write_null_rows<F, D, XP>(p, PRn, const_cast<float *>(PR), QSn, const_cast<float *>(QS),
                                       U, Pc, Qc, n_pad);
-        if constexpr (D == 8) {
-            // A fragments (fp32, v_mfma_f32_16x16x4_f32) of the window products, see compute_window:
-            // mt[0..64)        H0:   lane (row, g) -> Win[row][g]              (row < 8, g < F)
-            // mt[64 + 256 M + 64 s + lane]  records M (0: [P|R], 1: [Q|S]), k-step s:
-            //                   lane (row = record position, g) -> weight of input slot (s, g):
-            //                   g = 0: H0[s], g = 1: H0[4 + s], g = 2: x[s], g = 3: none
-            // mb[0..16) H0 bias (bin | 0), mb[16 + 16 M + row] record biases
-            float *mt = xbuf + xbuf_floats, *mb = mt + 64 + 2 * 256;
-            constexpr int C = F + D;
-            for (int i = tid; i < 64 + 2 * 256 + 48; i += NT) {
-                float v = 0.0f;
-                if (i < 64) {
-                    const int row = i & 15, g = i >> 4;
-                    if (row < 8 && g < F) v = p.Win[row * F + g];
-                } else if (i < 64 + 512) {
-                    const int j = i - 64, M = j >> 8, st = (j >> 6) & 3, row = j & 15, g = (j >> 4) & 3;
-                    const int k = g == 0 ? st : g == 1 ? 4 + st : (g == 2 && st < F) ? D + st : -1;
-                    const int c = row >> 2, w = row & 3, d = 2 * c + (w & 1);
-                    if (k >= 0)
-                        v = (w < 2) ? kTwoLog2e * p.W1[d * 2 * C + M * C + k] : p.W3[d * 3 * C + M * C + k];
-                } else {
-                    const int j = i - 64 - 512;
-                    if (j < 8) v = p.bin[j];
-                    else if (j >= 16 && j < 32) {                   // [P|R] biases: P = scaled b1
-                        const int row = j - 16, c = row >> 2, w = row & 3;
-                        if (w < 2) v = kTwoLog2e * p.b1[2 * c + w];
-                    }
-                }
-                (i < 64 + 512 ? mt : mb - 64 - 512)[i] = v;
-            }
-        }
     } else {
         stage4<NT>(table, lds, L::total / 4);        // visible after the first barrier
     }
+    float *mt = xbuf + (FIRST ? xbuf_floats : 0);    // D = 8: fp32 matrix-core tables (MT)
+    if constexpr (D == 8)
+        for (int i = tid; i < MT<F, D>::total; i += NT) mt[i] = mt_entry<F, D>(p, i, LAST);
     // XCD-aware start tile: workgroups are dealt round-robin to the 8 XCDs, so XCD x takes a
     // CONTIGUOUS run of the grid's tiles.  Neighbouring tiles are neighbouring levels of one
     // graph: level l's PR rows are the in-window of tile l+1 and the own-P rows of tile l, its QS
@@ -1679,12 +1723,13 @@ __global__ __launch_bounds__(1024) void k_iter2(
             // 4 (l >> 4) .. + 3 of that hit's record - one 16-byte LDS store.  5 MFMAs per 16 hits
             // instead of ~100 vector instructions per lane.
             typedef float f4v __attribute__((ext_vector_type(4)));
-            const float *mt = xbuf + xbuf_floats, *mb = mt + 64 + 2 * 256;
+            using MTL = MT<F, D>;
+            const float *mb = mt + MTL::o_b;
             const int hit = lane & 15, g = lane >> 4;
-            const float a0 = mt[lane];
+            const float a0 = mt[MTL::o_h0 + lane];
             float ar[4];
 #pragma unroll
-            for (int st = 0; st < 4; ++st) ar[st] = mt[64 + 256 * M + 64 * st + lane];
+            for (int st = 0; st < 4; ++st) ar[st] = mt[MTL::o_t + MTL::t_sz * M + 64 * st + lane];
             const f4v bias0 = *reinterpret_cast<const f4v *>(mb + 4 * g);
             const f4v biasr = *reinterpret_cast<const f4v *>(mb + 16 + 16 * M + 4 * g);
             for (int h0i = wv * 16; h0i < cnt; h0i += NWV * 16) {
@@ -1955,7 +2000,74 @@ __global__ __launch_bounds__(1024) void k_iter2(
                     b_cur = b_nxt;
                 }
             }
-            if (slice >= 0) {
+            if constexpr (D == 8) {
+                if (slice >= 0) {
+                    // Hit update and records on the matrix cores, exact fp32 (MT): the wave's 16
+                    // hits are the 16 columns.  tanh(acc) moves from the sweep's lane layout
+                    // (lane = hit * 4 + q: dims 2q, 2q+1) to the product's (lane = g * 16 + hit:
+                    // slots of group g) with two ds_bpermute, X with F more; everything after
+                    // that, stores included, stays in the product's layout.
+                    using MTL = MT<F, D>;
+                    typedef float f4v __attribute__((ext_vector_type(4)));
+                    const float *mb = mt + MTL::o_b;
+                    const int hit = lane & 15, g = lane >> 4;
+                    const int from = ((hit << 2) | g) << 2;          // byte index of the source lane
+                    const float q0 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(tanh_f(acc[0]))));
+                    const float q1 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(tanh_f(acc[1]))));
+                    float xm[F];
+#pragma unroll
+                    for (int k = 0; k < F; ++k)
+                        xm[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(hit << 4, __float_as_int(xv[k])));
+                    // H' = tanh(W4 q + b4): slot (s, g) = feature 2 g + s          (model.py:94-98,125)
+                    f4v h = *reinterpret_cast<const f4v *>(mb + 64 + 4 * g);
+                    h = __builtin_amdgcn_mfma_f32_16x16x4f32(mt[MTL::o_w4 + lane], q0, h, 0, 0, 0);
+                    h = __builtin_amdgcn_mfma_f32_16x16x4f32(mt[MTL::o_w4 + 64 + lane], q1, h, 0, 0, 0);
+                    const float hh[4] = {tanh_f(h.x), tanh_f(h.y), tanh_f(h.z), tanh_f(h.w)};
+                    // this lane's input of step s of the record products (MT::slot_k)
+                    auto slot_in = [&](int st) {
+                        if (st < 4) {
+                            if (g < 2) return hh[st];
+                            float v = 0.0f;
+#pragma unroll
+                            for (int k = 0; k < F; ++k)
+                                if (k == st || k == 4 + st) v = (g == (k < 4 ? 2 : 3) && (k & 3) == st) ? xm[k] : v;
+                            return v;
+                        }
+                        float v = 0.0f;
+#pragma unroll
+                        for (int k = 8; k < F; ++k) v = (g == k - 8) ? xm[k] : v;
+                        return v;
+                    };
+                    float bin_[MTL::NS];
+#pragma unroll
+                    for (int st = 0; st < MTL::NS; ++st) bin_[st] = slot_in(st);
+                    const int64_t n = (int64_t)__builtin_amdgcn_readfirstlane(slice) * SLICE + hit;
+                    constexpr int NP = LAST ? 1 : 3;
+#pragma unroll
+                    for (int T = 0; T < NP; ++T) {
+                        f4v c = *reinterpret_cast<const f4v *>(mb + 16 * (1 + T) + 4 * g);
+#pragma unroll
+                        for (int st = 0; st < MTL::NS; ++st)
+                            c = __builtin_amdgcn_mfma_f32_16x16x4f32(mt[MTL::o_t + MTL::t_sz * T + 64 * st + lane],
+                                                                     bin_[st], c, 0, 0, 0);
+                        if constexpr (LAST) {          // rows 0..7 = P, 8..15 = Q (compact rows)
+                            if constexpr (XP) {
+                                c.x = __builtin_amdgcn_exp2f(c.x); c.y = __builtin_amdgcn_exp2f(c.y);
+                                c.z = __builtin_amdgcn_exp2f(c.z); c.w = __builtin_amdgcn_exp2f(c.w);
+                            }
+                            *reinterpret_cast<f4v *>((g < 2 ? Pc : Qc) + n * D + 4 * (g & 1)) = c;
+                        } else if (T < 2) {            // [P|R] / [Q|S]: this lane's 16-byte chunk g
+                            if constexpr (XP) {
+                                c.x = __builtin_amdgcn_exp2f(c.x);
+                                c.y = __builtin_amdgcn_exp2f(c.y);
+                            }
+                            *reinterpret_cast<f4v *>((T == 0 ? PRn : QSn) + n * 2 * D + 4 * g) = c;
+                        } else if (g < 2) {            // U: rows 0..7
+                            *reinterpret_cast<f4v *>(U + n * D + 4 * g) = c;
+                        }
+                    }
+                }
+            } else if (slice >= 0) {
                 // opaque weight-table offset: keeps the LDS weight reads out of registers
                 int woff = q * L::stride;
                 asm volatile("" : "+v"(woff));
@@ -2138,13 +2250,14 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
                    pl->in_nbr16 && pl->out_nbr16 && pl->in_off16 && pl->out_off16 && pl->sched_a && pl->sched_b;
             capA = (int)capa;
             capB = (int)capb;
-            it2_lds = (size_t)(L::total + (capa + capb) * 2 * D + 4) * sizeof(float);
+            constexpr int mt_floats = (D == 8) ? (64 + 3 * ((F <= 8 ? 4 : 5) * 64) + 128 + 80) : 0;   // MT<F, D>::total
+            it2_lds = (size_t)(L::total + (capa + capb) * 2 * D + 4 + mt_floats) * sizeof(float);
             if (it2_lds > (size_t)G::lds_bytes) use2 = false;
             // first iteration fused with the input network: + one buffer of X rows (256-byte pieces)
             const int64_t xfl = ((capa > capb ? capa : capb) * F + 63) / 64 * 64;
             xbuf_floats = (int)xfl;
             // + the fp32 A fragments / biases of the matrix-core window products (D = 8)
-            it2_lds_first = it2_lds + (size_t)(xfl + (D == 8 ? 64 + 512 + 48 : 0)) * sizeof(float);
+            it2_lds_first = it2_lds + (size_t)xfl * sizeof(float);
             // (exp-product mode only: the plain-exp variant of the fused kernel does not fit the
             // register budget without spills, and it is the rarely taken fallback anyway)
             fuse_first = G::fuse_first && XP && use2 && n_iters >= 2 && it2_lds_first <= (size_t)G::lds_bytes &&
