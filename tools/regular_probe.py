@@ -21,7 +21,7 @@ def regular_graph(n_layers, per_layer, deg, seed):
     return synth.HitGraph(X, src, dst, np.zeros(len(src), np.float32))
 
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-for deg in (12, 10, 8):
+for deg in [int(a) for a in sys.argv[2:]] or (12, 10, 8):
     graphs = [regular_graph(10, 1000, deg, s) for s in range(G)]
     b = HitGraphBatch.from_graphs(graphs).cuda()
     torch.manual_seed(0)
