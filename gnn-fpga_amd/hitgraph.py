@@ -48,8 +48,7 @@ class _EventLayout:
 class HitGraphBatch:
     """A block-diagonal batch of hit graphs in index form (see module docstring)."""
 
-    _TENSORS = ("X", "src", "dst", "in_ptr", "in_eid", "in_nbr",
-                "out_ptr", "out_eid", "out_nbr", "y")
+    _TENSORS = ("X", "src", "dst", "y")        # (+ the six CSR arrays once they exist)
 
     def __init__(self, X, src, dst, y=None, hit_ptr=None, seg_ptr=None,
                  dense_shape=None, csr=None):
@@ -71,17 +70,33 @@ class HitGraphBatch:
                                   dtype=np.int64)
         self.n_graphs = len(self.hit_ptr) - 1
         self.dense_shape = dense_shape  # (B, N_max, E_max) when built from a padded batch
-        if csr is None:
-            in_ptr, in_eid, in_nbr = _csr_by(dst, src, n)
-            out_ptr, out_eid, out_nbr = _csr_by(src, dst, n)
-        else:
-            in_ptr, in_eid, in_nbr, out_ptr, out_eid, out_nbr = csr
         t = torch.from_numpy
         self.X, self.src, self.dst = t(X), t(src), t(dst)
-        self.in_ptr, self.in_eid, self.in_nbr = t(in_ptr), t(in_eid), t(in_nbr)
-        self.out_ptr, self.out_eid, self.out_nbr = t(out_ptr), t(out_eid), t(out_nbr)
+        # The two CSRs serve the per-module kernels, the small-event kernel and the backward; the
+        # tiled pipeline works from its own plan.  They are therefore built on first use (two
+        # stable sorts of E keys: 15 s for 25.6 M segments) unless the caller brought them.
+        self._csr = None if csr is None else tuple(t(np.ascontiguousarray(a, dtype=_I32)) for a in csr)
+        self._src_host = src if csr is None else None
+        self._dst_host = dst if csr is None else None
         self.y = None if y is None else t(np.ascontiguousarray(y, dtype=np.float32))
         self.plan = None
+
+    _CSR_NAMES = ("in_ptr", "in_eid", "in_nbr", "out_ptr", "out_eid", "out_nbr")
+
+    def _ensure_csr(self):
+        if self._csr is None:
+            src, dst, n = self._src_host, self._dst_host, self.n_hits
+            parts = _csr_by(dst, src, n) + _csr_by(src, dst, n)
+            self._csr = tuple(torch.from_numpy(a).to(self.X.device) for a in parts)
+            self._src_host = self._dst_host = None
+        return self._csr
+
+    in_ptr = property(lambda self: self._ensure_csr()[0])
+    in_eid = property(lambda self: self._ensure_csr()[1])
+    in_nbr = property(lambda self: self._ensure_csr()[2])
+    out_ptr = property(lambda self: self._ensure_csr()[3])
+    out_eid = property(lambda self: self._ensure_csr()[4])
+    out_nbr = property(lambda self: self._ensure_csr()[5])
 
     def build_plan(self, hidden_dim, limits=None):
         """Tiles + windows + SELL-16 execution plan of the fused kernels (plan.py); built once,
@@ -235,6 +250,8 @@ class HitGraphBatch:
             v = getattr(self, k)
             if v is not None:
                 setattr(self, k, v.to(device))
+        if self._csr is not None:
+            self._csr = tuple(a.to(device) for a in self._csr)
         if self.plan is not None:
             self.plan.to(device)
         return self

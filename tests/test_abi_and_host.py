@@ -225,3 +225,21 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert lib.gnn_plan_limits(3, 8, lim) == 0 and lim[0] >= 16 and lim[2] >= 1024
     assert lib.gnn_forward_workspace_bytes(-1, 5, 3, 8) == 0 or True       # size queries never fail hard
     assert lib.gnn_plan_workspace_bytes(10, 20, 5, 7) == 0
+
+
+def test_csr_is_built_on_first_use_only():
+    """The two CSRs are not needed by the tiled pipeline: HitGraphBatch builds them when a consumer
+    (per-module kernels, small-event kernel, backward) first asks, also after a device move."""
+    g = synth.layered_graph(200, 900, 3, seed=4)
+    b = HitGraphBatch.from_graphs([g, g])
+    assert b._csr is None
+    b.build_plan(8, dict(tile_hits=64, iter_records=40, chunk_segments=50, edge_records=60))
+    assert b._csr is None                                   # the plan does not touch them
+    b.to("cpu")
+    ip, ie, inb = b.in_ptr, b.in_eid, b.in_nbr
+    assert b._csr is not None and b._src_host is None
+    assert ip.dtype == torch.int32 and ip.shape == (401,) and int(ip[-1]) == 1800
+    src, dst = b.src.numpy(), b.dst.numpy()
+    assert np.array_equal(inb.numpy(), src[ie.numpy()])
+    assert np.all(np.diff(dst[ie.numpy()]) >= 0)            # grouped by end hit
+    assert np.array_equal(b.out_nbr.numpy(), dst[b.out_eid.numpy()])
