@@ -30,7 +30,8 @@ def _csr_by(key, other, n_hits):
     """Group valid segments by `key` hit; stable => ascending segment id per hit."""
     valid = np.flatnonzero(key >= 0)
     k = key[valid]
-    order = np.argsort(k, kind="stable")
+    from .plan import stable_argsort
+    order = stable_argsort(k)
     eid = valid[order].astype(_I32)
     ptr = np.zeros(n_hits + 1, dtype=np.int64)
     np.cumsum(np.bincount(k, minlength=n_hits), out=ptr[1:])

@@ -34,15 +34,32 @@ TILE_DESC = 8    # ints per tile:  slice_begin, slice_end, in_lo, in_cnt, out_lo
 CHUNK_DESC = 8   # ints per chunk: seg_begin, seg_end, src_lo, src_cnt, dst_lo, dst_cnt, mode, 0
 
 
+def stable_argsort(a):
+    """np.argsort(a, kind="stable") for large arrays of non-negative ids that fit int32: torch's
+    CPU sort is a parallel radix sort there (10x numpy's merge sort at 25 M keys)."""
+    a = np.asarray(a)
+    if a.size >= (1 << 16) and a.size and a.min(initial=0) >= 0 and a.max(initial=0) < 2 ** 31:
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).argsort(stable=True).numpy()
+    return np.argsort(a, kind="stable")
+
+
+def _run_starts(sorted_keys):
+    """(unique values, index of their first occurrence) of an already SORTED array."""
+    if sorted_keys.size == 0:
+        return sorted_keys[:0], np.zeros(0, dtype=np.int64)
+    start = np.flatnonzero(np.r_[True, sorted_keys[1:] != sorted_keys[:-1]])
+    return sorted_keys[start], start
+
+
 def topological_levels(src, dst, n, max_iter=64):
     """level[n] = longest path (in segments) from a hit with no incoming segment.
     Graphs with cycles stop at `max_iter` (any labelling is valid, only locality suffers)."""
     level = np.zeros(n, dtype=np.int32)
     if src.size == 0:
         return level
-    order = np.argsort(dst, kind="stable")
+    order = stable_argsort(dst)
     s, d = src[order], dst[order]
-    uniq, start = np.unique(d, return_index=True)
+    uniq, start = _run_starts(d)
     for _ in range(max_iter):
         cand = np.maximum.reduceat(level[s] + 1, start)
         new = level.copy()
@@ -54,8 +71,8 @@ def topological_levels(src, dst, n, max_iter=64):
     # windows of that tile over the whole graph: place it one level below its nearest end hit
     no_in = np.ones(n, dtype=bool)
     no_in[uniq] = False
-    so = np.argsort(src, kind="stable")
-    us, st = np.unique(src[so], return_index=True)
+    so = stable_argsort(src)
+    us, st = _run_starts(src[so])
     down = np.minimum.reduceat(level[dst[so]], st) - 1
     fix = no_in[us]
     level[us[fix]] = np.maximum(down[fix], 0)
@@ -64,12 +81,12 @@ def topological_levels(src, dst, n, max_iter=64):
 
 def _node_minmax(key, other, n):
     """Per hit: min / max of `other` over segments whose `key` endpoint is the hit."""
-    order = np.argsort(key, kind="stable")
+    order = stable_argsort(key)
     k, o = key[order], other[order]
     lo = np.full(n, np.iinfo(np.int64).max, dtype=np.int64)
     hi = np.full(n, -1, dtype=np.int64)
     if k.size:
-        uniq, start = np.unique(k, return_index=True)
+        uniq, start = _run_starts(k)
         lo[uniq] = np.minimum.reduceat(o, start)
         hi[uniq] = np.maximum.reduceat(o, start)
     return lo, hi
@@ -86,7 +103,7 @@ def _sell(key_new, other_rel, n_pad, null_of_slice):
     """SELL-16 lists over padded hit ids; `other_rel` is the stored value per segment,
     `null_of_slice[s]` the padding value of slice s."""
     n_slices = n_pad // SLICE
-    order = np.argsort(key_new, kind="stable")
+    order = stable_argsort(key_new)
     k = key_new[order]
     oth = other_rel[order]
     deg = np.bincount(k, minlength=n_pad)
