@@ -101,28 +101,26 @@ def _range_minmax(lo, hi, bounds):
 
 def _sell(key_new, other_rel, n_pad, null_of_slice):
     """SELL-16 lists over padded hit ids; `other_rel` is the stored value per segment,
-    `null_of_slice[s]` the padding value of slice s.  (torch CPU ops: the gathers / scatters over
-    E entries run on all cores, numpy's do not.)"""
+    `null_of_slice[s]` the padding value of slice s."""
     n_slices = n_pad // SLICE
-    t = torch.from_numpy
-    key_t = t(np.ascontiguousarray(key_new, dtype=np.int64))
-    order = t(stable_argsort(key_new))
-    k = key_t[order]
-    oth = t(np.ascontiguousarray(other_rel, dtype=np.int32))[order]
-    deg = torch.bincount(k, minlength=n_pad)
-    ptr = torch.zeros(n_pad + 1, dtype=torch.int64)
-    torch.cumsum(deg, 0, out=ptr[1:])
-    pos = torch.arange(k.shape[0], dtype=torch.int64) - ptr[k]
-    slen = deg.view(n_slices, SLICE).max(dim=1).values if n_slices else torch.zeros(0, dtype=torch.int64)
-    off = torch.zeros(n_slices + 1, dtype=torch.int64)
-    torch.cumsum(slen * SLICE, 0, out=off[1:])
-    if int(off[-1]) >= 2 ** 31:
+    order = stable_argsort(key_new)
+    k = key_new[order]
+    oth = other_rel[order]
+    deg = np.bincount(k, minlength=n_pad)
+    ptr = np.zeros(n_pad + 1, dtype=np.int64)
+    np.cumsum(deg, out=ptr[1:])
+    pos = np.arange(k.shape[0], dtype=np.int64) - ptr[k]
+    slen = deg.reshape(n_slices, SLICE).max(axis=1).astype(np.int64) if n_slices else \
+        np.zeros(0, np.int64)
+    off = np.zeros(n_slices + 1, dtype=np.int64)
+    np.cumsum(slen * SLICE, out=off[1:])
+    if off[-1] >= 2 ** 31:
         raise ValueError("SELL list exceeds int32 index range")
-    nbr = torch.repeat_interleave(t(np.ascontiguousarray(null_of_slice, dtype=np.int32)), slen * SLICE)
+    nbr = np.repeat(null_of_slice.astype(np.int32), (slen * SLICE).astype(np.int64))
     nbr[off[k // SLICE] + pos * SLICE + (k % SLICE)] = oth
     # the kernel reads lists in chunks of 4 steps: up to 3 steps past the end of the last list
-    nbr = torch.cat([nbr, torch.zeros(4 * SLICE, dtype=torch.int32)])
-    return off.to(torch.int32).numpy(), nbr.numpy()
+    nbr = np.concatenate([nbr, np.zeros(4 * SLICE, dtype=np.int32)])
+    return off.astype(np.int32), nbr
 
 
 def _pack16(off, nbr, null_of_slice):
@@ -133,24 +131,20 @@ def _pack16(off, nbr, null_of_slice):
     2p+1 (high half) at `off16[s] + 16*p + i`.  Lane q of a quad loads word 4*sc+q of
     super-chunk sc, i.e. one load covers 8 list steps.  Entries are window-relative (< 65536)."""
     n_slices = off.shape[0] - 1
-    t = torch.from_numpy
-    off64 = t(off.astype(np.int64))
-    L = (off64[1:] - off64[:-1]) // SLICE                      # steps per slice
+    L = np.diff(off.astype(np.int64)) // SLICE                 # steps per slice
     steps8 = (L + 7) // 8 * 8
-    poff = torch.zeros(n_slices + 1, dtype=torch.int64)
-    torch.cumsum(steps8 * SLICE, 0, out=poff[1:])
-    pad = torch.repeat_interleave(t(np.ascontiguousarray(null_of_slice, dtype=np.int64)) & 0xFFFF, steps8 * SLICE)
+    poff = np.zeros(n_slices + 1, dtype=np.int64)
+    np.cumsum(steps8 * SLICE, out=poff[1:])
+    pad = np.repeat((null_of_slice.astype(np.int64) & 0xFFFF), steps8 * SLICE)
     real = int(off[-1])
     if real:
-        s_of = torch.repeat_interleave(torch.arange(n_slices), L * SLICE)
-        idx = torch.arange(real, dtype=torch.int64)
-        pad[idx - off64[s_of] + poff[s_of]] = t(nbr[:real]).to(torch.int64) & 0xFFFF
-    pr = pad.view(-1, 2, SLICE)
+        s_of = np.repeat(np.arange(n_slices), L * SLICE)
+        idx = np.arange(real, dtype=np.int64)
+        pad[idx - off.astype(np.int64)[s_of] + poff[s_of]] = nbr[:real].astype(np.int64) & 0xFFFF
+    pr = pad.reshape(-1, 2, SLICE)
     words = (pr[:, 0, :] | (pr[:, 1, :] << 16)).reshape(-1)
-    words = torch.cat([words, torch.zeros(64, dtype=torch.int64)])
-    # low 32 bits as int32 (values < 2^32)
-    w32 = words.numpy().astype(np.uint32).view(np.int32)
-    return (poff // 2).to(torch.int32).numpy(), w32
+    words = np.concatenate([words, np.zeros(64, dtype=np.int64)])
+    return (poff // 2).astype(np.int32), words.astype(np.uint32).view(np.int32)
 
 
 def _chunk_bounds(key, ok, E, CH):
