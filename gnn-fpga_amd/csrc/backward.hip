@@ -8,6 +8,7 @@
 //
 //   edge pass t   e = sigmoid(u), u = W2 a + b2, a = tanh(z), z = P[s] + Q[d]
 //       k_edge_bwd   per segment:  gu = ge e (1-e);  gz = gu W2 (1-a^2)  -> gz[E,D];  gW2, gb2
+//                                  (+ gb1 of the padded segments)
 //       k_pq_bwd     per hit:      gP = sum_out gz, gQ = sum_in gz (CSR pulls, fixed order)
 //                                  gH += W1[:, :C]^T gP + W1[:, C:]^T gQ;  gW1, gb1
 //   node pass t   H' = tanh(W4 q + b4), q = tanh(W3 M + b3), M = [mi | mo | H]
@@ -31,6 +32,25 @@ struct Shape {
     static constexpr int C = F + D;
     static constexpr int LDH = (C + 3) & ~3;
 };
+
+// row of LDH floats (16-byte aligned: LDH % 4 == 0) as float4 loads
+template <int N4>
+__device__ __forceinline__ void load_row4(const float *__restrict__ row, float *v)
+{
+    const float4 *r = reinterpret_cast<const float4 *>(row);
+#pragma unroll
+    for (int i = 0; i < N4; ++i) {
+        const float4 a = r[i];
+        v[4 * i] = a.x; v[4 * i + 1] = a.y; v[4 * i + 2] = a.z; v[4 * i + 3] = a.w;
+    }
+}
+template <int N4>
+__device__ __forceinline__ void store_row4(float *__restrict__ row, const float *v)
+{
+    float4 *r = reinterpret_cast<float4 *>(row);
+#pragma unroll
+    for (int i = 0; i < N4; ++i) r[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+}
 
 // sum over the workgroup's items of L (x) R, added into g[i * ldg + col0 + k]
 template <int NL, int NR>
@@ -79,9 +99,8 @@ __global__ __launch_bounds__(kBlock) void kb_pq(const float *__restrict__ H, int
     constexpr int C = F + D;
     const int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (n >= n_hits) return;
-    float h[C];
-#pragma unroll
-    for (int k = 0; k < C; ++k) h[k] = H[n * ldh + k];
+    float h[Shape<F, D>::LDH], pq[2 * D];
+    load_row4<Shape<F, D>::LDH / 4>(H + n * ldh, h);
 #pragma unroll
     for (int d = 0; d < D; ++d) {
         float p = b1[d], q = 0.0f;
@@ -90,39 +109,87 @@ __global__ __launch_bounds__(kBlock) void kb_pq(const float *__restrict__ H, int
             p = fmaf(W1[d * 2 * C + k], h[k], p);
             q = fmaf(W1[d * 2 * C + C + k], h[k], q);
         }
-        PQ[n * 2 * D + d] = p;
-        PQ[n * 2 * D + D + d] = q;
+        pq[d] = p;
+        pq[D + d] = q;
     }
+    store_row4<2 * D / 4>(PQ + n * 2 * D, pq);
 }
 
+// Per-segment kernels are grid-stride with a bounded grid: every thread keeps private sums of its
+// segments' contributions, the workgroup adds them up once at the end (wavefront butterfly, one
+// LDS slot per wavefront) and issues ONE atomic per gradient element - a few hundred per launch
+// instead of one per 256 segments (12 500 at 3.2 M segments: they serialised and were the launch).
+constexpr int kSegGrid = 1024;
+
+// per segment; padded segments (src = -1) score sigmoid(W2 tanh(b1) + b2): their gz flows into
+// b1 only (summed here, the hits' share of gb1 comes from k_pq_bwd)
 template <int D>
 __global__ __launch_bounds__(kBlock) void k_edge_bwd(
     const int32_t *__restrict__ src, const int32_t *__restrict__ dst,
     const float *__restrict__ PQ, const float *__restrict__ b1, const float *__restrict__ W2,
     const float *__restrict__ e, const float *__restrict__ ge, float *__restrict__ gz,
-    float *__restrict__ gW2, float *__restrict__ gb2, int64_t n_segments)
+    float *__restrict__ gW2, float *__restrict__ gb2, float *__restrict__ gb1, int64_t n_segments)
 {
-    __shared__ float lds[kBlock * (D + 2)];
-    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const bool active = j < n_segments;
-    float a[D], gu = 0.0f;
+    __shared__ float lds[(kBlock / 64) * (2 * D + 1)];
+    float sum[2 * D + 1];                  // gW2[D] | gb1 share of the padded segments [D] | gb2
 #pragma unroll
-    for (int i = 0; i < D; ++i) a[i] = 0.0f;
-    if (active) {
+    for (int i = 0; i < 2 * D + 1; ++i) sum[i] = 0.0f;
+    float w2[D], bb[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        w2[i] = W2[i];
+        bb[i] = b1[i];
+    }
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n_segments;
+         j += (int64_t)gridDim.x * kBlock) {
         const int s = src[j], d = dst[j];
+        float z[D];
+        if (s >= 0) {
+            const float4 *p = reinterpret_cast<const float4 *>(PQ + (int64_t)s * 2 * D);
+            const float4 *q = reinterpret_cast<const float4 *>(PQ + (int64_t)d * 2 * D + D);
 #pragma unroll
-        for (int i = 0; i < D; ++i) {
-            const float z = s >= 0 ? PQ[(int64_t)s * 2 * D + i] + PQ[(int64_t)d * 2 * D + D + i] : b1[i];
-            a[i] = tanh_f(z);
+            for (int v = 0; v < D / 4; ++v) {
+                const float4 a = p[v], b = q[v];
+                z[4 * v] = a.x + b.x; z[4 * v + 1] = a.y + b.y;
+                z[4 * v + 2] = a.z + b.z; z[4 * v + 3] = a.w + b.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < D; ++i) z[i] = bb[i];
         }
         const float ev = e[j];
-        gu = ge[j] * ev * (1.0f - ev);
+        const float gu = ge[j] * ev * (1.0f - ev);
+        float g[D];
 #pragma unroll
-        for (int i = 0; i < D; ++i) gz[j * D + i] = gu * W2[i] * (1.0f - a[i] * a[i]);
+        for (int i = 0; i < D; ++i) {
+            const float a = tanh_f(z[i]);
+            g[i] = gu * w2[i] * (1.0f - a * a);
+            sum[i] = fmaf(gu, a, sum[i]);
+            sum[D + i] += s < 0 ? g[i] : 0.0f;
+        }
+        sum[2 * D] += gu;
+        float4 *o = reinterpret_cast<float4 *>(gz + j * D);
+#pragma unroll
+        for (int v = 0; v < D / 4; ++v) o[v] = make_float4(g[4 * v], g[4 * v + 1], g[4 * v + 2], g[4 * v + 3]);
     }
-    const float one = 1.0f;
-    accum_outer<1, D>(&gu, a, active, gW2, D, 0, lds);       // gW2[0][i] += gu a_i
-    accum_outer<1, 1>(&gu, &one, active, gb2, 1, 0, lds);
+    {
+        constexpr int NW = kBlock / 64, N = 2 * D + 1;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            float x = sum[i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+            if ((threadIdx.x & 63) == 0) lds[(threadIdx.x >> 6) * N + i] = x;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < N) {
+            float x = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) x += lds[w * N + threadIdx.x];
+            const int i = threadIdx.x;
+            atomicAdd(i < D ? gW2 + i : i < 2 * D ? gb1 + (i - D) : gb2, x);
+        }
+    }
 }
 
 template <int F, int D>
@@ -133,7 +200,7 @@ __global__ __launch_bounds__(kBlock) void k_pq_bwd(
     const float *__restrict__ W1, float *__restrict__ gH, float *__restrict__ gW1,
     float *__restrict__ gb1, int64_t n_pad_edges_b1, int64_t n_hits)
 {
-    constexpr int C = F + D;
+    constexpr int C = F + D, LDH = Shape<F, D>::LDH;
     __shared__ float lds[outer_lds_floats<D, C>()];
     const int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool active = n < n_hits;
@@ -143,18 +210,24 @@ __global__ __launch_bounds__(kBlock) void k_pq_bwd(
 #pragma unroll
     for (int k = 0; k < C; ++k) h[k] = 0.0f;
     if (active) {
-        for (int k = out_ptr[n], k1 = out_ptr[n + 1]; k < k1; ++k) {
-            const float *r = gz + (int64_t)out_eid[k] * D;
+        constexpr int U = D <= 16 ? 4 : 2;
+        csr_walk<D / 4, U>(out_ptr[n], out_ptr[n + 1],
+                           [&](int k) { return gz + (int64_t)out_eid[k] * D; }, [](int) { return 1.0f; },
+                           [&](float, const float *r) {
 #pragma unroll
-            for (int i = 0; i < D; ++i) gP[i] += r[i];
-        }
-        for (int k = in_ptr[n], k1 = in_ptr[n + 1]; k < k1; ++k) {
-            const float *r = gz + (int64_t)in_eid[k] * D;
+                               for (int i = 0; i < D; ++i) gP[i] += r[i];
+                           });
+        csr_walk<D / 4, U>(in_ptr[n], in_ptr[n + 1],
+                           [&](int k) { return gz + (int64_t)in_eid[k] * D; }, [](int) { return 1.0f; },
+                           [&](float, const float *r) {
 #pragma unroll
-            for (int i = 0; i < D; ++i) gQ[i] += r[i];
-        }
+                               for (int i = 0; i < D; ++i) gQ[i] += r[i];
+                           });
+        float hr[LDH], gh[LDH];
+        load_row4<LDH / 4>(H + n * ldh, hr);
+        load_row4<LDH / 4>(gH + n * ldh, gh);
 #pragma unroll
-        for (int k = 0; k < C; ++k) h[k] = H[n * ldh + k];
+        for (int k = 0; k < C; ++k) h[k] = hr[k];
 #pragma unroll
         for (int k = 0; k < C; ++k) {
             float acc = 0.0f;
@@ -163,30 +236,15 @@ __global__ __launch_bounds__(kBlock) void k_pq_bwd(
                 acc = fmaf(W1[i * 2 * C + k], gP[i], acc);
                 acc = fmaf(W1[i * 2 * C + C + k], gQ[i], acc);
             }
-            gH[n * ldh + k] += acc;
+            gh[k] += acc;
         }
+        store_row4<LDH / 4>(gH + n * ldh, gh);
     }
     const float one = 1.0f;
     accum_outer_wide<D, C>(gP, h, active, gW1, 2 * C, 0, lds);
     accum_outer_wide<D, C>(gQ, h, active, gW1, 2 * C, C, lds);
     accum_outer<D, 1>(gP, &one, active, gb1, 1, 0, lds);
     (void)n_pad_edges_b1;
-}
-
-// padded segments (src = -1) score sigmoid(W2 tanh(b1) + b2): their gz flows into b1 only
-template <int D>
-__global__ __launch_bounds__(kBlock) void k_pad_b1(const int32_t *__restrict__ src,
-                                                   const float *__restrict__ gz,
-                                                   float *__restrict__ gb1, int64_t n_segments)
-{
-    __shared__ float lds[kBlock * (D + 1)];
-    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const bool active = j < n_segments && src[j] < 0;
-    float g[D];
-#pragma unroll
-    for (int i = 0; i < D; ++i) g[i] = active ? gz[j * D + i] : 0.0f;
-    const float one = 1.0f;
-    accum_outer<D, 1>(g, &one, active, gb1, 1, 0, lds);
 }
 
 template <int F, int D>
@@ -200,7 +258,7 @@ __global__ __launch_bounds__(kBlock) void k_node_bwd(
     float *__restrict__ gH, float *__restrict__ gmio, float *__restrict__ gW3,
     float *__restrict__ gb3, float *__restrict__ gW4, float *__restrict__ gb4, int64_t n_hits)
 {
-    constexpr int C = Shape<F, D>::C;
+    constexpr int C = Shape<F, D>::C, LDH = Shape<F, D>::LDH;
     __shared__ float lds[outer_lds_floats<D, 3 * C>()];
     const int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool active = n < n_hits;
@@ -210,20 +268,27 @@ __global__ __launch_bounds__(kBlock) void k_node_bwd(
 #pragma unroll
     for (int i = 0; i < D; ++i) q[i] = gr[i] = gp[i] = 0.0f;
     if (active) {
-        for (int k = in_ptr[n], k1 = in_ptr[n + 1]; k < k1; ++k) {
-            const float w = e[in_eid[k]];
-            const float *hp = H + (int64_t)in_nbr[k] * ldh;
+        constexpr int U = D <= 16 ? 4 : 1;
+        csr_walk<LDH / 4, U>(in_ptr[n], in_ptr[n + 1],
+                             [&](int k) { return H + (int64_t)in_nbr[k] * ldh; },
+                             [&](int k) { return e[in_eid[k]]; },
+                             [&](float w, const float *hp) {
 #pragma unroll
-            for (int c = 0; c < C; ++c) M[c] = fmaf(w, hp[c], M[c]);
+                                 for (int c = 0; c < C; ++c) M[c] = fmaf(w, hp[c], M[c]);
+                             });
+        csr_walk<LDH / 4, U>(out_ptr[n], out_ptr[n + 1],
+                             [&](int k) { return H + (int64_t)out_nbr[k] * ldh; },
+                             [&](int k) { return e[out_eid[k]]; },
+                             [&](float w, const float *hp) {
+#pragma unroll
+                                 for (int c = 0; c < C; ++c) M[C + c] = fmaf(w, hp[c], M[C + c]);
+                             });
+        {
+            float hp[LDH];
+            load_row4<LDH / 4>(H + n * ldh, hp);
+#pragma unroll
+            for (int c = 0; c < C; ++c) M[2 * C + c] = hp[c];
         }
-        for (int k = out_ptr[n], k1 = out_ptr[n + 1]; k < k1; ++k) {
-            const float w = e[out_eid[k]];
-            const float *hp = H + (int64_t)out_nbr[k] * ldh;
-#pragma unroll
-            for (int c = 0; c < C; ++c) M[C + c] = fmaf(w, hp[c], M[C + c]);
-        }
-#pragma unroll
-        for (int c = 0; c < C; ++c) M[2 * C + c] = H[n * ldh + c];
 #pragma unroll
         for (int i = 0; i < D; ++i) {
             float acc = b3[i];
@@ -231,10 +296,12 @@ __global__ __launch_bounds__(kBlock) void k_node_bwd(
             for (int k = 0; k < 3 * C; ++k) acc = fmaf(W3[i * 3 * C + k], M[k], acc);
             q[i] = tanh_f(acc);
         }
+        {
+            float hn[D], gn[D];
+            load_row4<D / 4>(Hn + n * ldh, hn);
+            load_row4<D / 4>(gHn + n * ldh, gn);
 #pragma unroll
-        for (int i = 0; i < D; ++i) {
-            const float hp = Hn[n * ldh + i];
-            gr[i] = gHn[n * ldh + i] * (1.0f - hp * hp);
+            for (int i = 0; i < D; ++i) gr[i] = gn[i] * (1.0f - hn[i] * hn[i]);
         }
 #pragma unroll
         for (int k = 0; k < D; ++k) {
@@ -243,16 +310,19 @@ __global__ __launch_bounds__(kBlock) void k_node_bwd(
             for (int i = 0; i < D; ++i) acc = fmaf(W4[i * D + k], gr[i], acc);
             gp[k] = acc * (1.0f - q[k] * q[k]);
         }
+        float gm[3][LDH];                          // gmi | gmo | gHself, rows padded to LDH
+#pragma unroll
+        for (int k = 0; k < 3 * LDH; ++k) gm[k / LDH][k % LDH] = 0.0f;
 #pragma unroll
         for (int k = 0; k < 3 * C; ++k) {
             float acc = 0.0f;
 #pragma unroll
             for (int i = 0; i < D; ++i) acc = fmaf(W3[i * 3 * C + k], gp[i], acc);
-            if (k < 2 * C)
-                gmio[n * 2 * C + k] = acc;          // [gmi | gmo]
-            else
-                gH[n * ldh + (k - 2 * C)] = acc;    // gHself initialises gH_prev
+            gm[k / C][k % C] = acc;
         }
+        store_row4<LDH / 4>(gmio + n * 2 * LDH, gm[0]);          // [gmi | gmo], rows of LDH
+        store_row4<LDH / 4>(gmio + n * 2 * LDH + LDH, gm[1]);
+        store_row4<LDH / 4>(gH + n * ldh, gm[2]);                // gHself initialises gH_prev
     }
     const float one = 1.0f;
     accum_outer_wide<D, 3 * C>(gp, M, active, gW3, 3 * C, 0, lds);
@@ -268,14 +338,17 @@ __global__ __launch_bounds__(kBlock) void k_agg_bwd_e(const int32_t *__restrict_
                                                       const float *__restrict__ gmio,
                                                       float *__restrict__ ge, int64_t n_segments)
 {
-    constexpr int C = F + D;
+    constexpr int C = F + D, LDH = Shape<F, D>::LDH;
     const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (j >= n_segments) return;
     const int s = src[j], d = dst[j];
     float acc = 0.0f;
     if (s >= 0) {
-        const float *hs = H + (int64_t)s * ldh, *hd = H + (int64_t)d * ldh;
-        const float *gmi_d = gmio + (int64_t)d * 2 * C, *gmo_s = gmio + (int64_t)s * 2 * C + C;
+        float hs[LDH], hd[LDH], gmi_d[LDH], gmo_s[LDH];
+        load_row4<LDH / 4>(H + (int64_t)s * ldh, hs);
+        load_row4<LDH / 4>(H + (int64_t)d * ldh, hd);
+        load_row4<LDH / 4>(gmio + (int64_t)d * 2 * LDH, gmi_d);
+        load_row4<LDH / 4>(gmio + (int64_t)s * 2 * LDH + LDH, gmo_s);
 #pragma unroll
         for (int c = 0; c < C; ++c) acc = fmaf(gmi_d[c], hs[c], acc);
 #pragma unroll
@@ -292,28 +365,30 @@ __global__ __launch_bounds__(kBlock) void k_agg_bwd_n(
     const int32_t *__restrict__ out_eid, const int32_t *__restrict__ out_nbr,
     float *__restrict__ gH, int ldh, int64_t n_hits)
 {
-    constexpr int C = F + D;
+    constexpr int C = F + D, LDH = Shape<F, D>::LDH;
     const int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (n >= n_hits) return;
-    float acc[C];
+    float acc[LDH];
+    load_row4<LDH / 4>(gH + n * ldh, acc);
+    float sum[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) acc[c] = 0.0f;
+    for (int c = 0; c < C; ++c) sum[c] = 0.0f;
     // n is the START of these segments: H[n] entered mi of the end hit d
-    for (int k = out_ptr[n], k1 = out_ptr[n + 1]; k < k1; ++k) {
-        const float w = e[out_eid[k]];
-        const float *g = gmio + (int64_t)out_nbr[k] * 2 * C;          // gmi[d]
+    constexpr int U = D <= 16 ? 4 : 2;
+    auto add = [&](float w, const float *g) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) acc[c] = fmaf(w, g[c], acc[c]);
-    }
+        for (int c = 0; c < C; ++c) sum[c] = fmaf(w, g[c], sum[c]);
+    };
+    csr_walk<LDH / 4, U>(out_ptr[n], out_ptr[n + 1],
+                         [&](int k) { return gmio + (int64_t)out_nbr[k] * 2 * LDH; },            // gmi[d]
+                         [&](int k) { return e[out_eid[k]]; }, add);
     // n is the END of these segments: H[n] entered mo of the start hit s
-    for (int k = in_ptr[n], k1 = in_ptr[n + 1]; k < k1; ++k) {
-        const float w = e[in_eid[k]];
-        const float *g = gmio + (int64_t)in_nbr[k] * 2 * C + C;       // gmo[s]
+    csr_walk<LDH / 4, U>(in_ptr[n], in_ptr[n + 1],
+                         [&](int k) { return gmio + (int64_t)in_nbr[k] * 2 * LDH + LDH; },       // gmo[s]
+                         [&](int k) { return e[in_eid[k]]; }, add);
 #pragma unroll
-        for (int c = 0; c < C; ++c) acc[c] = fmaf(w, g[c], acc[c]);
-    }
-#pragma unroll
-    for (int c = 0; c < C; ++c) gH[n * ldh + c] += acc[c];
+    for (int c = 0; c < C; ++c) acc[c] += sum[c];
+    store_row4<LDH / 4>(gH + n * ldh, acc);
 }
 
 template <int F, int D>
@@ -364,7 +439,7 @@ BwdWs carve_bwd(char *b, int64_t N, int64_t E, int ldh, int C, int D)
     w.ge = take((size_t)E);
     w.gHa = take((size_t)N * ldh);
     w.gHb = take((size_t)N * ldh);
-    w.gmio = take((size_t)N * 2 * C);
+    w.gmio = take((size_t)N * 2 * ldh);      // [gmi | gmo], rows padded to LDH
     w.bytes = off;
     return w;
 }
@@ -389,9 +464,9 @@ int backward_t(const gnn_graph_t *g, const gnn_params_t *p, int T, const float *
         // edge pass t backward: adds into gH (gradient w.r.t. H_t)
         if (N > 0) GNN_LAUNCH("kb_pq", (kb_pq<F, D>), grid_for(N), kBlock, s, Ht, LDH, p->W1, p->b1, w.PQ, N);
         if (E > 0) {
-            GNN_LAUNCH("k_edge_bwd", (k_edge_bwd<D>), grid_for(E), kBlock, s, g->src, g->dst, w.PQ,
-                       p->b1, p->W2, et, ge, w.gz, gr->W2, gr->b2, E);
-            GNN_LAUNCH("k_pad_b1", (k_pad_b1<D>), grid_for(E), kBlock, s, g->src, w.gz, gr->b1, E);
+            const unsigned ge_grid = grid_for(E) < (unsigned)kSegGrid ? grid_for(E) : (unsigned)kSegGrid;
+            GNN_LAUNCH("k_edge_bwd", (k_edge_bwd<D>), ge_grid, kBlock, s, g->src, g->dst, w.PQ,
+                       p->b1, p->W2, et, ge, w.gz, gr->W2, gr->b2, gr->b1, E);
         }
         if (N > 0)
             GNN_LAUNCH("k_pq_bwd", (k_pq_bwd<F, D>), grid_for(N), kBlock, s, Ht, LDH, w.gz, g->in_ptr,

@@ -55,6 +55,48 @@ __device__ __forceinline__ float sigmoid_f(float x)
     return __builtin_amdgcn_rcpf(1.0f + t);
 }
 
+// Walk CSR entries [k0, k1) of one hit: `row_of(k)` gives the float row entry k points at (an
+// index load), `w_of(k)` its weight (an index load and a dependent gather), `use(w, row)` consumes
+// them IN ENTRY ORDER (the sums stay bit-identical to a plain loop).  A plain loop is two
+// dependent memory latencies per entry; here the index loads, weights and rows of U entries are
+// all in flight together before the first one is consumed.
+template <int N4, int U = 4, typename RowOf, typename WOf, typename Use>
+__device__ __forceinline__ void csr_walk(int k0, int k1, RowOf row_of, WOf w_of, Use use)
+{
+    int k = k0;
+    for (; k + U <= k1; k += U) {
+        const float *rp[U];
+        float w[U], r[U][4 * N4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) rp[u] = row_of(k + u);
+#pragma unroll
+        for (int u = 0; u < U; ++u) w[u] = w_of(k + u);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float4 *r4 = reinterpret_cast<const float4 *>(rp[u]);
+#pragma unroll
+            for (int i = 0; i < N4; ++i) {
+                const float4 a = r4[i];
+                r[u][4 * i] = a.x; r[u][4 * i + 1] = a.y; r[u][4 * i + 2] = a.z; r[u][4 * i + 3] = a.w;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) use(w[u], r[u]);
+    }
+    for (; k < k1; ++k) {
+        const float *rp = row_of(k);
+        const float w = w_of(k);
+        float r[4 * N4];
+        const float4 *r4 = reinterpret_cast<const float4 *>(rp);
+#pragma unroll
+        for (int i = 0; i < N4; ++i) {
+            const float4 a = r4[i];
+            r[4 * i] = a.x; r[4 * i + 1] = a.y; r[4 * i + 2] = a.z; r[4 * i + 3] = a.w;
+        }
+        use(w, r);
+    }
+}
+
 // forward of the plan-based pipeline (sell_pipeline.hip)
 int sell_forward(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e_out, void *ws,
                  size_t ws_bytes, hipStream_t s);

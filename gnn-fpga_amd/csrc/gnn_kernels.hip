@@ -217,31 +217,22 @@ __global__ __launch_bounds__(kBlock) void k_node(
         }
     }
     // segments ending here: weight e[j], features of the start hit      (model.py:117-118)
-    for (int k = in_ptr[n], k1 = in_ptr[n + 1]; k < k1; ++k) {
-        const float w = e[in_eid[k]];
-        const float4 *hp = reinterpret_cast<const float4 *>(H + (int64_t)in_nbr[k] * ldh);
+    constexpr int U = D <= 16 ? 4 : 1;
+    csr_walk<LDH / 4, U>(in_ptr[n], in_ptr[n + 1],
+                         [&](int k) { return H + (int64_t)in_nbr[k] * ldh; },
+                         [&](int k) { return e[in_eid[k]]; },
+                         [&](float w, const float *a) {
 #pragma unroll
-        for (int v = 0; v < LDH / 4; ++v) {
-            const float4 a = hp[v];
-            M[4 * v] = fmaf(w, a.x, M[4 * v]);
-            M[4 * v + 1] = fmaf(w, a.y, M[4 * v + 1]);
-            M[4 * v + 2] = fmaf(w, a.z, M[4 * v + 2]);
-            M[4 * v + 3] = fmaf(w, a.w, M[4 * v + 3]);
-        }
-    }
+                             for (int c = 0; c < LDH; ++c) M[c] = fmaf(w, a[c], M[c]);
+                         });
     // segments starting here: weight e[j], features of the end hit      (model.py:116,119)
-    for (int k = out_ptr[n], k1 = out_ptr[n + 1]; k < k1; ++k) {
-        const float w = e[out_eid[k]];
-        const float4 *hp = reinterpret_cast<const float4 *>(H + (int64_t)out_nbr[k] * ldh);
+    csr_walk<LDH / 4, U>(out_ptr[n], out_ptr[n + 1],
+                         [&](int k) { return H + (int64_t)out_nbr[k] * ldh; },
+                         [&](int k) { return e[out_eid[k]]; },
+                         [&](float w, const float *a) {
 #pragma unroll
-        for (int v = 0; v < LDH / 4; ++v) {
-            const float4 a = hp[v];
-            M[LDH + 4 * v] = fmaf(w, a.x, M[LDH + 4 * v]);
-            M[LDH + 4 * v + 1] = fmaf(w, a.y, M[LDH + 4 * v + 1]);
-            M[LDH + 4 * v + 2] = fmaf(w, a.z, M[LDH + 4 * v + 2]);
-            M[LDH + 4 * v + 3] = fmaf(w, a.w, M[LDH + 4 * v + 3]);
-        }
-    }
+                             for (int c = 0; c < LDH; ++c) M[LDH + c] = fmaf(w, a[c], M[LDH + c]);
+                         });
     // MLP on M = [mi | mo | h]                                          (model.py:120,94-98)
     float q[D];
 #pragma unroll
