@@ -97,7 +97,7 @@ __global__ __launch_bounds__(kBlock) void kb_pq(const float *__restrict__ H, int
                                                 float *__restrict__ PQ, int64_t n_hits)
 {
     constexpr int C = F + D;
-    const int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t n = xcd_block() * kBlock + threadIdx.x;
     if (n >= n_hits) return;
     float h[Shape<F, D>::LDH], pq[2 * D];
     load_row4<Shape<F, D>::LDH / 4>(H + n * ldh, h);
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(kBlock) void k_pq_bwd(
 {
     constexpr int C = F + D, LDH = Shape<F, D>::LDH;
     __shared__ float lds[outer_lds_floats<D, C>()];
-    const int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t n = xcd_block() * kBlock + threadIdx.x;
     const bool active = n < n_hits;
     float gP[D], gQ[D], h[C];
 #pragma unroll
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(kBlock) void k_node_bwd(
 {
     constexpr int C = Shape<F, D>::C, LDH = Shape<F, D>::LDH;
     __shared__ float lds[outer_lds_floats<D, 3 * C>()];
-    const int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t n = xcd_block() * kBlock + threadIdx.x;
     const bool active = n < n_hits;
     float M[3 * C], q[D], gr[D], gp[D];
 #pragma unroll
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(kBlock) void k_agg_bwd_e(const int32_t *__restrict_
                                                       float *__restrict__ ge, int64_t n_segments)
 {
     constexpr int C = F + D, LDH = Shape<F, D>::LDH;
-    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t j = xcd_block() * kBlock + threadIdx.x;
     if (j >= n_segments) return;
     const int s = src[j], d = dst[j];
     float acc = 0.0f;
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(kBlock) void k_agg_bwd_n(
     float *__restrict__ gH, int ldh, int64_t n_hits)
 {
     constexpr int C = F + D, LDH = Shape<F, D>::LDH;
-    const int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t n = xcd_block() * kBlock + threadIdx.x;
     if (n >= n_hits) return;
     float acc[LDH];
     load_row4<LDH / 4>(gH + n * ldh, acc);
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(kBlock) void k_input_bwd(const float *__restrict__ 
                                                       float *__restrict__ gbin, int64_t n_hits)
 {
     __shared__ float lds[kBlock * (D + F)];
-    const int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t n = xcd_block() * kBlock + threadIdx.x;
     const bool active = n < n_hits;
     float g[D], x[F];
 #pragma unroll

@@ -38,7 +38,23 @@ void prof_post(hipStream_t s);
 
 constexpr int kBlock = 256;   // 4 waves of 64
 
-inline unsigned grid_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+// one item per thread; grids beyond 8 workgroups are rounded up to a multiple of 8 so that
+// xcd_block() below is a bijection (the surplus workgroups find nothing to do)
+inline unsigned grid_for(int64_t n)
+{
+    const unsigned g = (unsigned)((n + kBlock - 1) / kBlock);
+    return g > 8 ? (g + 7) & ~7u : g;
+}
+
+// Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Items are stored graph
+// by graph (hits, segments), and a kernel's gathers stay inside the item's graph: with the plain
+// blockIdx order every XCD works on every graph in flight and its L2 thrashes; here XCD x takes
+// a CONTIGUOUS eighth of the items, a few graphs at a time.
+__device__ __forceinline__ int64_t xcd_block()
+{
+    const unsigned g = gridDim.x, b = blockIdx.x;
+    return (g & 7) ? b : (b & 7) * (g >> 3) + (b >> 3);
+}
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // tanh(x) = 1 - 2 / (2^(2 log2(e) x) + 1): v_exp_f32 + v_rcp_f32 (1 ulp each), absolute error

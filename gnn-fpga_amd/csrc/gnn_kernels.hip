@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kBlock) void k_input(const float *__restrict__ X,
                                                   float *__restrict__ PQ, int64_t n_hits)
 {
     constexpr int LDH = Shape<F, D>::LDH;
-    const int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t n = xcd_block() * kBlock + threadIdx.x;
     if (n >= n_hits) return;
     float h[LDH];
 #pragma unroll
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kBlock) void k_pq(const float *__restrict__ H, int 
                                                float *__restrict__ PQ, int64_t n_hits)
 {
     constexpr int C = F + D;
-    const int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t n = xcd_block() * kBlock + threadIdx.x;
     if (n >= n_hits) return;
     float h[C];
 #pragma unroll
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(kBlock) void k_edge(const int32_t *__restrict__ src
                                                  const float *__restrict__ b2,
                                                  float *__restrict__ e, int64_t n_segments)
 {
-    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t j = xcd_block() * kBlock + threadIdx.x;
     if (j >= n_segments) return;
     const int s = src[j], d = dst[j];
     float z[D];
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kBlock) void k_node(
 {
     constexpr int C = Shape<F, D>::C;
     constexpr int LDH = Shape<F, D>::LDH;
-    const int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t n = xcd_block() * kBlock + threadIdx.x;
     if (n >= n_hits) return;
 
     float M[3 * LDH];   // [mi | mo | h], each padded to LDH
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(64) void k_exp_bound(const float *__restrict__ W1,
 __global__ __launch_bounds__(kBlock) void k_unpad(const float *__restrict__ H, int ldh, int C,
                                                   float *__restrict__ out, int64_t total)
 {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t i = xcd_block() * kBlock + threadIdx.x;
     if (i >= total) return;
     out[i] = H[(i / C) * ldh + (i % C)];
 }
