@@ -7,9 +7,9 @@
 // autograd in fp64).  Index form, CSR pulls, fp32:
 //
 //   edge pass t   e = sigmoid(u), u = W2 a + b2, a = tanh(z), z = P[s] + Q[d]
-//       k_edge_bwd   per segment:  gu = ge e (1-e);  gz = gu W2 (1-a^2)  -> gz[E,D];  gW2, gb2
-//                                  (+ gb1 of the padded segments)
-//       k_pq_bwd     per hit:      gP = sum_out gz, gQ = sum_in gz (CSR pulls, fixed order)
+//       k_edge_bwd   per segment:  gu = ge e (1-e) -> gu[E];  gW2, gb2 (+ gb1 of the padded segments)
+//       k_pq_bwd     per hit:      gz = gu W2 (1-a^2) rebuilt per CSR entry from the other end's
+//                                  P / Q row;  gP = sum_out gz, gQ = sum_in gz (fixed order)
 //                                  gH += W1[:, :C]^T gP + W1[:, C:]^T gQ;  gW1, gb1
 //   node pass t   H' = tanh(W4 q + b4), q = tanh(W3 M + b3), M = [mi | mo | H]
 //       k_node_bwd   per hit: recompute M, q; gr = gH' (1-H'^2); gp = W4^T gr (1-q^2);
@@ -20,7 +20,8 @@
 //
 // Weight gradients are sums of per-item outer products: a workgroup parks its 256 items' factors
 // in LDS, each thread then owns output elements and sums over the 256 items (fixed order), and
-// one atomicAdd per element per workgroup goes to the (zero-initialised) gradient tensor.
+// one atomicAdd per element per workgroup goes to the (zero-initialised) gradient tensor
+// (accum_outer; the per-segment kernel keeps private sums instead, see kSegGrid).
 // Only the order of those cross-workgroup atomics is run-dependent (last-bit differences).
 #include "common.h"
 
@@ -52,41 +53,55 @@ __device__ __forceinline__ void store_row4(float *__restrict__ row, const float 
     for (int i = 0; i < N4; ++i) r[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
 }
 
-// sum over the workgroup's items of L (x) R, added into g[i * ldg + col0 + k]
+// Sum over the workgroup's 256 items of L (x) R, added into g[i * ldg + col0 + k], and (gb != null)
+// of L itself, added into gb[i].  The items' factors are parked in LDS TRANSPOSED - row c holds
+// factor c of all 256 items, rows padded by 4 floats - so that the thread that owns an output
+// element walks two rows with 16-byte reads (4 items per read, bank-conflict free across the
+// wavefront: neighbouring threads own neighbouring k, i.e. rows 4 banks apart), in item order.
+// One atomicAdd per element per workgroup goes to the (zero-initialised) gradient tensor.
+// Wide right factors: the staging area is capped at kOuterCap rows (133 KB), the columns of R are
+// taken in chunks that fit beside L.
+constexpr int kOuterCap = 128, kOuterStride = kBlock + 4;
 template <int NL, int NR>
-__device__ __forceinline__ void accum_outer(const float *L, const float *R, bool active, float *g,
-                                            int ldg, int col0, float *lds)
-{
-    constexpr int S = NL + NR;
-    float *mine = lds + threadIdx.x * S;
-#pragma unroll
-    for (int i = 0; i < NL; ++i) mine[i] = active ? L[i] : 0.0f;
-#pragma unroll
-    for (int k = 0; k < NR; ++k) mine[NL + k] = active ? R[k] : 0.0f;
-    __syncthreads();
-    for (int o = threadIdx.x; o < NL * NR; o += kBlock) {
-        const int i = o / NR, k = o % NR;
-        float acc = 0.0f;
-        for (int t = 0; t < kBlock; ++t) acc = fmaf(lds[t * S + i], lds[t * S + NL + k], acc);
-        atomicAdd(&g[i * ldg + col0 + k], acc);
-    }
-    __syncthreads();
-}
-
-// same for wide right factors: the LDS staging area is capped at kOuterCap floats per item
-// (128 KB per workgroup), the columns of R are taken in chunks that fit beside L
-constexpr int kOuterCap = 128;
-template <int NL, int NR>
-constexpr int outer_lds_floats() { return kBlock * ((NL + NR) < kOuterCap ? (NL + NR) : kOuterCap); }
+constexpr int outer_lds_floats() { return kOuterStride * ((NL + NR) < kOuterCap ? (NL + NR) : kOuterCap); }
 
 template <int NL, int NR, int C0 = 0>
-__device__ __forceinline__ void accum_outer_wide(const float *L, const float *R, bool active,
-                                                 float *g, int ldg, int col0, float *lds)
+__device__ __forceinline__ void accum_outer(const float *L, const float *R, bool active, float *g,
+                                            int ldg, int col0, float *gb, float *lds)
 {
     static_assert(NL < kOuterCap, "left factor too wide");
-    constexpr int CH = (NL + NR - C0 <= kOuterCap) ? NR - C0 : kOuterCap - NL;
-    accum_outer<NL, CH>(L, R + C0, active, g, ldg, col0 + C0, lds);
-    if constexpr (C0 + CH < NR) accum_outer_wide<NL, NR, C0 + CH>(L, R, active, g, ldg, col0, lds);
+    constexpr int CH = (NL + NR - C0 <= kOuterCap) ? NR - C0 : kOuterCap - NL, RS = kOuterStride;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) lds[i * RS + threadIdx.x] = active ? L[i] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) lds[(NL + k) * RS + threadIdx.x] = active ? R[C0 + k] : 0.0f;
+    __syncthreads();
+    const int n_out = NL * CH + ((C0 == 0 && gb) ? NL : 0);
+    for (int o = threadIdx.x; o < n_out; o += kBlock) {
+        const bool bias = o >= NL * CH;
+        const int i = bias ? o - NL * CH : o / CH, k = bias ? 0 : o % CH;
+        const float4 *a = reinterpret_cast<const float4 *>(lds + i * RS);
+        const float4 *b = reinterpret_cast<const float4 *>(lds + (NL + k) * RS);
+        float acc = 0.0f;
+        if (bias) {
+#pragma unroll 4
+            for (int t = 0; t < kBlock / 4; ++t) {
+                const float4 x = a[t];
+                acc += x.x; acc += x.y; acc += x.z; acc += x.w;
+            }
+            atomicAdd(&gb[i], acc);
+        } else {
+#pragma unroll 4
+            for (int t = 0; t < kBlock / 4; ++t) {
+                const float4 x = a[t], y = b[t];
+                acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc);
+                acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
+            }
+            atomicAdd(&g[i * ldg + col0 + C0 + k], acc);
+        }
+    }
+    __syncthreads();
+    if constexpr (C0 + CH < NR) accum_outer<NL, NR, C0 + CH>(L, R, active, g, ldg, col0, gb, lds);
 }
 
 // P/Q rows from H (same as the forward's k_pq; kept local to this file)
@@ -127,7 +142,7 @@ template <int D>
 __global__ __launch_bounds__(kBlock) void k_edge_bwd(
     const int32_t *__restrict__ src, const int32_t *__restrict__ dst,
     const float *__restrict__ PQ, const float *__restrict__ b1, const float *__restrict__ W2,
-    const float *__restrict__ e, const float *__restrict__ ge, float *__restrict__ gz,
+    const float *__restrict__ e, const float *__restrict__ ge, float *__restrict__ gu_out,
     float *__restrict__ gW2, float *__restrict__ gb2, float *__restrict__ gb1, int64_t n_segments)
 {
     __shared__ float lds[(kBlock / 64) * (2 * D + 1)];
@@ -159,18 +174,14 @@ __global__ __launch_bounds__(kBlock) void k_edge_bwd(
         }
         const float ev = e[j];
         const float gu = ge[j] * ev * (1.0f - ev);
-        float g[D];
 #pragma unroll
         for (int i = 0; i < D; ++i) {
             const float a = tanh_f(z[i]);
-            g[i] = gu * w2[i] * (1.0f - a * a);
             sum[i] = fmaf(gu, a, sum[i]);
-            sum[D + i] += s < 0 ? g[i] : 0.0f;
+            sum[D + i] += s < 0 ? gu * w2[i] * (1.0f - a * a) : 0.0f;
         }
         sum[2 * D] += gu;
-        float4 *o = reinterpret_cast<float4 *>(gz + j * D);
-#pragma unroll
-        for (int v = 0; v < D / 4; ++v) o[v] = make_float4(g[4 * v], g[4 * v + 1], g[4 * v + 2], g[4 * v + 3]);
+        gu_out[j] = gu;
     }
     {
         constexpr int NW = kBlock / 64, N = 2 * D + 1;
@@ -194,14 +205,15 @@ __global__ __launch_bounds__(kBlock) void k_edge_bwd(
 
 template <int F, int D>
 __global__ __launch_bounds__(kBlock) void k_pq_bwd(
-    const float *__restrict__ H, int ldh, const float *__restrict__ gz,
+    const float *__restrict__ H, int ldh, const float *__restrict__ PQ, const float *__restrict__ gu,
     const int32_t *__restrict__ in_ptr, const int32_t *__restrict__ in_eid,
-    const int32_t *__restrict__ out_ptr, const int32_t *__restrict__ out_eid,
-    const float *__restrict__ W1, float *__restrict__ gH, float *__restrict__ gW1,
-    float *__restrict__ gb1, int64_t n_pad_edges_b1, int64_t n_hits)
+    const int32_t *__restrict__ in_nbr, const int32_t *__restrict__ out_ptr,
+    const int32_t *__restrict__ out_eid, const int32_t *__restrict__ out_nbr,
+    const float *__restrict__ W1, const float *__restrict__ W2, float *__restrict__ gH,
+    float *__restrict__ gW1, float *__restrict__ gb1, int64_t n_hits)
 {
     constexpr int C = F + D, LDH = Shape<F, D>::LDH;
-    __shared__ float lds[outer_lds_floats<D, C>()];
+    __shared__ __attribute__((aligned(16))) float lds[outer_lds_floats<D, C>()];
     const int64_t n = xcd_block() * kBlock + threadIdx.x;
     const bool active = n < n_hits;
     float gP[D], gQ[D], h[C];
@@ -210,18 +222,33 @@ __global__ __launch_bounds__(kBlock) void k_pq_bwd(
 #pragma unroll
     for (int k = 0; k < C; ++k) h[k] = 0.0f;
     if (active) {
+        // gz of a segment is rebuilt from the other end's P / Q row (small, cache-resident) and
+        // the segment's gu instead of being stored per segment by k_edge_bwd and gathered here
+        // (E x D floats through HBM, twice)
         constexpr int U = D <= 16 ? 4 : 2;
-        csr_walk<D / 4, U>(out_ptr[n], out_ptr[n + 1],
-                           [&](int k) { return gz + (int64_t)out_eid[k] * D; }, [](int) { return 1.0f; },
-                           [&](float, const float *r) {
+        float own[2 * D], w2[D];
+        load_row4<2 * D / 4>(PQ + n * 2 * D, own);
 #pragma unroll
-                               for (int i = 0; i < D; ++i) gP[i] += r[i];
+        for (int i = 0; i < D; ++i) w2[i] = W2[i];
+        csr_walk<D / 4, U>(out_ptr[n], out_ptr[n + 1],
+                           [&](int k) { return PQ + (int64_t)out_nbr[k] * 2 * D + D; },      // Q[d]
+                           [&](int k) { return gu[out_eid[k]]; },
+                           [&](float g, const float *r) {
+#pragma unroll
+                               for (int i = 0; i < D; ++i) {
+                                   const float a = tanh_f(own[i] + r[i]);
+                                   gP[i] += g * w2[i] * (1.0f - a * a);
+                               }
                            });
         csr_walk<D / 4, U>(in_ptr[n], in_ptr[n + 1],
-                           [&](int k) { return gz + (int64_t)in_eid[k] * D; }, [](int) { return 1.0f; },
-                           [&](float, const float *r) {
+                           [&](int k) { return PQ + (int64_t)in_nbr[k] * 2 * D; },           // P[s]
+                           [&](int k) { return gu[in_eid[k]]; },
+                           [&](float g, const float *r) {
 #pragma unroll
-                               for (int i = 0; i < D; ++i) gQ[i] += r[i];
+                               for (int i = 0; i < D; ++i) {
+                                   const float a = tanh_f(r[i] + own[D + i]);
+                                   gQ[i] += g * w2[i] * (1.0f - a * a);
+                               }
                            });
         float hr[LDH], gh[LDH];
         load_row4<LDH / 4>(H + n * ldh, hr);
@@ -240,11 +267,8 @@ __global__ __launch_bounds__(kBlock) void k_pq_bwd(
         }
         store_row4<LDH / 4>(gH + n * ldh, gh);
     }
-    const float one = 1.0f;
-    accum_outer_wide<D, C>(gP, h, active, gW1, 2 * C, 0, lds);
-    accum_outer_wide<D, C>(gQ, h, active, gW1, 2 * C, C, lds);
-    accum_outer<D, 1>(gP, &one, active, gb1, 1, 0, lds);
-    (void)n_pad_edges_b1;
+    accum_outer<D, C>(gP, h, active, gW1, 2 * C, 0, gb1, lds);
+    accum_outer<D, C>(gQ, h, active, gW1, 2 * C, C, nullptr, lds);
 }
 
 template <int F, int D>
@@ -259,7 +283,7 @@ __global__ __launch_bounds__(kBlock) void k_node_bwd(
     float *__restrict__ gb3, float *__restrict__ gW4, float *__restrict__ gb4, int64_t n_hits)
 {
     constexpr int C = Shape<F, D>::C, LDH = Shape<F, D>::LDH;
-    __shared__ float lds[outer_lds_floats<D, 3 * C>()];
+    __shared__ __attribute__((aligned(16))) float lds[outer_lds_floats<D, 3 * C>()];
     const int64_t n = xcd_block() * kBlock + threadIdx.x;
     const bool active = n < n_hits;
     float M[3 * C], q[D], gr[D], gp[D];
@@ -324,11 +348,8 @@ __global__ __launch_bounds__(kBlock) void k_node_bwd(
         store_row4<LDH / 4>(gmio + n * 2 * LDH + LDH, gm[1]);
         store_row4<LDH / 4>(gH + n * ldh, gm[2]);                // gHself initialises gH_prev
     }
-    const float one = 1.0f;
-    accum_outer_wide<D, 3 * C>(gp, M, active, gW3, 3 * C, 0, lds);
-    accum_outer<D, 1>(gp, &one, active, gb3, 1, 0, lds);
-    accum_outer_wide<D, D>(gr, q, active, gW4, D, 0, lds);
-    accum_outer<D, 1>(gr, &one, active, gb4, 1, 0, lds);
+    accum_outer<D, 3 * C>(gp, M, active, gW3, 3 * C, 0, gb3, lds);
+    accum_outer<D, D>(gr, q, active, gW4, D, 0, gb4, lds);
 }
 
 template <int F, int D>
@@ -398,7 +419,7 @@ __global__ __launch_bounds__(kBlock) void k_input_bwd(const float *__restrict__ 
                                                       float *__restrict__ gWin,
                                                       float *__restrict__ gbin, int64_t n_hits)
 {
-    __shared__ float lds[kBlock * (D + F)];
+    __shared__ __attribute__((aligned(16))) float lds[outer_lds_floats<D, F>()];
     const int64_t n = xcd_block() * kBlock + threadIdx.x;
     const bool active = n < n_hits;
     float g[D], x[F];
@@ -415,13 +436,11 @@ __global__ __launch_bounds__(kBlock) void k_input_bwd(const float *__restrict__ 
 #pragma unroll
         for (int k = 0; k < F; ++k) x[k] = X[n * F + k];
     }
-    const float one = 1.0f;
-    accum_outer<D, F>(g, x, active, gWin, F, 0, lds);
-    accum_outer<D, 1>(g, &one, active, gbin, 1, 0, lds);
+    accum_outer<D, F>(g, x, active, gWin, F, 0, gbin, lds);
 }
 
 struct BwdWs {
-    float *PQ, *gz, *ge, *gHa, *gHb, *gmio;
+    float *PQ, *gu, *ge, *gHa, *gHb, *gmio;
     size_t bytes;
 };
 
@@ -435,7 +454,7 @@ BwdWs carve_bwd(char *b, int64_t N, int64_t E, int ldh, int C, int D)
         return p;
     };
     w.PQ = take((size_t)N * 2 * D);
-    w.gz = take((size_t)E * D);
+    w.gu = take((size_t)E);
     w.ge = take((size_t)E);
     w.gHa = take((size_t)N * ldh);
     w.gHb = take((size_t)N * ldh);
@@ -466,11 +485,12 @@ int backward_t(const gnn_graph_t *g, const gnn_params_t *p, int T, const float *
         if (E > 0) {
             const unsigned ge_grid = grid_for(E) < (unsigned)kSegGrid ? grid_for(E) : (unsigned)kSegGrid;
             GNN_LAUNCH("k_edge_bwd", (k_edge_bwd<D>), ge_grid, kBlock, s, g->src, g->dst, w.PQ,
-                       p->b1, p->W2, et, ge, w.gz, gr->W2, gr->b2, gr->b1, E);
+                       p->b1, p->W2, et, ge, w.gu, gr->W2, gr->b2, gr->b1, E);
         }
         if (N > 0)
-            GNN_LAUNCH("k_pq_bwd", (k_pq_bwd<F, D>), grid_for(N), kBlock, s, Ht, LDH, w.gz, g->in_ptr,
-                       g->in_eid, g->out_ptr, g->out_eid, p->W1, gH, gr->W1, gr->b1, (int64_t)0, N);
+            GNN_LAUNCH("k_pq_bwd", (k_pq_bwd<F, D>), grid_for(N), kBlock, s, Ht, LDH, w.PQ, w.gu,
+                       g->in_ptr, g->in_eid, g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, p->W1, p->W2,
+                       gH, gr->W1, gr->b1, N);
         if (t == 0) break;
         // node pass t-1 backward: H_{t-1}, e_{t-1} -> H_t
         const float *Hp = H_all + (size_t)(t - 1) * N * LDH;
