@@ -53,8 +53,8 @@ __device__ __forceinline__ void store_row4(float *__restrict__ row, const float 
     for (int i = 0; i < N4; ++i) r[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
 }
 
-// Sum over the workgroup's 256 items of L (x) R, added into g[i * ldg + col0 + k], and (gb != null)
-// of L itself, added into gb[i].  The items' factors are parked in LDS TRANSPOSED - row c holds
+// Sum over the workgroup's 256 items of L (x) [R | 1], added into g[i * ldg + col0 + k] and (the
+// ones column, gb != null) into gb[i].  The items' factors are parked in LDS TRANSPOSED - row c holds
 // factor c of all 256 items, rows padded by 4 floats - so that the thread that owns an output
 // element walks two rows with 16-byte reads (4 items per read, bank-conflict free across the
 // wavefront: neighbouring threads own neighbouring k, i.e. rows 4 banks apart), in item order.
@@ -62,43 +62,47 @@ __device__ __forceinline__ void store_row4(float *__restrict__ row, const float 
 // Wide right factors: the staging area is capped at kOuterCap rows (133 KB), the columns of R are
 // taken in chunks that fit beside L.
 constexpr int kOuterCap = 128, kOuterStride = kBlock + 4;
+
+// Gradient atomics go to one of 8 REPLICAS of the gradient vector, picked by the XCD the
+// workgroup runs on (workgroups are dealt round-robin): a replica's lines then stay in one L2
+// instead of bouncing between the 8 of them (k_pq_bwd: 135 -> ~100 us at 320 k hits).
+// k_grad_fold adds the replicas into the caller's tensors once per backward.
+constexpr int kReplicas = 8;
+__device__ __forceinline__ float *my_replica(float *g, int rep_stride)
+{
+    return g + (size_t)(blockIdx.x & (kReplicas - 1)) * rep_stride;
+}
 template <int NL, int NR>
-constexpr int outer_lds_floats() { return kOuterStride * ((NL + NR) < kOuterCap ? (NL + NR) : kOuterCap); }
+constexpr int outer_lds_floats() { return kOuterStride * ((NL + NR + 1) < kOuterCap ? (NL + NR + 1) : kOuterCap); }
 
 template <int NL, int NR, int C0 = 0>
 __device__ __forceinline__ void accum_outer(const float *L, const float *R, bool active, float *g,
                                             int ldg, int col0, float *gb, float *lds)
 {
-    static_assert(NL < kOuterCap, "left factor too wide");
-    constexpr int CH = (NL + NR - C0 <= kOuterCap) ? NR - C0 : kOuterCap - NL, RS = kOuterStride;
+    static_assert(NL + 1 < kOuterCap, "left factor too wide");
+    // rows: L (NL) | this chunk of R (CH) | ones (the bias column, first chunk only)
+    constexpr bool ONES = (C0 == 0);
+    constexpr int ROOM = kOuterCap - NL - (ONES ? 1 : 0);
+    constexpr int CH = (NR - C0 <= ROOM) ? NR - C0 : ROOM, RS = kOuterStride;
 #pragma unroll
     for (int i = 0; i < NL; ++i) lds[i * RS + threadIdx.x] = active ? L[i] : 0.0f;
 #pragma unroll
     for (int k = 0; k < CH; ++k) lds[(NL + k) * RS + threadIdx.x] = active ? R[C0 + k] : 0.0f;
+    if constexpr (ONES) lds[(NL + CH) * RS + threadIdx.x] = active ? 1.0f : 0.0f;
     __syncthreads();
-    const int n_out = NL * CH + ((C0 == 0 && gb) ? NL : 0);
-    for (int o = threadIdx.x; o < n_out; o += kBlock) {
-        const bool bias = o >= NL * CH;
-        const int i = bias ? o - NL * CH : o / CH, k = bias ? 0 : o % CH;
+    const int cols = CH + ((ONES && gb) ? 1 : 0);
+    for (int o = threadIdx.x; o < NL * cols; o += kBlock) {
+        const int i = o / cols, k = o % cols;
         const float4 *a = reinterpret_cast<const float4 *>(lds + i * RS);
         const float4 *b = reinterpret_cast<const float4 *>(lds + (NL + k) * RS);
         float acc = 0.0f;
-        if (bias) {
 #pragma unroll 4
-            for (int t = 0; t < kBlock / 4; ++t) {
-                const float4 x = a[t];
-                acc += x.x; acc += x.y; acc += x.z; acc += x.w;
-            }
-            atomicAdd(&gb[i], acc);
-        } else {
-#pragma unroll 4
-            for (int t = 0; t < kBlock / 4; ++t) {
-                const float4 x = a[t], y = b[t];
-                acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc);
-                acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
-            }
-            atomicAdd(&g[i * ldg + col0 + C0 + k], acc);
+        for (int t = 0; t < kBlock / 4; ++t) {
+            const float4 x = a[t], y = b[t];
+            acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc);
+            acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
         }
+        atomicAdd(k < CH ? &g[i * ldg + col0 + C0 + k] : &gb[i], acc);
     }
     __syncthreads();
     if constexpr (C0 + CH < NR) accum_outer<NL, NR, C0 + CH>(L, R, active, g, ldg, col0, gb, lds);
@@ -143,48 +147,44 @@ __global__ __launch_bounds__(kBlock) void k_edge_bwd(
     const int32_t *__restrict__ src, const int32_t *__restrict__ dst,
     const float *__restrict__ PQ, const float *__restrict__ b1, const float *__restrict__ W2,
     const float *__restrict__ e, const float *__restrict__ ge, float *__restrict__ gu_out,
-    float *__restrict__ gW2, float *__restrict__ gb2, float *__restrict__ gb1, int64_t n_segments)
+    float *__restrict__ gW2, float *__restrict__ gb2, float *__restrict__ gb1, int rep_stride,
+    int64_t n_segments)
 {
-    __shared__ float lds[(kBlock / 64) * (2 * D + 1)];
-    float sum[2 * D + 1];                  // gW2[D] | gb1 share of the padded segments [D] | gb2
+    gW2 = my_replica(gW2, rep_stride);
+    gb2 = my_replica(gb2, rep_stride);
+    gb1 = my_replica(gb1, rep_stride);
+    __shared__ float lds[(kBlock / 64) * (D + 2)];
+    // private sums: gW2[D] | gb2 | sum of gu over the padded segments.  A padded segment has
+    // z = b1, the same for all of them, so its gz = gu W2 (1 - tanh(b1)^2) needs only that sum.
+    float sum[D + 2];
 #pragma unroll
-    for (int i = 0; i < 2 * D + 1; ++i) sum[i] = 0.0f;
-    float w2[D], bb[D];
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-        w2[i] = W2[i];
-        bb[i] = b1[i];
-    }
+    for (int i = 0; i < D + 2; ++i) sum[i] = 0.0f;
     for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n_segments;
          j += (int64_t)gridDim.x * kBlock) {
         const int s = src[j], d = dst[j];
-        float z[D];
+        const float ev = e[j];
+        const float gu = ge[j] * ev * (1.0f - ev);
         if (s >= 0) {
             const float4 *p = reinterpret_cast<const float4 *>(PQ + (int64_t)s * 2 * D);
             const float4 *q = reinterpret_cast<const float4 *>(PQ + (int64_t)d * 2 * D + D);
 #pragma unroll
             for (int v = 0; v < D / 4; ++v) {
                 const float4 a = p[v], b = q[v];
-                z[4 * v] = a.x + b.x; z[4 * v + 1] = a.y + b.y;
-                z[4 * v + 2] = a.z + b.z; z[4 * v + 3] = a.w + b.w;
+                sum[4 * v] = fmaf(gu, tanh_f(a.x + b.x), sum[4 * v]);
+                sum[4 * v + 1] = fmaf(gu, tanh_f(a.y + b.y), sum[4 * v + 1]);
+                sum[4 * v + 2] = fmaf(gu, tanh_f(a.z + b.z), sum[4 * v + 2]);
+                sum[4 * v + 3] = fmaf(gu, tanh_f(a.w + b.w), sum[4 * v + 3]);
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < D; ++i) z[i] = bb[i];
+            for (int i = 0; i < D; ++i) sum[i] = fmaf(gu, tanh_f(b1[i]), sum[i]);
+            sum[D + 1] += gu;
         }
-        const float ev = e[j];
-        const float gu = ge[j] * ev * (1.0f - ev);
-#pragma unroll
-        for (int i = 0; i < D; ++i) {
-            const float a = tanh_f(z[i]);
-            sum[i] = fmaf(gu, a, sum[i]);
-            sum[D + i] += s < 0 ? gu * w2[i] * (1.0f - a * a) : 0.0f;
-        }
-        sum[2 * D] += gu;
+        sum[D] += gu;
         gu_out[j] = gu;
     }
     {
-        constexpr int NW = kBlock / 64, N = 2 * D + 1;
+        constexpr int NW = kBlock / 64, N = D + 2;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             float x = sum[i];
@@ -193,12 +193,18 @@ __global__ __launch_bounds__(kBlock) void k_edge_bwd(
             if ((threadIdx.x & 63) == 0) lds[(threadIdx.x >> 6) * N + i] = x;
         }
         __syncthreads();
-        if ((int)threadIdx.x < N) {
+        if ((int)threadIdx.x <= D) {
             float x = 0.0f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) x += lds[w * N + threadIdx.x];
-            const int i = threadIdx.x;
-            atomicAdd(i < D ? gW2 + i : i < 2 * D ? gb1 + (i - D) : gb2, x);
+            atomicAdd((int)threadIdx.x < D ? gW2 + threadIdx.x : gb2, x);
+        } else if ((int)threadIdx.x < 2 * D + 1) {
+            const int i = threadIdx.x - D - 1;
+            float x = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) x += lds[w * N + D + 1];
+            const float a = tanh_f(b1[i]);
+            if (x != 0.0f) atomicAdd(gb1 + i, x * W2[i] * (1.0f - a * a));
         }
     }
 }
@@ -210,8 +216,10 @@ __global__ __launch_bounds__(kBlock) void k_pq_bwd(
     const int32_t *__restrict__ in_nbr, const int32_t *__restrict__ out_ptr,
     const int32_t *__restrict__ out_eid, const int32_t *__restrict__ out_nbr,
     const float *__restrict__ W1, const float *__restrict__ W2, float *__restrict__ gH,
-    float *__restrict__ gW1, float *__restrict__ gb1, int64_t n_hits)
+    float *__restrict__ gW1, float *__restrict__ gb1, int rep_stride, int64_t n_hits)
 {
+    gW1 = my_replica(gW1, rep_stride);
+    gb1 = my_replica(gb1, rep_stride);
     constexpr int C = F + D, LDH = Shape<F, D>::LDH;
     __shared__ __attribute__((aligned(16))) float lds[outer_lds_floats<D, C>()];
     const int64_t n = xcd_block() * kBlock + threadIdx.x;
@@ -280,8 +288,13 @@ __global__ __launch_bounds__(kBlock) void k_node_bwd(
     const int32_t *__restrict__ out_nbr, const float *__restrict__ W3,
     const float *__restrict__ b3, const float *__restrict__ W4, const float *__restrict__ gHn,
     float *__restrict__ gH, float *__restrict__ gmio, float *__restrict__ gW3,
-    float *__restrict__ gb3, float *__restrict__ gW4, float *__restrict__ gb4, int64_t n_hits)
+    float *__restrict__ gb3, float *__restrict__ gW4, float *__restrict__ gb4, int rep_stride,
+    int64_t n_hits)
 {
+    gW3 = my_replica(gW3, rep_stride);
+    gb3 = my_replica(gb3, rep_stride);
+    gW4 = my_replica(gW4, rep_stride);
+    gb4 = my_replica(gb4, rep_stride);
     constexpr int C = Shape<F, D>::C, LDH = Shape<F, D>::LDH;
     __shared__ __attribute__((aligned(16))) float lds[outer_lds_floats<D, 3 * C>()];
     const int64_t n = xcd_block() * kBlock + threadIdx.x;
@@ -417,8 +430,11 @@ __global__ __launch_bounds__(kBlock) void k_input_bwd(const float *__restrict__ 
                                                       const float *__restrict__ H0, int ldh,
                                                       const float *__restrict__ gH,
                                                       float *__restrict__ gWin,
-                                                      float *__restrict__ gbin, int64_t n_hits)
+                                                      float *__restrict__ gbin, int rep_stride,
+                                                      int64_t n_hits)
 {
+    gWin = my_replica(gWin, rep_stride);
+    gbin = my_replica(gbin, rep_stride);
     __shared__ __attribute__((aligned(16))) float lds[outer_lds_floats<D, F>()];
     const int64_t n = xcd_block() * kBlock + threadIdx.x;
     const bool active = n < n_hits;
@@ -439,8 +455,41 @@ __global__ __launch_bounds__(kBlock) void k_input_bwd(const float *__restrict__ 
     accum_outer<D, F>(g, x, active, gWin, F, 0, gbin, lds);
 }
 
+// layout of one gradient replica (floats): the ten tensors in state_dict order
+template <int F, int D>
+struct GradLayout {
+    static constexpr int C = F + D;
+    static constexpr int oWin = 0, obin = oWin + D * F, oW1 = obin + D, ob1 = oW1 + D * 2 * C,
+                         oW2 = ob1 + D, ob2 = oW2 + D, oW3 = ob2 + 1, ob3 = oW3 + D * 3 * C,
+                         oW4 = ob3 + D, ob4 = oW4 + D * D, total = ob4 + D;
+    static constexpr int stride = (total + 63) & ~63;      // replicas on separate 256-byte lines
+};
+
+template <int F, int D>
+__global__ __launch_bounds__(kBlock) void k_grad_fold(const float *__restrict__ rep, gnn_grads_t gr)
+{
+    using G = GradLayout<F, D>;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= G::total) return;
+    float sum = 0.0f;
+#pragma unroll
+    for (int x = 0; x < kReplicas; ++x) sum += rep[x * G::stride + i];
+    float *dst = i < G::obin ? gr.Win + (i - G::oWin)
+               : i < G::oW1 ? gr.bin + (i - G::obin)
+               : i < G::ob1 ? gr.W1 + (i - G::oW1)
+               : i < G::oW2 ? gr.b1 + (i - G::ob1)
+               : i < G::ob2 ? gr.W2 + (i - G::oW2)
+               : i < G::oW3 ? gr.b2 + (i - G::ob2)
+               : i < G::ob3 ? gr.W3 + (i - G::oW3)
+               : i < G::oW4 ? gr.b3 + (i - G::ob3)
+               : i < G::ob4 ? gr.W4 + (i - G::oW4)
+                            : gr.b4 + (i - G::ob4);
+    *dst += sum;
+}
+
 struct BwdWs {
-    float *PQ, *gu, *ge, *gHa, *gHb, *gmio;
+    float *PQ, *gu, *ge, *gHa, *gHb, *gmio, *rep;
+    char *rep_end;
     size_t bytes;
 };
 
@@ -456,9 +505,14 @@ BwdWs carve_bwd(char *b, int64_t N, int64_t E, int ldh, int C, int D)
     w.PQ = take((size_t)N * 2 * D);
     w.gu = take((size_t)E);
     w.ge = take((size_t)E);
-    w.gHa = take((size_t)N * ldh);
     w.gHb = take((size_t)N * ldh);
     w.gmio = take((size_t)N * 2 * ldh);      // [gmi | gmo], rows padded to LDH
+    // gHa and the gradient replicas (GradLayout<F, D>::stride each; F = C - D) are adjacent: one
+    // memset clears both
+    w.gHa = take((size_t)N * ldh);
+    const int tot = D * (C - D) + D + D * 2 * C + D + D + 1 + D * 3 * C + D + D * D + D;
+    w.rep = take((size_t)kReplicas * ((tot + 63) & ~63));
+    w.rep_end = b + off;
     w.bytes = off;
     return w;
 }
@@ -471,11 +525,16 @@ int backward_t(const gnn_graph_t *g, const gnn_params_t *p, int T, const float *
     constexpr int C = Shape<F, D>::C, LDH = Shape<F, D>::LDH;
     const int64_t N = g->n_hits, E = g->n_segments;
     BwdWs w = carve_bwd(ws, N, E, LDH, C, D);
+    using GL = GradLayout<F, D>;
     float *gH = w.gHa, *gHprev = w.gHb;
-    if (N > 0) {
-        hipError_t err = hipMemsetAsync(gH, 0, (size_t)N * LDH * sizeof(float), s);
-        if (err != hipSuccess) return fail(-(int)err, "memset of the hit gradient failed");
+    {   // hit gradient of the last iteration and the gradient replicas start at zero
+        hipError_t err = hipMemsetAsync(gH, 0, (size_t)(w.rep_end - reinterpret_cast<char *>(gH)), s);
+        if (err != hipSuccess) return fail(-(int)err, "memset of the gradient workspace failed");
     }
+    float *const rp = w.rep;
+    constexpr int RS = GL::stride;
+    if (w.rep_end - reinterpret_cast<char *>(rp) < (ptrdiff_t)(kReplicas * RS * sizeof(float)))
+        return fail(GNN_ERR_WORKSPACE, "gradient replica area does not match GradLayout");
     const float *ge = grad_out;
     for (int t = T; t >= 0; --t) {
         const float *Ht = H_all + (size_t)t * N * LDH;
@@ -485,12 +544,12 @@ int backward_t(const gnn_graph_t *g, const gnn_params_t *p, int T, const float *
         if (E > 0) {
             const unsigned ge_grid = grid_for(E) < (unsigned)kSegGrid ? grid_for(E) : (unsigned)kSegGrid;
             GNN_LAUNCH("k_edge_bwd", (k_edge_bwd<D>), ge_grid, kBlock, s, g->src, g->dst, w.PQ,
-                       p->b1, p->W2, et, ge, w.gu, gr->W2, gr->b2, gr->b1, E);
+                       p->b1, p->W2, et, ge, w.gu, rp + GL::oW2, rp + GL::ob2, rp + GL::ob1, RS, E);
         }
         if (N > 0)
             GNN_LAUNCH("k_pq_bwd", (k_pq_bwd<F, D>), grid_for(N), kBlock, s, Ht, LDH, w.PQ, w.gu,
                        g->in_ptr, g->in_eid, g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, p->W1, p->W2,
-                       gH, gr->W1, gr->b1, N);
+                       gH, rp + GL::oW1, rp + GL::ob1, RS, N);
         if (t == 0) break;
         // node pass t-1 backward: H_{t-1}, e_{t-1} -> H_t
         const float *Hp = H_all + (size_t)(t - 1) * N * LDH;
@@ -498,7 +557,8 @@ int backward_t(const gnn_graph_t *g, const gnn_params_t *p, int T, const float *
         if (N > 0) {
             GNN_LAUNCH("k_node_bwd", (k_node_bwd<F, D>), grid_for(N), kBlock, s, Hp, Ht, LDH, ep,
                        g->in_ptr, g->in_eid, g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, p->W3,
-                       p->b3, p->W4, gH, gHprev, w.gmio, gr->W3, gr->b3, gr->W4, gr->b4, N);
+                       p->b3, p->W4, gH, gHprev, w.gmio, rp + GL::oW3, rp + GL::ob3, rp + GL::oW4,
+                       rp + GL::ob4, RS, N);
             if (E > 0)
                 GNN_LAUNCH("k_agg_bwd_e", (k_agg_bwd_e<F, D>), grid_for(E), kBlock, s, g->src, g->dst,
                            Hp, LDH, w.gmio, w.ge, E);
@@ -511,7 +571,8 @@ int backward_t(const gnn_graph_t *g, const gnn_params_t *p, int T, const float *
     }
     if (N > 0)
         GNN_LAUNCH("k_input_bwd", (k_input_bwd<F, D>), grid_for(N), kBlock, s, g->X, H_all, LDH, gH,
-                   gr->Win, gr->bin, N);
+                   rp + GL::oWin, rp + GL::obin, RS, N);
+    GNN_LAUNCH("k_grad_fold", (k_grad_fold<F, D>), (GL::total + kBlock - 1) / kBlock, kBlock, s, rp, *gr);
     return 0;
 }
 
