@@ -14,7 +14,8 @@
 //   node pass t   H' = tanh(W4 q + b4), q = tanh(W3 M + b3), M = [mi | mo | H]
 //       k_node_bwd   per hit: recompute M, q; gr = gH' (1-H'^2); gp = W4^T gr (1-q^2);
 //                             gM = W3^T gp -> gmi, gmo stored, gH_prev = gHself;  gW3, gb3, gW4, gb4
-//       k_agg_bwd_e  per segment:  ge = <gmi[d], H[s]> + <gmo[s], H[d]>
+//       (the gradient of that pass's scores, ge = <gmi[d], H[s]> + <gmo[s], H[d]>, is rebuilt per
+//        segment inside the k_edge_bwd of the earlier edge pass)
 //       k_agg_bwd_n  per hit:      gH_prev += sum_out e gmi[d] + sum_in e gmo[s]
 //   input         k_input_bwd per hit: g = gH0[:D] (1-H0^2);  gWin, gbin
 //
@@ -142,14 +143,19 @@ constexpr int kSegGrid = 1024;
 
 // per segment; padded segments (src = -1) score sigmoid(W2 tanh(b1) + b2): their gz flows into
 // b1 only (summed here, the hits' share of gb1 comes from k_pq_bwd)
-template <int D>
+// ge: gradient w.r.t. this pass's scores - the loss gradient for the last pass (ge != null), else
+// rebuilt here from the node pass that consumed them (k_node_bwd's gmio and the H it read):
+// ge = <gmi[d], H[s]> + <gmo[s], H[d]>, zero for padded segments.
+template <int F, int D>
 __global__ __launch_bounds__(kBlock) void k_edge_bwd(
     const int32_t *__restrict__ src, const int32_t *__restrict__ dst,
     const float *__restrict__ PQ, const float *__restrict__ b1, const float *__restrict__ W2,
-    const float *__restrict__ e, const float *__restrict__ ge, float *__restrict__ gu_out,
+    const float *__restrict__ e, const float *__restrict__ ge, const float *__restrict__ H,
+    const float *__restrict__ gmio, float *__restrict__ gu_out,
     float *__restrict__ gW2, float *__restrict__ gb2, float *__restrict__ gb1, int rep_stride,
     int64_t n_segments)
 {
+    constexpr int C = F + D, LDH = Shape<F, D>::LDH;
     gW2 = my_replica(gW2, rep_stride);
     gb2 = my_replica(gb2, rep_stride);
     gb1 = my_replica(gb1, rep_stride);
@@ -159,11 +165,31 @@ __global__ __launch_bounds__(kBlock) void k_edge_bwd(
     float sum[D + 2];
 #pragma unroll
     for (int i = 0; i < D + 2; ++i) sum[i] = 0.0f;
-    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n_segments;
-         j += (int64_t)gridDim.x * kBlock) {
+    // XCD x (= blockIdx & 7, see xcd_block) walks its own contiguous eighth of the segments, so
+    // the rows its workgroups gather at any one time belong to a fraction of one graph
+    const bool split = (gridDim.x & 7) == 0;
+    const int64_t per = split ? (n_segments + 7) / 8 : n_segments;
+    const int64_t lo = split ? (int64_t)(blockIdx.x & 7) * per : 0;
+    const int64_t hi = lo + per < n_segments ? lo + per : n_segments;
+    const int64_t lb = split ? blockIdx.x >> 3 : blockIdx.x, nlb = split ? gridDim.x >> 3 : gridDim.x;
+    for (int64_t j = lo + lb * kBlock + threadIdx.x; j < hi; j += nlb * kBlock) {
         const int s = src[j], d = dst[j];
         const float ev = e[j];
-        const float gu = ge[j] * ev * (1.0f - ev);
+        float gej = 0.0f;
+        if (ge) {
+            gej = ge[j];
+        } else if (s >= 0) {
+            float hs[LDH], hd[LDH], gmi_d[LDH], gmo_s[LDH];
+            load_row4<LDH / 4>(H + (int64_t)s * LDH, hs);
+            load_row4<LDH / 4>(H + (int64_t)d * LDH, hd);
+            load_row4<LDH / 4>(gmio + (int64_t)d * 2 * LDH, gmi_d);
+            load_row4<LDH / 4>(gmio + (int64_t)s * 2 * LDH + LDH, gmo_s);
+#pragma unroll
+            for (int c = 0; c < C; ++c) gej = fmaf(gmi_d[c], hs[c], gej);
+#pragma unroll
+            for (int c = 0; c < C; ++c) gej = fmaf(gmo_s[c], hd[c], gej);
+        }
+        const float gu = gej * ev * (1.0f - ev);
         if (s >= 0) {
             const float4 *p = reinterpret_cast<const float4 *>(PQ + (int64_t)s * 2 * D);
             const float4 *q = reinterpret_cast<const float4 *>(PQ + (int64_t)d * 2 * D + D);
@@ -366,32 +392,6 @@ __global__ __launch_bounds__(kBlock) void k_node_bwd(
 }
 
 template <int F, int D>
-__global__ __launch_bounds__(kBlock) void k_agg_bwd_e(const int32_t *__restrict__ src,
-                                                      const int32_t *__restrict__ dst,
-                                                      const float *__restrict__ H, int ldh,
-                                                      const float *__restrict__ gmio,
-                                                      float *__restrict__ ge, int64_t n_segments)
-{
-    constexpr int C = F + D, LDH = Shape<F, D>::LDH;
-    const int64_t j = xcd_block() * kBlock + threadIdx.x;
-    if (j >= n_segments) return;
-    const int s = src[j], d = dst[j];
-    float acc = 0.0f;
-    if (s >= 0) {
-        float hs[LDH], hd[LDH], gmi_d[LDH], gmo_s[LDH];
-        load_row4<LDH / 4>(H + (int64_t)s * ldh, hs);
-        load_row4<LDH / 4>(H + (int64_t)d * ldh, hd);
-        load_row4<LDH / 4>(gmio + (int64_t)d * 2 * LDH, gmi_d);
-        load_row4<LDH / 4>(gmio + (int64_t)s * 2 * LDH + LDH, gmo_s);
-#pragma unroll
-        for (int c = 0; c < C; ++c) acc = fmaf(gmi_d[c], hs[c], acc);
-#pragma unroll
-        for (int c = 0; c < C; ++c) acc = fmaf(gmo_s[c], hd[c], acc);
-    }
-    ge[j] = acc;
-}
-
-template <int F, int D>
 __global__ __launch_bounds__(kBlock) void k_agg_bwd_n(
     const float *__restrict__ e, const float *__restrict__ gmio,
     const int32_t *__restrict__ in_ptr, const int32_t *__restrict__ in_eid,
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(kBlock) void k_grad_fold(const float *__restrict__ 
 }
 
 struct BwdWs {
-    float *PQ, *gu, *ge, *gHa, *gHb, *gmio, *rep;
+    float *PQ, *gu, *gHa, *gHb, *gmio, *rep;
     char *rep_end;
     size_t bytes;
 };
@@ -504,7 +504,6 @@ BwdWs carve_bwd(char *b, int64_t N, int64_t E, int ldh, int C, int D)
     };
     w.PQ = take((size_t)N * 2 * D);
     w.gu = take((size_t)E);
-    w.ge = take((size_t)E);
     w.gHb = take((size_t)N * ldh);
     w.gmio = take((size_t)N * 2 * ldh);      // [gmi | gmo], rows padded to LDH
     // gHa and the gradient replicas (GradLayout<F, D>::stride each; F = C - D) are adjacent: one
@@ -543,8 +542,9 @@ int backward_t(const gnn_graph_t *g, const gnn_params_t *p, int T, const float *
         if (N > 0) GNN_LAUNCH("kb_pq", (kb_pq<F, D>), grid_for(N), kBlock, s, Ht, LDH, p->W1, p->b1, w.PQ, N);
         if (E > 0) {
             const unsigned ge_grid = grid_for(E) < (unsigned)kSegGrid ? grid_for(E) : (unsigned)kSegGrid;
-            GNN_LAUNCH("k_edge_bwd", (k_edge_bwd<D>), ge_grid, kBlock, s, g->src, g->dst, w.PQ,
-                       p->b1, p->W2, et, ge, w.gu, rp + GL::oW2, rp + GL::ob2, rp + GL::ob1, RS, E);
+            GNN_LAUNCH("k_edge_bwd", (k_edge_bwd<F, D>), ge_grid, kBlock, s, g->src, g->dst, w.PQ,
+                       p->b1, p->W2, et, ge, Ht, w.gmio, w.gu, rp + GL::oW2, rp + GL::ob2, rp + GL::ob1,
+                       RS, E);
         }
         if (N > 0)
             GNN_LAUNCH("k_pq_bwd", (k_pq_bwd<F, D>), grid_for(N), kBlock, s, Ht, LDH, w.PQ, w.gu,
@@ -559,15 +559,12 @@ int backward_t(const gnn_graph_t *g, const gnn_params_t *p, int T, const float *
                        g->in_ptr, g->in_eid, g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, p->W3,
                        p->b3, p->W4, gH, gHprev, w.gmio, rp + GL::oW3, rp + GL::ob3, rp + GL::oW4,
                        rp + GL::ob4, RS, N);
-            if (E > 0)
-                GNN_LAUNCH("k_agg_bwd_e", (k_agg_bwd_e<F, D>), grid_for(E), kBlock, s, g->src, g->dst,
-                           Hp, LDH, w.gmio, w.ge, E);
             GNN_LAUNCH("k_agg_bwd_n", (k_agg_bwd_n<F, D>), grid_for(N), kBlock, s, ep, w.gmio,
                        g->in_ptr, g->in_eid, g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, gHprev,
                        LDH, N);
         }
         float *tmp = gH; gH = gHprev; gHprev = tmp;
-        ge = w.ge;
+        ge = nullptr;      // the next (earlier) edge pass rebuilds its ge from gmio and H_{t-1}
     }
     if (N > 0)
         GNN_LAUNCH("k_input_bwd", (k_input_bwd<F, D>), grid_for(N), kBlock, s, g->X, H_all, LDH, gH,
