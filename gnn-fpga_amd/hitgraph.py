@@ -20,6 +20,8 @@ row-major (reference gnn/graph.py:23-26), so `Ri_rows` is sorted by hit and
 
 Host-side numpy builds the plan once per batch; `to(device)` uploads it.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -100,15 +102,20 @@ class HitGraphBatch:
     out_nbr = property(lambda self: self._ensure_csr()[5])
 
     def build_plan(self, hidden_dim, limits=None):
-        """Tiles + windows + SELL-16 execution plan of the fused kernels (plan.py); built once,
-        on the host, for the kernel shape (input_dim = n_features, hidden_dim), then moved to
-        this batch's device."""
+        """Tiles + windows + SELL-16 execution plan of the fused kernels, built once for the
+        kernel shape (input_dim = n_features, hidden_dim): on the GPU with torch ops when the batch
+        lives there (plan_device.py, a fraction of a second for 25.6 M segments), else on the host
+        with numpy (plan.py); both build the same plan, array for array."""
         if self.plan is None or self.plan.hidden_dim != hidden_dim:
             from . import _lib
-            from .plan import SellPlan
             lim = _lib.plan_limits(self.n_features, hidden_dim)
             lim.update(limits or {})       # tests / experiments: e.g. iter_records=0 -> global mode
-            self.plan = SellPlan(self, lim)
+            if self.X.is_cuda and not os.environ.get("GNN_HOST_PLAN"):
+                from .plan_device import DeviceSellPlan
+                self.plan = DeviceSellPlan(self, lim)
+            else:
+                from .plan import SellPlan
+                self.plan = SellPlan(self, lim)
             self.plan.hidden_dim = hidden_dim
             self.plan.to(self.X.device)
         return self.plan

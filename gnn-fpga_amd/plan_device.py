@@ -1,0 +1,382 @@
+"""The execution plan of plan.py built with torch ops on the batch's own device.
+
+Same plan, array for array (tests/test_plan.py compares the two builders on the CPU): sorts are
+stable, segment reductions are scatter-min / scatter-max, and the few sequential decisions (packing
+(graph, level) units into tiles, cutting the final edge pass into chunks) run on the host over a
+few thousand integers.  On a GPU the 25.6 M-segment plan of the benchmark batch takes a fraction
+of a second instead of 7 s of numpy, and none of it crosses PCIe.
+"""
+import numpy as np
+import torch
+
+from .plan import SLICE, TILE_DESC, CHUNK_DESC, SellPlan
+
+BIG = torch.iinfo(torch.int64).max
+
+
+def _lexsort(keys):
+    """np.lexsort: the LAST key is the primary one; stable."""
+    idx = None
+    for k in keys:
+        if idx is None:
+            idx = torch.sort(k, stable=True).indices
+        else:
+            idx = idx[torch.sort(k[idx], stable=True).indices]
+    return idx
+
+
+def _cumsum0(x):
+    """[0, x0, x0+x1, ...] (length len(x) + 1), int64."""
+    out = torch.zeros(x.numel() + 1, dtype=torch.int64, device=x.device)
+    torch.cumsum(x, 0, out=out[1:])
+    return out
+
+
+def _arange(n, dev):
+    return torch.arange(n, dtype=torch.int64, device=dev)
+
+
+def _repeat(values, counts):
+    return torch.repeat_interleave(values, counts)
+
+
+def _topological_levels(src, dst, n, max_iter=64):
+    level = torch.zeros(n, dtype=torch.int64, device=src.device)
+    if src.numel() == 0:
+        return level
+    for _ in range(max_iter):
+        new = level.clone().scatter_reduce_(0, dst, level[src] + 1, "amax", include_self=True)
+        if torch.equal(new, level):
+            break
+        level = new
+    no_in = torch.ones(n, dtype=torch.bool, device=src.device)
+    no_in[dst] = False
+    has_out = torch.zeros(n, dtype=torch.bool, device=src.device)
+    has_out[src] = True
+    down = torch.full((n,), BIG, dtype=torch.int64, device=src.device)
+    down.scatter_reduce_(0, src, level[dst], "amin", include_self=True)
+    fix = no_in & has_out
+    level[fix] = torch.clamp(down[fix] - 1, min=0)
+    return level
+
+
+def _node_minmax(key, other, n):
+    lo = torch.full((n,), BIG, dtype=torch.int64, device=key.device)
+    hi = torch.full((n,), -1, dtype=torch.int64, device=key.device)
+    if key.numel():
+        lo.scatter_reduce_(0, key, other, "amin", include_self=True)
+        hi.scatter_reduce_(0, key, other, "amax", include_self=True)
+    return lo, hi
+
+
+def _range_minmax(lo, hi, bounds):
+    """min(lo) / max(hi) over the consecutive, non-empty ranges [bounds[i], bounds[i+1])."""
+    nseg = bounds.numel() - 1
+    seg = _repeat(_arange(nseg, lo.device), bounds[1:] - bounds[:-1])
+    rl = torch.full((nseg,), BIG, dtype=torch.int64, device=lo.device)
+    rh = torch.full((nseg,), torch.iinfo(torch.int64).min, dtype=torch.int64, device=lo.device)
+    rl.scatter_reduce_(0, seg, lo, "amin", include_self=True)
+    rh.scatter_reduce_(0, seg, hi, "amax", include_self=True)
+    return rl, rh
+
+
+def _sell(key_new, other_rel, n_pad, null_of_slice):
+    dev = key_new.device
+    n_slices = n_pad // SLICE
+    order = torch.sort(key_new, stable=True).indices
+    k = key_new[order]
+    oth = other_rel[order]
+    deg = torch.bincount(k, minlength=n_pad)
+    ptr = _cumsum0(deg)
+    pos = _arange(k.numel(), dev) - ptr[k]
+    slen = deg.view(n_slices, SLICE).max(dim=1).values if n_slices else torch.zeros(0, dtype=torch.int64, device=dev)
+    off = _cumsum0(slen * SLICE)
+    if int(off[-1]) >= 2 ** 31:
+        raise ValueError("SELL list exceeds int32 index range")
+    nbr = _repeat(null_of_slice, slen * SLICE)
+    nbr[off[k // SLICE] + pos * SLICE + (k % SLICE)] = oth
+    nbr = torch.cat([nbr, torch.zeros(4 * SLICE, dtype=torch.int64, device=dev)])
+    return off, nbr
+
+
+def _pack16(off, nbr, null_of_slice):
+    dev = off.device
+    n_slices = off.numel() - 1
+    L = (off[1:] - off[:-1]) // SLICE
+    steps8 = (L + 7) // 8 * 8
+    poff = _cumsum0(steps8 * SLICE)
+    pad = _repeat(null_of_slice & 0xFFFF, steps8 * SLICE)
+    real = int(off[-1])
+    if real:
+        s_of = _repeat(_arange(n_slices, dev), L * SLICE)
+        idx = _arange(real, dev)
+        pad[idx - off[s_of] + poff[s_of]] = nbr[:real] & 0xFFFF
+    pr = pad.view(-1, 2, SLICE)
+    words = (pr[:, 0, :] | (pr[:, 1, :] << 16)).reshape(-1)
+    words = torch.cat([words, torch.zeros(64, dtype=torch.int64, device=dev)])
+    words = torch.where(words >= 2 ** 31, words - 2 ** 32, words)        # uint32 bit pattern as int32
+    return (poff // 2).to(torch.int32), words.to(torch.int32)
+
+
+def _chunk_bounds(key, ok, E, CH):
+    """plan._chunk_bounds: run detection on the device, the marks on the host."""
+    if E == 0:
+        return np.zeros(1, np.int64)
+    k = key
+    if not bool(ok.all()):
+        idx = torch.where(ok, _arange(E, key.device), torch.zeros((), dtype=torch.int64, device=key.device))
+        idx = torch.cummax(idx, 0).values
+        k = key[idx]
+    change = torch.ones(E, dtype=torch.bool, device=key.device)
+    change[1:] = k[1:] != k[:-1]
+    rb = torch.nonzero(change).reshape(-1).cpu().numpy()
+    rsz = np.diff(np.r_[rb, E])
+    big = rsz >= max(1, CH // 4)
+    marks = np.unique(np.r_[0, rb[big], (rb + rsz)[big], E])
+    out = [np.zeros(1, np.int64)]
+    for a, b in zip(marks[:-1].tolist(), marks[1:].tolist()):
+        parts = -(-(b - a) // CH)
+        out.append(a + (np.arange(1, parts + 1, dtype=np.int64) * (b - a)) // parts)
+    return np.concatenate(out)
+
+
+class DeviceSellPlan(SellPlan):
+    """SellPlan whose arrays were built where the batch lives (see module docstring)."""
+
+    def __init__(self, batch, limits):    # noqa: C901  (one long recipe, mirrors plan.SellPlan)
+        dev = batch.X.device
+        i64 = torch.int64
+        src = batch.src.to(dev).to(i64)
+        dst = batch.dst.to(dev).to(i64)
+        X = batch.X.to(dev)
+        n, E = batch.n_hits, batch.n_segments
+        tile_hits = int(limits["tile_hits"])
+        want = 512 if int(limits["iter_records"]) > 0 else 256
+        if n < want * tile_hits:
+            tile_hits = max(64, ((n + want - 1) // want + SLICE - 1) // SLICE * SLICE)
+        ok = src >= 0
+        vs, vd = src[ok], dst[ok]
+        deg_in = torch.bincount(vd, minlength=n)
+        deg_out = torch.bincount(vs, minlength=n)
+        gid = torch.zeros(n, dtype=i64, device=dev)
+        if batch.n_graphs > 1:
+            hp = np.asarray(batch.hit_ptr[1:-1], dtype=np.int64)
+            hp = torch.from_numpy(hp[hp < n]).to(dev)
+            gid.index_add_(0, hp, torch.ones_like(hp))
+            gid = torch.cumsum(gid, 0)
+        level = _topological_levels(vs, vd, n)
+        lmax1 = int(level.max()) + 1 if n else 1
+
+        # -- (graph, level) units -> tiles (sequential packing on the host) -------------------
+        base = _lexsort((-deg_out, -deg_in, level, gid)) if n else _arange(0, dev)
+        ukey = gid[base] * lmax1 + level[base]
+        if n:
+            change = torch.ones(n, dtype=torch.bool, device=dev)
+            change[1:] = ukey[1:] != ukey[:-1]
+            ustart = torch.nonzero(change).reshape(-1).cpu().numpy()
+        else:
+            ustart = np.zeros(0, np.int64)
+        usize = np.diff(np.r_[ustart, n])
+        tile_bounds = [0]
+        cur = 0
+        for st, sz in zip(ustart.tolist(), usize.tolist()):
+            if sz > tile_hits:
+                if cur:
+                    tile_bounds.append(st)
+                    cur = 0
+                for a in range(st + tile_hits, st + sz, tile_hits):
+                    tile_bounds.append(a)
+                tile_bounds.append(st + sz)
+                continue
+            if cur + sz > tile_hits:
+                tile_bounds.append(st)
+                cur = 0
+            cur += sz
+        if n and tile_bounds[-1] != n:
+            tile_bounds.append(n)
+        tile_bounds = torch.tensor(tile_bounds, dtype=i64, device=dev)
+        n_tiles = tile_bounds.numel() - 1
+        tsize = tile_bounds[1:] - tile_bounds[:-1]
+        tile_of_pos = _repeat(_arange(n_tiles, dev), tsize)
+        order = _lexsort((-deg_out[base], -((deg_in[base] + 3) // 4), tile_of_pos)) if n else _arange(0, dev)
+        old_of_rank = base[order]
+        tpad = (tsize + SLICE - 1) // SLICE * SLICE
+        tpad_off = _cumsum0(tpad)
+        n_pad = int(tpad_off[-1])
+        rank_in_tile = _arange(n, dev) - _repeat(tile_bounds[:-1], tsize)
+        new_of_rank = _repeat(tpad_off[:-1], tsize) + rank_in_tile
+        inv = torch.empty(n + 1, dtype=i64, device=dev)
+        inv[old_of_rank] = new_of_rank
+        inv[n] = n_pad
+        perm = torch.full((n_pad,), -1, dtype=i64, device=dev)
+        perm[new_of_rank] = old_of_rank
+
+        self.n_hits, self.n_pad, self.n_segments = n, n_pad, E
+        self.n_features = batch.n_features
+        self.n_slices = n_pad // SLICE
+        self.n_tiles = n_tiles
+        nth = torch.full_like(src, n)
+        src_new = inv[torch.where(ok, src, nth)]
+        dst_new = inv[torch.where(ok, dst, nth)]
+        vs_new, vd_new = src_new[ok], dst_new[ok]
+
+        # -- per-tile windows ------------------------------------------------------------------
+        tb = tpad_off
+        in_lo_n, in_hi_n = _node_minmax(vd_new, vs_new, n_pad)
+        out_lo_n, out_hi_n = _node_minmax(vs_new, vd_new, n_pad)
+        if n_tiles:
+            in_lo, in_hi = _range_minmax(in_lo_n, in_hi_n, tb)
+            out_lo, out_hi = _range_minmax(out_lo_n, out_hi_n, tb)
+        else:
+            in_lo = in_hi = out_lo = out_hi = torch.zeros(0, dtype=i64, device=dev)
+        zero = torch.zeros((), dtype=i64, device=dev)
+        in_cnt = torch.where(in_hi >= 0, in_hi - in_lo + 1, zero)
+        out_cnt = torch.where(out_hi >= 0, out_hi - out_lo + 1, zero)
+        in_lo = torch.where(in_cnt > 0, in_lo, zero)
+        out_lo = torch.where(out_cnt > 0, out_lo, zero)
+        lds_mode = (in_cnt + out_cnt + 2) <= int(limits["iter_records"])
+        tile_of_new = _repeat(_arange(n_tiles, dev), tpad)
+        slice_tile = tile_of_new[::SLICE] if n_pad else torch.zeros(0, dtype=i64, device=dev)
+        npad_t = torch.full((), n_pad, dtype=i64, device=dev)
+
+        def lists(key_new, other_new, lo, cnt):
+            t = tile_of_new[key_new]
+            rel = torch.where(lds_mode[t], other_new - lo[t], other_new)
+            null = torch.where(lds_mode[slice_tile], cnt[slice_tile], npad_t)
+            off, nbr = _sell(key_new, rel, n_pad, null)
+            return (off, nbr) + _pack16(off, nbr, null)
+
+        in_off, in_nbr, in_off16, in_nbr16 = lists(vd_new, vs_new, in_lo, in_cnt)
+        out_off, out_nbr, out_off16, out_nbr16 = lists(vs_new, vd_new, out_lo, out_cnt)
+        tiles = torch.zeros((n_tiles, TILE_DESC), dtype=i64, device=dev)
+        tiles[:, 0] = tb[:-1] // SLICE
+        tiles[:, 1] = tb[1:] // SLICE
+        tiles[:, 2], tiles[:, 3] = in_lo, in_cnt
+        tiles[:, 4], tiles[:, 5] = out_lo, out_cnt
+        tiles[:, 6] = lds_mode.to(i64)
+        nsl = tiles[:, 1] - tiles[:, 0]
+        rounds = (nsl + 15) // 16
+        sbase = _cumsum0(rounds * 16)
+        tiles[:, 7] = sbase[:-1]
+        tile_of_slice = _repeat(_arange(n_tiles, dev), nsl)
+        n_sched = int(sbase[-1]) + 16
+        first = torch.cumsum(nsl, 0) - nsl
+
+        def schedule(cost):
+            order = _lexsort((-cost, tile_of_slice))
+            rank = _arange(order.numel(), dev) - _repeat(first, nsl)
+            r, c = rank // 16, rank % 16
+            wave = torch.where(r % 2 == 0, c, 15 - c)
+            out = torch.full((n_sched,), -1, dtype=i64, device=dev)
+            out[sbase[tile_of_slice[order]] + r * 16 + wave] = order
+            return out
+
+        steps_in = (in_off[1:] - in_off[:-1]) // SLICE
+        steps_out = (out_off[1:] - out_off[:-1]) // SLICE
+
+        def schedule_two_phase(cost_a, cost_b):
+            out = torch.full((n_sched,), -1, dtype=i64, device=dev)
+            if n_tiles == 0 or int(nsl.max()) == 0:
+                return out
+            by_ab = _lexsort((-cost_b, -cost_a, tile_of_slice))
+            rnd = (_arange(by_ab.numel(), dev) - _repeat(first, nsl)) // 16
+            by_tot = by_ab[_lexsort((-(cost_a + cost_b)[by_ab], rnd, tile_of_slice[by_ab]))]
+            A = torch.zeros((n_tiles, 16), dtype=torch.float64, device=dev)
+            B = torch.zeros((n_tiles, 16), dtype=torch.float64, device=dev)
+            inf = torch.full((), float("inf"), dtype=torch.float64, device=dev)
+            for r in range(int(rounds.max())):
+                used = torch.zeros((n_tiles, 16), dtype=torch.bool, device=dev)
+                for j in range(16):
+                    act = torch.nonzero(nsl > r * 16 + j).reshape(-1)
+                    if not act.numel():
+                        break
+                    sl = by_tot[first[act] + r * 16 + j]
+                    a, b = cost_a[sl][:, None], cost_b[sl][:, None]
+                    Aa, Ba = A[act], B[act]
+                    score = (torch.maximum(Aa + a, Aa.max(1, keepdim=True).values) +
+                             torch.maximum(Ba + b, Ba.max(1, keepdim=True).values) + 1e-3 * (Aa + Ba))
+                    score = torch.where(used[act], inf, score)
+                    w = score.argmin(1)
+                    out[sbase[act] + r * 16 + w] = sl
+                    A[act, w] += a[:, 0]
+                    B[act, w] += b[:, 0]
+                    used[act, w] = True
+            return out
+
+        groups_in, groups_out = (steps_in + 3) // 4, (steps_out + 3) // 4
+        sched_a = schedule_two_phase(groups_in.to(torch.float64), groups_out.to(torch.float64) + 2.6)
+        sched_b = schedule(groups_out + 3)
+
+        # -- final edge pass: chunks of the caller's segment order -------------------------------
+        CH = int(limits["chunk_segments"])
+        if E < 512 * CH:
+            CH = min(CH, max(1024, (E + 511) // 512))
+        src0 = torch.where(ok, src, zero)
+        ckey = torch.where(ok, gid[src0] * lmax1 + level[src0], torch.full((), -1, dtype=i64, device=dev)) if n else \
+            torch.full((E,), -1, dtype=i64, device=dev)
+        cb = torch.from_numpy(_chunk_bounds(ckey, ok, E, CH)).to(dev)
+        n_chunks = cb.numel() - 1
+        bigt = torch.full((), BIG, dtype=i64, device=dev)
+        neg1 = torch.full((), -1, dtype=i64, device=dev)
+        if n_chunks:
+            s_lo, s_hi = _range_minmax(torch.where(ok, src_new, bigt), torch.where(ok, src_new, neg1), cb)
+            d_lo, d_hi = _range_minmax(torch.where(ok, dst_new, bigt), torch.where(ok, dst_new, neg1), cb)
+        else:
+            s_lo = s_hi = d_lo = d_hi = torch.zeros(0, dtype=i64, device=dev)
+        s_cnt = torch.where(s_hi >= 0, s_hi - s_lo + 1, zero)
+        d_cnt = torch.where(d_hi >= 0, d_hi - d_lo + 1, zero)
+        s_lo = torch.where(s_cnt > 0, s_lo, zero)
+        d_lo = torch.where(d_cnt > 0, d_lo, zero)
+        c_lds = (s_cnt + d_cnt + 2) <= int(limits["edge_records"])
+        c = _repeat(_arange(n_chunks, dev), cb[1:] - cb[:-1])
+        src_st = torch.where(c_lds[c], torch.where(ok, src_new - s_lo[c], s_cnt[c]), src_new)
+        dst_st = torch.where(c_lds[c], torch.where(ok, dst_new - d_lo[c], d_cnt[c]), dst_new)
+        chunks = torch.zeros((n_chunks, CHUNK_DESC), dtype=i64, device=dev)
+        chunks[:, 0], chunks[:, 1] = cb[:-1], cb[1:]
+        chunks[:, 2], chunks[:, 3] = s_lo, s_cnt
+        chunks[:, 4], chunks[:, 5] = d_lo, d_cnt
+        chunks[:, 6] = c_lds.to(i64)
+        self.n_chunks = n_chunks
+
+        def masked_max(v, m):
+            v = v[m]
+            return int(v.max()) if v.numel() else 0
+
+        self.iter_lds_records = masked_max(in_cnt + out_cnt + 2, lds_mode)
+        self.edge_lds_rows = masked_max(s_cnt + d_cnt + 2, c_lds)
+        self.n_lds_tiles = int(lds_mode.sum())
+        self.iter_lds_in = masked_max(in_cnt, lds_mode)
+        self.iter_lds_out = masked_max(out_cnt, lds_mode)
+        self.tile_hits_max = int(tpad.max()) if n_tiles else 0
+        dmax = lambda off: int((off[1:] - off[:-1]).max()) if off.numel() > 1 else 0   # noqa: E731
+        self.max_list_steps = max(dmax(in_off), dmax(out_off)) // SLICE
+
+        Xp = torch.zeros((n_pad + 1 + 64, X.shape[1]), dtype=torch.float32, device=dev)
+        Xp[new_of_rank] = X[old_of_rank].to(torch.float32)
+        self.X = Xp
+        self.x_absmax = Xp.abs().max(dim=0).values if n else torch.zeros(X.shape[1], dtype=torch.float32, device=dev)
+        i32 = torch.int32
+        self.src, self.dst = src_st.to(i32), dst_st.to(i32)
+        if E:
+            sd = torch.where(c_lds[c], (dst_st << 16) | (src_st & 0xFFFF), zero)
+            sd = torch.where(sd >= 2 ** 31, sd - 2 ** 32, sd)
+        else:
+            sd = torch.zeros(0, dtype=i64, device=dev)
+        self.sd16 = sd.to(i32)
+        self.in_off, self.in_nbr = in_off.to(i32), in_nbr.to(i32)
+        self.out_off, self.out_nbr = out_off.to(i32), out_nbr.to(i32)
+        self.in_off16, self.in_nbr16 = in_off16, in_nbr16
+        self.out_off16, self.out_nbr16 = out_off16, out_nbr16
+        self.tiles, self.chunks = tiles.to(i32).reshape(-1), chunks.to(i32).reshape(-1)
+        self.sched_a, self.sched_b = sched_a.to(i32), sched_b.to(i32)
+        self.perm = perm.to(i32)
+        nv = max(1, int(ok.sum()))
+        self.padding = (int(in_off[-1]) + int(out_off[-1])) / (2 * nv) - 1.0
+        self.lds_tile_fraction = float(lds_mode.double().mean()) if n_tiles else 1.0
+        self.lds_chunk_fraction = float(c_lds.double().mean()) if n_chunks else 1.0
+        self._src_abs, self._dst_abs, self._level = src_new, dst_new, level
+
+    # host copies for tests (plan.SellPlan keeps them as arrays; here they are made on demand)
+    src_abs = property(lambda self: self._src_abs.cpu().numpy())
+    dst_abs = property(lambda self: self._dst_abs.cpu().numpy())
+    level = property(lambda self: self._level.cpu().numpy().astype(np.int32))

@@ -596,3 +596,29 @@ def test_bf16_matrix_core_hit_update(hip, F, D, T):
     for g, eg in zip(graphs, batch.split_scores(e16.cpu().numpy())):
         ref = index_c.segment_classifier(g.X, g.src, g.dst, params, T)
         assert np.abs(eg - ref).max() < TOL_BF16
+
+
+@pytest.mark.parametrize("lim_over", [{}, {"iter_records": 0, "edge_records": 0}])
+def test_plan_built_on_the_gpu_equals_the_host_plan(hip, lim_over):
+    """HitGraphBatch.build_plan on a CUDA batch runs plan_device.DeviceSellPlan (torch sorts and
+    scatters on the GPU): every array and scalar must equal the numpy builder's (plan.SellPlan) -
+    the CPU suite checks the same code on CPU tensors, this checks the CUDA sort / scatter / argmin
+    semantics it relies on (stability, first minimum)."""
+    from test_plan import _same_plan
+    from gnn_fpga_amd import _lib
+    from gnn_fpga_amd.plan import SellPlan
+    from gnn_fpga_amd.plan_device import DeviceSellPlan
+    graphs = [synth.layered_graph(3000, 30000, 3, seed=300 + s) for s in range(12)]
+    graphs.append(synth.layered_graph(2, 1, 3, n_layers=2, seed=1))
+    b = HitGraphBatch.from_graphs(graphs)
+    src, dst = b.src.numpy().copy(), b.dst.numpy().copy()
+    src[5::11] = -1
+    dst[5::11] = -1
+    b = HitGraphBatch(b.X.numpy(), src, dst, hit_ptr=b.hit_ptr, seg_ptr=b.seg_ptr)
+    lim = _lib.plan_limits(3, 8)
+    lim.update(lim_over)
+    host = SellPlan(b, lim)
+    dev = DeviceSellPlan(b.cuda(), lim)
+    assert dev.X.is_cuda
+    _same_plan(host, dev)
+    assert isinstance(b.cuda().build_plan(8), DeviceSellPlan)

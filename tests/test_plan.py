@@ -2,6 +2,7 @@
 fused kernels do with the plan arrays (tiles, windows, SELL-16 lists, chunks) must reproduce
 the oracle.  Runs without a GPU (the limits come from the library's host-side query)."""
 import numpy as np
+import torch
 import pytest
 
 from golden_util import Fixture
@@ -163,3 +164,50 @@ def test_packed16_lists_decode_to_the_sell_lists():
                     assert np.all(got == want)
     assert plan.max_list_steps == max(np.diff(plan.in_off.numpy()).max(),
                                       np.diff(plan.out_off.numpy()).max()) // SLICE
+
+
+def _same_plan(a, b):
+    for k in a._TENSORS:
+        x, y = getattr(a, k), getattr(b, k)
+        assert x.dtype == y.dtype and x.shape == y.shape, k
+        assert torch.equal(x.cpu(), y.cpu()), k
+    for k in ("n_hits", "n_pad", "n_segments", "n_features", "n_slices", "n_tiles", "n_chunks",
+              "iter_lds_records", "edge_lds_rows", "n_lds_tiles", "iter_lds_in", "iter_lds_out",
+              "tile_hits_max", "max_list_steps", "padding", "lds_tile_fraction", "lds_chunk_fraction"):
+        assert getattr(a, k) == getattr(b, k), k
+    assert np.array_equal(a.src_abs, b.src_abs) and np.array_equal(a.dst_abs, b.dst_abs)
+    assert np.array_equal(a.level, b.level)
+
+
+@pytest.mark.parametrize("case", ["layered", "ragged", "padded", "global", "wide", "empty", "one_graph_big_levels"])
+def test_device_builder_builds_the_same_plan(case):
+    """plan_device.DeviceSellPlan (torch ops, runs where the batch lives) against plan.SellPlan
+    (numpy), array for array."""
+    from gnn_fpga_amd.plan_device import DeviceSellPlan
+    F, D, lim_over = 3, 8, {}
+    if case == "layered":
+        graphs = [synth.layered_graph(700, 4000, 3, seed=s) for s in range(5)]
+    elif case == "ragged":
+        graphs = [synth.layered_graph(n, e, 3, n_layers=L, seed=s)
+                  for s, (n, e, L) in enumerate([(40, 90, 10), (3, 2, 2), (300, 2500, 10), (17, 16, 3), (2, 1, 2)])]
+    elif case == "padded":
+        graphs = [synth.layered_graph(200, 900, 3, seed=s) for s in range(3)]
+    elif case == "global":
+        graphs = [synth.layered_graph(700, 4000, 3, seed=s) for s in range(3)]
+        lim_over = {"iter_records": 0, "edge_records": 0}
+    elif case == "wide":
+        F, D = 3, 64
+        graphs = [synth.layered_graph(500, 3000, 3, seed=s) for s in range(4)]
+    elif case == "empty":
+        graphs = [synth.layered_graph(50, 0, 3, seed=1)]
+    else:
+        graphs = [synth.layered_graph(20000, 60000, 3, n_layers=4, seed=3)]
+    b = HitGraphBatch.from_graphs(graphs)
+    if case == "padded":     # zero-padded segments (src = dst = -1) scattered through the list
+        src, dst = b.src.numpy().copy(), b.dst.numpy().copy()
+        src[::7] = -1
+        dst[::7] = -1
+        b = HitGraphBatch(b.X.numpy(), src, dst, hit_ptr=b.hit_ptr, seg_ptr=b.seg_ptr)
+    lim = _lib.plan_limits(F, D)
+    lim.update(lim_over)
+    _same_plan(SellPlan(b, lim), DeviceSellPlan(b, lim))
