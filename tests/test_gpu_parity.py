@@ -622,3 +622,19 @@ def test_plan_built_on_the_gpu_equals_the_host_plan(hip, lim_over):
     assert dev.X.is_cuda
     _same_plan(host, dev)
     assert isinstance(b.cuda().build_plan(8), DeviceSellPlan)
+
+
+def test_csr_built_on_the_gpu_equals_the_host_csr(hip):
+    """The two CSRs of the per-module / training kernels are built where the batch lives: the
+    torch version (stable sort on the GPU) must give the host version's arrays, padded segments
+    (src = dst = -1) left out of both."""
+    graphs = [synth.layered_graph(2000, 15000, 3, seed=400 + s) for s in range(6)]
+    b = HitGraphBatch.from_graphs(graphs)
+    src, dst = b.src.numpy().copy(), b.dst.numpy().copy()
+    src[3::13] = -1
+    dst[3::13] = -1
+    host = HitGraphBatch(b.X.numpy(), src, dst, hit_ptr=b.hit_ptr, seg_ptr=b.seg_ptr)
+    dev = HitGraphBatch(b.X.numpy(), src, dst, hit_ptr=b.hit_ptr, seg_ptr=b.seg_ptr).cuda()
+    for name in HitGraphBatch._CSR_NAMES:
+        a, c = getattr(host, name), getattr(dev, name)
+        assert c.is_cuda and a.dtype == c.dtype and torch.equal(a, c.cpu()), name
