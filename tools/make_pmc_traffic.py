@@ -18,13 +18,23 @@ def short(name):
 
 res = {}
 for cname in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = glob.glob(os.path.join(out, "pmc_" + cname, "**", "*counter_collection.csv"), recursive=True)[0]
-    acc = {}
-    for r in csv.DictReader(open(f)):
-        acc.setdefault(short(r["Kernel_Name"]), []).append(float(r["Counter_Value"]))
-    for k, v in acc.items():
-        res.setdefault(k, {})[cname + "_KB_mean"] = sum(v) / len(v)
-        res[k]["launches"] = len(v)
+    found = glob.glob(os.path.join(out, "pmc_" + cname, "**", "*counter_collection.csv"), recursive=True)
+    if found:
+        acc = {}
+        for r in csv.DictReader(open(found[0])):
+            acc.setdefault(short(r["Kernel_Name"]), []).append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            res.setdefault(k, {})[cname + "_KB_mean"] = sum(v) / len(v)
+            res[k]["launches"] = len(v)
+        continue
+    # profile_bench.sh drops csv files above 2 MB (the plan builder's torch kernels fill them):
+    # the per-kernel means are in its summary.txt
+    for line in open(os.path.join(out, "summary.txt")):
+        m = re.match(r"\s+(\S.*?)\s+%s mean (\S+) \(n=(\d+)\)" % cname, line)
+        if m:
+            k = short(m.group(1))
+            res.setdefault(k, {})[cname + "_KB_mean"] = float(m.group(2))
+            res[k]["launches"] = int(m.group(3))
 for v in res.values():
     v["hbm_bytes_per_launch"] = (2 * v.get("FETCH_SIZE_KB_mean", 0) + v.get("WRITE_SIZE_KB_mean", 0)) * 1024
 doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python3 bench.py "

@@ -16,5 +16,9 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES
 done
 python3 "$ROOT/tools/summarize_prof.py" "$OUT" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
+# counter files: keep the rows of this library's kernels (the plan builder's torch kernels are thousands of rows)
+for f in $(find "$OUT" -name "*counter_collection.csv"); do
+  { head -1 "$f"; grep -E '"[^"]*(k_iter|k_edge|k_input|k_pack|k_event|k_node|k_pq|k_exp_bound)' "$f"; } > "$f.tmp" && mv "$f.tmp" "$f"
+done
 # keep only small files (csv traces of 100k+ dispatches are not needed)
 find "$OUT" -name "*.csv" -size +2M -delete
