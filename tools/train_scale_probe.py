@@ -10,7 +10,7 @@ from gnn_fpga_amd.loss import BCELoss
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 dev = torch.device("cuda:0")
-graphs = [synth.layered_graph(10000, 100000, 3, seed=s) for s in range(G)]
+graphs = [synth.layered_graph(10000, 100000, 3, seed=s, sort_hits_by_layer=bool(int(os.environ.get("SORTED", "0")))) for s in range(G)]
 batch = HitGraphBatch.from_graphs(graphs).to(dev)
 y = (torch.rand(batch.n_segments, device=dev) < 0.3).float()
 torch.manual_seed(0)
