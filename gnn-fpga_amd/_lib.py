@@ -65,6 +65,11 @@ SIGNATURES = {
     "gnn_events_supported": (ctypes.c_int, [_i32, _i32, _i64, _i64]),
     "gnn_segclf_forward_events": (ctypes.c_int, [ctypes.POINTER(GnnGraph), ctypes.POINTER(GnnParams),
                                                  _f, _f, _i64, _i32, _i32, _i32, _f, _f]),
+    "gnn_events_backward_supported": (ctypes.c_int, [_i32, _i32, _i64, _i64]),
+    "gnn_backward_events_workspace_bytes": (_sz, [_i32, _i32]),
+    "gnn_segclf_backward_events": (ctypes.c_int, [ctypes.POINTER(GnnGraph), ctypes.POINTER(GnnParams),
+                                                  _f, _f, _i64, _i32, _i32, _i32, _f, _f, _f,
+                                                  ctypes.POINTER(GnnGrads), _f, _sz, _f]),
     "gnn_segclf_forward_train": (ctypes.c_int, [ctypes.POINTER(GnnGraph),
                                                 ctypes.POINTER(GnnParams), _i32, _f, _f, _f, _sz, _f]),
     "gnn_backward_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
@@ -308,6 +313,33 @@ def segclf_backward(batch, weights, F, D, n_iters, e_all, H_all, grad_out):
                                       _dev(H_all, torch.float32, "H_all"),
                                       _dev(grad_out, torch.float32, "grad_out"),
                                       ctypes.byref(gs), ws.data_ptr(), ws.numel(), _stream()))
+    return grads
+
+
+def events_backward_supported(F, D, max_hits, max_segments):
+    """True if graphs of at most that size fit the one-launch backward (one workgroup per graph)."""
+    return bool(load().gnn_events_backward_supported(F, D, max_hits, max_segments))
+
+
+def segclf_backward_events(batch, layout, weights, F, D, n_iters, e_all, H_all, grad_out):
+    """segclf_backward for a batch of small graphs in ONE launch (`layout` = batch.event_layout())."""
+    dev = batch.X.device
+    flat = torch.zeros(sum(w.numel() for w in weights), dtype=torch.float32, device=dev)
+    grads, o = [], 0
+    for w in weights:
+        grads.append(flat[o:o + w.numel()].view_as(w))
+        o += w.numel()
+    gs = GnnGrads()
+    for name, t in zip(("Win", "bin", "W1", "b1", "W2", "b2", "W3", "b3", "W4", "b4"), grads):
+        setattr(gs, name, t.data_ptr())
+    ws = torch.empty(int(load().gnn_backward_events_workspace_bytes(F, D)), dtype=torch.uint8, device=dev)
+    g = cached_graph_struct(batch)
+    p = params_struct(weights, F, D)
+    _check(load().gnn_segclf_backward_events(
+        ctypes.byref(g), ctypes.byref(p), _dev(layout.hit_ptr, torch.int32, "hit_ptr"),
+        _dev(layout.seg_ptr, torch.int32, "seg_ptr"), batch.n_graphs, layout.max_hits, layout.max_segments,
+        n_iters, _dev(e_all, torch.float32, "e_all"), _dev(H_all, torch.float32, "H_all"),
+        _dev(grad_out, torch.float32, "grad_out"), ctypes.byref(gs), ws.data_ptr(), ws.numel(), _stream()))
     return grads
 
 

@@ -13,19 +13,25 @@ from . import _lib
 
 class _SegClf(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, batch, F, D, n_iters, *weights):
+    def forward(ctx, batch, F, D, n_iters, use_events, *weights):
         w = [t.detach().to(torch.float32).contiguous() for t in weights]
         e_all, H_all = _lib.segclf_forward_train(batch, w, F, D, n_iters)
-        ctx.batch, ctx.F, ctx.D, ctx.n_iters = batch, F, D, n_iters
+        ctx.batch, ctx.F, ctx.D, ctx.n_iters, ctx.use_events = batch, F, D, n_iters, use_events
         ctx.save_for_backward(e_all, H_all, *w)
         return e_all[n_iters].clone()
 
     @staticmethod
     def backward(ctx, grad_out):
         e_all, H_all, *w = ctx.saved_tensors
-        grads = _lib.segclf_backward(ctx.batch, list(w), ctx.F, ctx.D, ctx.n_iters, e_all, H_all,
-                                     grad_out.to(torch.float32).contiguous())
-        return (None, None, None, None) + tuple(grads)
+        go = grad_out.to(torch.float32).contiguous()
+        b = ctx.batch
+        # small graphs (the reference's muon events): the whole backward in one launch
+        lay = b.event_layout() if (ctx.use_events and b.n_graphs > 0) else None
+        if lay is not None and _lib.events_backward_supported(ctx.F, ctx.D, lay.max_hits, lay.max_segments):
+            grads = _lib.segclf_backward_events(b, lay, list(w), ctx.F, ctx.D, ctx.n_iters, e_all, H_all, go)
+        else:
+            grads = _lib.segclf_backward(b, list(w), ctx.F, ctx.D, ctx.n_iters, e_all, H_all, go)
+        return (None, None, None, None, None) + tuple(grads)
 
 
 def segclf_apply(model, batch):
@@ -41,7 +47,9 @@ def segclf_apply(model, batch):
     weights = [lin.weight, lin.bias,
                en[0].effective_weight(), en[0].bias, en[2].effective_weight(), en[2].bias,
                nn_[0].effective_weight(), nn_[0].bias, nn_[2].effective_weight(), nn_[2].bias]
-    e = _SegClf.apply(batch, F, D, model.n_iters, *weights)
+    # (the 1024-graph bound of the one-launch kernels: beyond it the per-pass kernels fill the chip)
+    use_events = bool(getattr(model, "use_events", True)) and batch.n_graphs <= 1024
+    e = _SegClf.apply(batch, F, D, model.n_iters, use_events, *weights)
     if batch.dense_shape:
         e = e.view(batch.dense_shape[0], batch.dense_shape[2])
     return e

@@ -573,6 +573,381 @@ int backward_t(const gnn_graph_t *g, const gnn_params_t *p, int T, const float *
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// small events: the WHOLE backward of one graph in one workgroup, one launch for the batch
+// ---------------------------------------------------------------------------------------------
+// Counterpart of k_event (gnn_kernels.hip).  The per-pass kernels above cost 5T + 4 launches of a
+// few microseconds each, which for the reference's muon graphs (tens of hits) is all of the
+// backward.  Here a workgroup owns one graph: its saved H_t / e_t rows, the P/Q rows, the hit
+// gradients and every intermediate of backward_t live in LDS, the stages are the same statements
+// in the same order per item, a barrier separates them.  Weight gradients: every thread owns a few
+// elements of each gradient tensor, sums its graph's contributions in registers over all
+// iterations and issues one atomic per element at the end (to the workgroup's gradient replica).
+template <int F, int D>
+struct EvBwd {
+    static constexpr int C = F + D, LDH = (C + 3) & ~3;
+    // weights in LDS: W1, b1, W2, W3, b3, W4 (16-byte aligned pieces)
+    static constexpr int oW1 = 0, ob1 = oW1 + D * 2 * C, oW2 = ob1 + D, oW3 = oW2 + D,
+                         ob3 = oW3 + ((D * 3 * C + 3) & ~3), oW4 = ob3 + D, w_total = oW4 + D * D;
+    static constexpr int per_hit = 9 * LDH + 5 * D;     // Hc Hp gH gHp (4) + gmio (2) + M (3) | PQ fa (2D each) qb
+    static size_t lds_bytes(int64_t cap_h, int64_t cap_s)
+    {
+        const int64_t s4 = (cap_s + 3) & ~3;
+        return (size_t)(cap_h * per_hit + 2 * s4 + w_total + 2 * (cap_h + 1) + 6 * cap_s + 8) * sizeof(float);
+    }
+    static constexpr int n1 = D * 2 * C + D, n3 = D * 3 * C + D, n4 = D * D + D, nin = D * F + D;
+};
+
+template <int F, int D>
+__global__ __launch_bounds__(kBlock) void k_event_bwd(
+    gnn_graph_t g, gnn_params_t p, const int32_t *__restrict__ hit_ptr,
+    const int32_t *__restrict__ seg_ptr, int T, const float *__restrict__ e_all,
+    const float *__restrict__ H_all, const float *__restrict__ grad_out, float *__restrict__ rep,
+    int cap_h, int cap_s)
+{
+    using B = EvBwd<F, D>;
+    using GL = GradLayout<F, D>;
+    constexpr int C = B::C, LDH = B::LDH, NT = kBlock;
+    extern __shared__ __attribute__((aligned(16))) float eb_lds[];
+    const int s4 = (cap_s + 3) & ~3;
+    float *Hc = eb_lds, *Hp = Hc + cap_h * LDH, *gH = Hp + cap_h * LDH, *gHp = gH + cap_h * LDH,
+          *gmio = gHp + cap_h * LDH, *Mr = gmio + cap_h * 2 * LDH, *PQ = Mr + cap_h * 3 * LDH,
+          *fa = PQ + cap_h * 2 * D, *qb = fa + cap_h * 2 * D, *ec = qb + cap_h * D, *gu = ec + s4,
+          *wl = gu + s4;
+    int32_t *ip = reinterpret_cast<int32_t *>(wl + B::w_total), *op = ip + cap_h + 1,
+            *ie = op + cap_h + 1, *inb = ie + cap_s, *oe = inb + cap_s, *onb = oe + cap_s,
+            *sl = onb + cap_s, *dl = sl + cap_s;
+    const int tid = threadIdx.x;
+    const int h0 = hit_ptr[blockIdx.x], nh = hit_ptr[blockIdx.x + 1] - h0;
+    const int s0 = seg_ptr[blockIdx.x], ns = seg_ptr[blockIdx.x + 1] - s0;
+    const int64_t N = g.n_hits, E = g.n_segments;
+    rep = my_replica(rep, GL::stride);
+
+    for (int i = tid; i < D * 2 * C; i += NT) wl[B::oW1 + i] = p.W1[i];
+    for (int i = tid; i < D * 3 * C; i += NT) wl[B::oW3 + i] = p.W3[i];
+    for (int i = tid; i < D * D; i += NT) wl[B::oW4 + i] = p.W4[i];
+    for (int i = tid; i < D; i += NT) {
+        wl[B::ob1 + i] = p.b1[i];
+        wl[B::oW2 + i] = p.W2[i];
+        wl[B::ob3 + i] = p.b3[i];
+    }
+    const float *W1 = wl + B::oW1, *b1 = wl + B::ob1, *W2 = wl + B::oW2, *W3 = wl + B::oW3,
+                *b3 = wl + B::ob3, *W4 = wl + B::oW4;
+    if (nh > 0) {       // the graph's index arrays as LOCAL ids (see k_event)
+        const int ib = g.in_ptr[h0], ob = g.out_ptr[h0];
+        for (int n = tid; n <= nh; n += NT) {
+            ip[n] = g.in_ptr[h0 + n] - ib;
+            op[n] = g.out_ptr[h0 + n] - ob;
+        }
+        const int ni = g.in_ptr[h0 + nh] - ib, no = g.out_ptr[h0 + nh] - ob;
+        for (int k = tid; k < ni; k += NT) {
+            ie[k] = g.in_eid[ib + k] - s0;
+            inb[k] = g.in_nbr[ib + k] - h0;
+        }
+        for (int k = tid; k < no; k += NT) {
+            oe[k] = g.out_eid[ob + k] - s0;
+            onb[k] = g.out_nbr[ob + k] - h0;
+        }
+    }
+    for (int j = tid; j < ns; j += NT) {
+        const int sg = g.src[s0 + j];
+        sl[j] = sg < 0 ? -1 : sg - h0;
+        dl[j] = sg < 0 ? -1 : g.dst[s0 + j] - h0;
+    }
+    for (int i = tid; i < nh * LDH; i += NT) {
+        gH[i] = 0.0f;
+        Hc[i] = H_all[((int64_t)T * N + h0) * LDH + i];
+    }
+    for (int j = tid; j < ns; j += NT) ec[j] = e_all[(int64_t)T * E + s0 + j];
+
+    // this thread's elements of the gradient tensors (summed over the graph's items and over t)
+    float a1[(B::n1 + NT - 1) / NT], a3[(B::n3 + NT - 1) / NT], a4[(B::n4 + NT - 1) / NT],
+        ain[(B::nin + NT - 1) / NT];
+#pragma unroll
+    for (int u = 0; u < (B::n1 + NT - 1) / NT; ++u) a1[u] = 0.0f;
+#pragma unroll
+    for (int u = 0; u < (B::n3 + NT - 1) / NT; ++u) a3[u] = 0.0f;
+#pragma unroll
+    for (int u = 0; u < (B::n4 + NT - 1) / NT; ++u) a4[u] = 0.0f;
+#pragma unroll
+    for (int u = 0; u < (B::nin + NT - 1) / NT; ++u) ain[u] = 0.0f;
+    float sW2[D], sb2 = 0.0f, spad = 0.0f;      // per-segment sums (k_edge_bwd)
+#pragma unroll
+    for (int i = 0; i < D; ++i) sW2[i] = 0.0f;
+    __syncthreads();
+
+    for (int t = T;; --t) {
+        // P/Q rows of H_t (kb_pq): one (hit, row) per thread
+        for (int i = tid; i < nh * 2 * D; i += NT) {
+            const int n = i / (2 * D), r = i % (2 * D), d = r % D;
+            const bool isq = r >= D;
+            float acc = isq ? 0.0f : b1[d];
+            const float *w = W1 + d * 2 * C + (isq ? C : 0);
+            for (int k = 0; k < C; ++k) acc = fmaf(w[k], Hc[n * LDH + k], acc);
+            PQ[n * 2 * D + r] = acc;
+        }
+        __syncthreads();
+        // edge pass t (k_edge_bwd): gu per segment, sums for gW2 / gb2 / padded share of gb1
+        for (int j = tid; j < ns; j += NT) {
+            const int s = sl[j], d = dl[j];
+            const float ev = ec[j];
+            float gej = 0.0f;
+            if (t == T) {
+                gej = grad_out[s0 + j];
+            } else if (s >= 0) {
+                for (int c = 0; c < C; ++c) gej = fmaf(gmio[d * 2 * LDH + c], Hc[s * LDH + c], gej);
+                for (int c = 0; c < C; ++c) gej = fmaf(gmio[s * 2 * LDH + LDH + c], Hc[d * LDH + c], gej);
+            }
+            const float guv = gej * ev * (1.0f - ev);
+            if (s >= 0) {
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+                    sW2[i] = fmaf(guv, tanh_f(PQ[s * 2 * D + i] + PQ[d * 2 * D + D + i]), sW2[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < D; ++i) sW2[i] = fmaf(guv, tanh_f(b1[i]), sW2[i]);
+                spad += guv;
+            }
+            sb2 += guv;
+            gu[j] = guv;
+        }
+        __syncthreads();
+        // k_pq_bwd: gP = sum_out gz, gQ = sum_in gz, one (hit, unit, P|Q) per thread -> fa = [gP | gQ]
+        for (int i = tid; i < nh * 2 * D; i += NT) {
+            const int n = i / (2 * D), r = i % (2 * D), ii = r % D;
+            float acc = 0.0f;
+            if (r < D) {
+                const float own = PQ[n * 2 * D + ii];
+                for (int k = op[n]; k < op[n + 1]; ++k) {
+                    const float a = tanh_f(own + PQ[onb[k] * 2 * D + D + ii]);
+                    acc += gu[oe[k]] * W2[ii] * (1.0f - a * a);
+                }
+            } else {
+                const float own = PQ[n * 2 * D + D + ii];
+                for (int k = ip[n]; k < ip[n + 1]; ++k) {
+                    const float a = tanh_f(PQ[inb[k] * 2 * D + ii] + own);
+                    acc += gu[ie[k]] * W2[ii] * (1.0f - a * a);
+                }
+            }
+            fa[n * 2 * D + r] = acc;
+        }
+        __syncthreads();
+        for (int i = tid; i < nh * C; i += NT) {            // gH += W1a^T gP + W1b^T gQ
+            const int n = i / C, k = i % C;
+            float acc = 0.0f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                acc = fmaf(W1[d * 2 * C + k], fa[n * 2 * D + d], acc);
+                acc = fmaf(W1[d * 2 * C + C + k], fa[n * 2 * D + D + d], acc);
+            }
+            gH[n * LDH + k] += acc;
+        }
+#pragma unroll
+        for (int u = 0; u < (B::n1 + NT - 1) / NT; ++u) {    // gW1, gb1
+            const int o = tid + u * NT;
+            if (o < B::n1) {
+                float acc = 0.0f;
+                if (o < D * 2 * C) {
+                    const int d = o / (2 * C), k = o % (2 * C);
+                    const float *f = fa + (k < C ? d : D + d), *h = Hc + (k < C ? k : k - C);
+                    for (int n = 0; n < nh; ++n) acc = fmaf(f[n * 2 * D], h[n * LDH], acc);
+                } else {
+                    for (int n = 0; n < nh; ++n) acc += fa[n * 2 * D + (o - D * 2 * C)];
+                }
+                a1[u] += acc;
+            }
+        }
+        __syncthreads();
+        if (t == 0) break;
+        // node pass t-1 -> t (k_node_bwd): H_{t-1}, e_{t-1} in; Hc = H_t holds the pass's outputs
+        for (int i = tid; i < nh * LDH; i += NT) Hp[i] = H_all[((int64_t)(t - 1) * N + h0) * LDH + i];
+        for (int j = tid; j < ns; j += NT) ec[j] = e_all[(int64_t)(t - 1) * E + s0 + j];
+        __syncthreads();
+        for (int i = tid; i < nh * 3 * LDH; i += NT) {       // M = [mi | mo | h], rows padded to LDH
+            const int n = i / (3 * LDH), part = (i / LDH) % 3, c = i % LDH;
+            float acc = 0.0f;
+            if (part == 0) {
+                for (int k = ip[n]; k < ip[n + 1]; ++k) acc = fmaf(ec[ie[k]], Hp[inb[k] * LDH + c], acc);
+            } else if (part == 1) {
+                for (int k = op[n]; k < op[n + 1]; ++k) acc = fmaf(ec[oe[k]], Hp[onb[k] * LDH + c], acc);
+            } else {
+                acc = Hp[n * LDH + c];
+            }
+            Mr[i] = acc;
+        }
+        __syncthreads();
+        for (int i = tid; i < nh * D; i += NT) {             // q and gr
+            const int n = i / D, d = i % D;
+            float acc = b3[d];
+            for (int k = 0; k < 3 * C; ++k) acc = fmaf(W3[d * 3 * C + k], Mr[n * 3 * LDH + (k / C) * LDH + k % C], acc);
+            qb[i] = tanh_f(acc);
+            const float hn = Hc[n * LDH + d];
+            fa[n * 2 * D + d] = gH[n * LDH + d] * (1.0f - hn * hn);
+        }
+        __syncthreads();
+        for (int i = tid; i < nh * D; i += NT) {             // gp
+            const int n = i / D, k = i % D;
+            float acc = 0.0f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) acc = fmaf(W4[d * D + k], fa[n * 2 * D + d], acc);
+            fa[n * 2 * D + D + k] = acc * (1.0f - qb[i] * qb[i]);
+        }
+        __syncthreads();
+        for (int i = tid; i < nh * 3 * C; i += NT) {         // gM -> gmi | gmo | gH_prev (self part)
+            const int n = i / (3 * C), k = i % (3 * C);
+            float acc = 0.0f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) acc = fmaf(W3[d * 3 * C + k], fa[n * 2 * D + D + d], acc);
+            if (k < C) gmio[n * 2 * LDH + k] = acc;
+            else if (k < 2 * C) gmio[n * 2 * LDH + LDH + (k - C)] = acc;
+            else gHp[n * LDH + (k - 2 * C)] = acc;
+        }
+#pragma unroll
+        for (int u = 0; u < (B::n3 + NT - 1) / NT; ++u) {    // gW3, gb3
+            const int o = tid + u * NT;
+            if (o < B::n3) {
+                float acc = 0.0f;
+                if (o < D * 3 * C) {
+                    const int d = o / (3 * C), k = o % (3 * C);
+                    const float *f = fa + D + d, *m = Mr + (k / C) * LDH + k % C;
+                    for (int n = 0; n < nh; ++n) acc = fmaf(f[n * 2 * D], m[n * 3 * LDH], acc);
+                } else {
+                    for (int n = 0; n < nh; ++n) acc += fa[n * 2 * D + D + (o - D * 3 * C)];
+                }
+                a3[u] += acc;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < (B::n4 + NT - 1) / NT; ++u) {    // gW4, gb4
+            const int o = tid + u * NT;
+            if (o < B::n4) {
+                float acc = 0.0f;
+                if (o < D * D) {
+                    const int d = o / D, k = o % D;
+                    for (int n = 0; n < nh; ++n) acc = fmaf(fa[n * 2 * D + d], qb[n * D + k], acc);
+                } else {
+                    for (int n = 0; n < nh; ++n) acc += fa[n * 2 * D + (o - D * D)];
+                }
+                a4[u] += acc;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < nh * C; i += NT) {             // k_agg_bwd_n
+            const int n = i / C, c = i % C;
+            float acc = 0.0f;
+            for (int k = op[n]; k < op[n + 1]; ++k) acc = fmaf(ec[oe[k]], gmio[onb[k] * 2 * LDH + c], acc);
+            for (int k = ip[n]; k < ip[n + 1]; ++k) acc = fmaf(ec[ie[k]], gmio[inb[k] * 2 * LDH + LDH + c], acc);
+            gHp[n * LDH + c] += acc;
+        }
+        __syncthreads();
+        float *tmp = gH; gH = gHp; gHp = tmp;
+        tmp = Hc; Hc = Hp; Hp = tmp;          // H_{t-1} is the next pass's H_t; ec already holds e_{t-1}
+    }
+    // input network (k_input_bwd): Hc = H_0
+    for (int i = tid; i < nh * D; i += NT) {
+        const int n = i / D, d = i % D;
+        const float h = Hc[n * LDH + d];
+        fa[n * 2 * D + d] = gH[n * LDH + d] * (1.0f - h * h);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < (B::nin + NT - 1) / NT; ++u) {
+        const int o = tid + u * NT;
+        if (o < B::nin) {
+            float acc = 0.0f;
+            if (o < D * F) {
+                const int d = o / F, k = o % F;
+                for (int n = 0; n < nh; ++n) acc = fmaf(fa[n * 2 * D + d], Hc[n * LDH + D + k], acc);
+            } else {
+                for (int n = 0; n < nh; ++n) acc += fa[n * 2 * D + (o - D * F)];
+            }
+            ain[u] += acc;
+        }
+    }
+    // flush: one atomic per gradient element per graph
+#pragma unroll
+    for (int u = 0; u < (B::n1 + NT - 1) / NT; ++u) {
+        const int o = tid + u * NT;
+        if (o < B::n1) atomicAdd(rep + (o < D * 2 * C ? GL::oW1 + o : GL::ob1 + (o - D * 2 * C)), a1[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < (B::n3 + NT - 1) / NT; ++u) {
+        const int o = tid + u * NT;
+        if (o < B::n3) atomicAdd(rep + (o < D * 3 * C ? GL::oW3 + o : GL::ob3 + (o - D * 3 * C)), a3[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < (B::n4 + NT - 1) / NT; ++u) {
+        const int o = tid + u * NT;
+        if (o < B::n4) atomicAdd(rep + (o < D * D ? GL::oW4 + o : GL::ob4 + (o - D * D)), a4[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < (B::nin + NT - 1) / NT; ++u) {
+        const int o = tid + u * NT;
+        if (o < B::nin) atomicAdd(rep + (o < D * F ? GL::oWin + o : GL::obin + (o - D * F)), ain[u]);
+    }
+    {
+        constexpr int NS = D + 2, NW = NT / 64;
+        __shared__ float red[NW * NS];
+        float vals[NS];
+#pragma unroll
+        for (int i = 0; i < D; ++i) vals[i] = sW2[i];
+        vals[D] = sb2;
+        vals[D + 1] = spad;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            float x = vals[i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+            if ((tid & 63) == 0) red[(tid >> 6) * NS + i] = x;
+        }
+        __syncthreads();
+        if (tid <= D) {
+            float x = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) x += red[w * NS + tid];
+            atomicAdd(rep + (tid < D ? GL::oW2 + tid : GL::ob2), x);
+        } else if (tid < 2 * D + 1) {
+            const int i = tid - D - 1;
+            float x = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) x += red[w * NS + D + 1];
+            const float a = tanh_f(b1[i]);
+            if (x != 0.0f) atomicAdd(rep + GL::ob1 + i, x * W2[i] * (1.0f - a * a));
+        }
+    }
+}
+
+constexpr size_t kEventBwdLdsMax = 128 * 1024;
+
+template <int F, int D>
+int backward_events_t(const gnn_graph_t *g, const gnn_params_t *p, const int32_t *hit_ptr,
+                      const int32_t *seg_ptr, int64_t n_graphs, int cap_h, int cap_s, int T,
+                      const float *e_all, const float *H_all, const float *grad_out,
+                      const gnn_grads_t *gr, char *ws, hipStream_t s)
+{
+    using GL = GradLayout<F, D>;
+    float *rp = reinterpret_cast<float *>(ws);
+    hipError_t err = hipMemsetAsync(rp, 0, (size_t)kReplicas * GL::stride * sizeof(float), s);
+    if (err != hipSuccess) return fail(-(int)err, "memset of the gradient replicas failed");
+    if (n_graphs > 0) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_event_bwd<F, D>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEventBwdLdsMax);
+            attr_done = true;
+        }
+        using B = EvBwd<F, D>;
+        const size_t lds = B::lds_bytes(cap_h, cap_s);
+        GNN_LAUNCH_SH("k_event_bwd", (k_event_bwd<F, D>), (unsigned)n_graphs, kBlock, lds, s, *g, *p, hit_ptr,
+                      seg_ptr, T, e_all, H_all, grad_out, rp, cap_h, cap_s);
+    }
+    GNN_LAUNCH("k_grad_fold", (k_grad_fold<F, D>), (GL::total + kBlock - 1) / kBlock, kBlock, s, rp, *gr);
+    return 0;
+}
+
+// shapes of the one-launch backward: the register-held gradient elements must stay few
+#define BWD_EVENT_SHAPES(X_) X_(2, 4) X_(2, 8) X_(2, 16) X_(3, 4) X_(3, 8) X_(3, 16) X_(11, 4) X_(11, 8) X_(11, 16)
+
 // ---- fused BCE loss (value + gradient in one pass over the scores) ----------------------------
 // torch.nn.BCELoss semantics (the loss of gnn/estimator.py:57): logs clamped at -100,
 // d/de = (e - y) / max(e (1 - e), 1e-12).  Every workgroup sums a fixed set of elements in a fixed
@@ -626,6 +1001,39 @@ int bce_loss(const float *e, const float *y, int64_t n, float scale, float *loss
     GNN_LAUNCH("k_bce", k_bce, blocks, kBlock, s, e, y, n, scale, grad_e, partial);
     GNN_LAUNCH("k_bce_final", k_bce_final, 1, 64, s, partial, blocks, scale, loss);
     return 0;
+}
+
+int backward_events_supported(int F, int D, int64_t max_hits, int64_t max_segments)
+{
+#define X_(F_, D_) if (F == F_ && D == D_) return EvBwd<F_, D_>::lds_bytes(max_hits, max_segments) <= kEventBwdLdsMax;
+    BWD_EVENT_SHAPES(X_)
+#undef X_
+    return 0;
+}
+
+size_t backward_events_workspace_bytes(int F, int D)
+{
+    const int C = F + D;
+    const int tot = D * F + D + D * 2 * C + D + D + 1 + D * 3 * C + D + D * D + D;
+    return (size_t)kReplicas * ((tot + 63) & ~63) * sizeof(float) + 256;
+}
+
+int backward_events(const gnn_graph_t *g, const gnn_params_t *p, const int32_t *hit_ptr,
+                    const int32_t *seg_ptr, int64_t n_graphs, int cap_h, int cap_s, int T,
+                    const float *e_all, const float *H_all, const float *grad_out,
+                    const gnn_grads_t *gr, void *ws, size_t ws_bytes, hipStream_t s)
+{
+    if (ws_bytes < backward_events_workspace_bytes(p->F, p->D))
+        return fail(GNN_ERR_WORKSPACE, "event backward workspace too small: need %zu bytes",
+                    backward_events_workspace_bytes(p->F, p->D));
+    if (!backward_events_supported(p->F, p->D, cap_h, cap_s))
+        return fail(GNN_ERR_UNSUPPORTED, "events of up to %d hits / %d segments do not fit the one-launch "
+                    "backward at input_dim=%d hidden_dim=%d", cap_h, cap_s, p->F, p->D);
+    char *base = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
+#define X_(F_, D_) if (p->F == F_ && p->D == D_) return backward_events_t<F_, D_>(g, p, hit_ptr, seg_ptr, n_graphs, cap_h, cap_s, T, e_all, H_all, grad_out, gr, base, s);
+    BWD_EVENT_SHAPES(X_)
+#undef X_
+    return fail(GNN_ERR_UNSUPPORTED, "no one-launch backward for input_dim=%d hidden_dim=%d", p->F, p->D);
 }
 
 size_t backward_workspace_bytes(int64_t N, int64_t E, int F, int D)

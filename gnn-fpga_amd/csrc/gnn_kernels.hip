@@ -852,6 +852,31 @@ int gnn_segclf_backward(const gnn_graph_t *g, const gnn_params_t *p, int32_t n_i
                     static_cast<hipStream_t>(stream));
 }
 
+int gnn_events_backward_supported(int32_t F, int32_t D, int64_t max_hits, int64_t max_segments)
+{
+    if (max_hits < 0 || max_segments < 0) return 0;
+    return backward_events_supported(F, D, max_hits, max_segments);
+}
+
+size_t gnn_backward_events_workspace_bytes(int32_t F, int32_t D) { return backward_events_workspace_bytes(F, D); }
+
+int gnn_segclf_backward_events(const gnn_graph_t *g, const gnn_params_t *p, const int32_t *hit_ptr,
+                               const int32_t *seg_ptr, int64_t n_graphs, int32_t max_hits,
+                               int32_t max_segments, int32_t n_iters, const float *e_all,
+                               const float *H_all, const float *grad_out, const gnn_grads_t *gr,
+                               void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!g || !p || !gr || n_iters < 0 || n_graphs < 0 || max_hits < 0 || max_segments < 0 || !workspace)
+        return fail(GNN_ERR_BADARG, "gnn_segclf_backward_events: bad argument");
+    if (n_graphs > 0 && (!hit_ptr || !seg_ptr)) return fail(GNN_ERR_BADARG, "gnn_segclf_backward_events: graph offsets missing");
+    if ((g->n_segments > 0 && (!e_all || !grad_out || !g->src || !g->dst)) || (g->n_hits > 0 && (!H_all || !g->in_ptr || !g->out_ptr)))
+        return fail(GNN_ERR_BADARG, "gnn_segclf_backward_events: saved tensors or graph arrays missing");
+    if (!gr->Win || !gr->bin || !gr->W1 || !gr->b1 || !gr->W2 || !gr->b2 || !gr->W3 || !gr->b3 || !gr->W4 || !gr->b4)
+        return fail(GNN_ERR_BADARG, "gnn_segclf_backward_events: gradient pointer missing");
+    return backward_events(g, p, hit_ptr, seg_ptr, n_graphs, max_hits, max_segments, n_iters, e_all, H_all,
+                           grad_out, gr, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
 int gnn_bce_loss(const float *e, const float *y, int64_t n, float scale, float *loss_out,
                  float *grad_e, void *workspace, void *stream)
 {

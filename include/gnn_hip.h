@@ -195,6 +195,19 @@ int gnn_segclf_backward(const gnn_graph_t *g, const gnn_params_t *p, int32_t n_i
                         const gnn_grads_t *grads, void *workspace, size_t workspace_bytes,
                         void *stream);
 
+/* The same gradients for a batch of SMALL graphs (gnn/prepareMuonGraphs.py sizes) in ONE launch:
+ * one workgroup per graph keeps the graph's saved rows and every intermediate in LDS (counterpart
+ * of gnn_segclf_forward_events; same layout contract for hit_ptr / seg_ptr).  Workspace:
+ * gnn_backward_events_workspace_bytes.  gnn_events_backward_supported: 1 if graphs of that size
+ * fit one workgroup for this (input_dim, hidden_dim). */
+int gnn_events_backward_supported(int32_t F, int32_t D, int64_t max_hits, int64_t max_segments);
+size_t gnn_backward_events_workspace_bytes(int32_t F, int32_t D);
+int gnn_segclf_backward_events(const gnn_graph_t *g, const gnn_params_t *p, const int32_t *hit_ptr,
+                               const int32_t *seg_ptr, int64_t n_graphs, int32_t max_hits,
+                               int32_t max_segments, int32_t n_iters, const float *e_all,
+                               const float *H_all, const float *grad_out, const gnn_grads_t *grads,
+                               void *workspace, size_t workspace_bytes, void *stream);
+
 /* SegmentClassifier.forward (gnn/model.py:140-156) on a planned batch: the fast path.
  * One fused kernel per message-passing iteration (edge scores are recomputed at both
  * endpoints from per-hit partial products instead of being stored), one final edge kernel.

@@ -638,3 +638,45 @@ def test_csr_built_on_the_gpu_equals_the_host_csr(hip):
     for name in HitGraphBatch._CSR_NAMES:
         a, c = getattr(host, name), getattr(dev, name)
         assert c.is_cuda and a.dtype == c.dtype and torch.equal(a, c.cpu()), name
+
+
+@pytest.mark.parametrize("F,D,T", [(11, 8, 3), (3, 8, 2), (2, 16, 1), (3, 4, 0)])
+def test_one_launch_backward_for_small_events(hip, F, D, T):
+    """gnn_segclf_backward_events (one workgroup per graph, everything in LDS) against the per-pass
+    backward kernels on the same saved tensors: all ten gradients, padded segments, isolated hits,
+    graphs without segments."""
+    from gnn_fpga_amd import _lib
+    from gnn_fpga_amd.loss import BCELoss
+    from gnn_fpga_amd.model import SegmentClassifier
+    torch.manual_seed(F + D + T)
+    if F == 11:
+        graphs = [synth.muon_graph(s) for s in range(40)]
+    else:
+        graphs = [synth.layered_graph(n, e, F, n_layers=L, seed=500 + i)
+                  for i, (n, e, L) in enumerate([(60, 200, 6), (3, 2, 2), (40, 0, 4), (25, 90, 5), (2, 1, 2)])]
+    b = HitGraphBatch.from_graphs(graphs)
+    src, dst = b.src.numpy().copy(), b.dst.numpy().copy()
+    src[1::9] = -1
+    dst[1::9] = -1
+    b = HitGraphBatch(b.X.numpy(), src, dst, hit_ptr=b.hit_ptr, seg_ptr=b.seg_ptr).cuda()
+    lay = b.event_layout()
+    assert lay is not None and _lib.events_backward_supported(F, D, lay.max_hits, lay.max_segments)
+    y = (torch.arange(b.n_segments, device="cuda") % 2 == 0).float()
+    m = SegmentClassifier(input_dim=F, hidden_dim=D, n_iters=T).cuda().train()
+    out, calls = {}, []
+    real = _lib.segclf_backward_events
+    _lib.segclf_backward_events = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        for events in (True, False):
+            m.use_events = events
+            m.zero_grad()
+            BCELoss()(m(b), y).backward()
+            out[events] = [p.grad.detach().cpu().double().numpy().copy() for p in m.parameters()]
+    finally:
+        _lib.segclf_backward_events = real
+    assert len(calls) == 1                      # the one-launch path ran for use_events = True only
+    for (k, _), a, r in zip(m.named_parameters(), out[True], out[False]):
+        assert np.abs(a - r).max() < 1e-7 + 1e-4 * np.abs(r).max(), k
+    big = HitGraphBatch.from_graphs([synth.layered_graph(20000, 100000, 3, seed=1)])
+    lb = big.event_layout()
+    assert not _lib.events_backward_supported(3, 8, lb.max_hits, lb.max_segments)
