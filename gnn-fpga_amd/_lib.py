@@ -65,6 +65,8 @@ SIGNATURES = {
     "gnn_events_supported": (ctypes.c_int, [_i32, _i32, _i64, _i64]),
     "gnn_segclf_forward_events": (ctypes.c_int, [ctypes.POINTER(GnnGraph), ctypes.POINTER(GnnParams),
                                                  _f, _f, _i64, _i32, _i32, _i32, _f, _f]),
+    "gnn_segclf_forward_train_events": (ctypes.c_int, [ctypes.POINTER(GnnGraph), ctypes.POINTER(GnnParams),
+                                                       _f, _f, _i64, _i32, _i32, _i32, _f, _f, _f]),
     "gnn_events_backward_supported": (ctypes.c_int, [_i32, _i32, _i64, _i64]),
     "gnn_backward_events_workspace_bytes": (_sz, [_i32, _i32]),
     "gnn_segclf_backward_events": (ctypes.c_int, [ctypes.POINTER(GnnGraph), ctypes.POINTER(GnnParams),
@@ -276,13 +278,23 @@ def segclf_forward_events(batch, layout, weights, F, D, n_iters, out=None, param
     return out
 
 
-def segclf_forward_train(batch, weights, F, D, n_iters):
-    """Training forward: returns (e_all [(T+1), E], H_all [(T+1), N, ldh]); scores = e_all[-1]."""
+def segclf_forward_train(batch, weights, F, D, n_iters, layout=None):
+    """Training forward: returns (e_all [(T+1), E], H_all [(T+1), N, ldh]); scores = e_all[-1].
+    `layout` (batch.event_layout() of a batch of small graphs): one launch for the whole forward."""
     dev = batch.X.device
     E, N = batch.n_segments, batch.n_hits
     ldh = h_stride(F, D)
     e_all = torch.empty((n_iters + 1, E), dtype=torch.float32, device=dev)
     H_all = torch.empty((n_iters + 1, N, ldh), dtype=torch.float32, device=dev)
+    if layout is not None:
+        g = cached_graph_struct(batch)
+        p = params_struct(weights, F, D)
+        _check(load().gnn_segclf_forward_train_events(
+            ctypes.byref(g), ctypes.byref(p), _dev(layout.hit_ptr, torch.int32, "hit_ptr"),
+            _dev(layout.seg_ptr, torch.int32, "seg_ptr"), batch.n_graphs, layout.max_hits,
+            layout.max_segments, n_iters, _dev(e_all, torch.float32, "e_all"),
+            _dev(H_all, torch.float32, "H_all"), _stream()))
+        return e_all, H_all
     ws = torch.empty(workspace_bytes(N, E, F, D), dtype=torch.uint8, device=dev)
     g = cached_graph_struct(batch)
     p = params_struct(weights, F, D)

@@ -15,7 +15,11 @@ class _SegClf(torch.autograd.Function):
     @staticmethod
     def forward(ctx, batch, F, D, n_iters, use_events, *weights):
         w = [t.detach().to(torch.float32).contiguous() for t in weights]
-        e_all, H_all = _lib.segclf_forward_train(batch, w, F, D, n_iters)
+        # small graphs (the reference's muon events): the whole forward in one launch
+        lay = batch.event_layout() if (use_events and batch.n_graphs > 0) else None
+        if lay is not None and not _lib.events_supported(F, D, lay.max_hits, lay.max_segments):
+            lay = None
+        e_all, H_all = _lib.segclf_forward_train(batch, w, F, D, n_iters, layout=lay)
         ctx.batch, ctx.F, ctx.D, ctx.n_iters, ctx.use_events = batch, F, D, n_iters, use_events
         ctx.save_for_backward(e_all, H_all, *w)
         return e_all[n_iters].clone()

@@ -308,8 +308,9 @@ __global__ __launch_bounds__((EvCfg<D>::NT)) void k_event(
     const float *__restrict__ b2, const float *__restrict__ W3, const float *__restrict__ b3,
     const float *__restrict__ W4, const float *__restrict__ b4,
     const int32_t *__restrict__ hit_ptr, const int32_t *__restrict__ seg_ptr, int n_iters,
-    float *__restrict__ e_out, int cap_hits, int cap_segments)
-{
+    float *__restrict__ e_out, int cap_hits, int cap_segments, float *__restrict__ e_all,
+    float *__restrict__ H_all)
+{   // e_all / H_all (training forward): every pass's scores [T+1, E] and hit rows [T+1, N, LDH]
     constexpr int C = Shape<F, D>::C;
     constexpr int LDH = Shape<F, D>::LDH;
     constexpr int NT = EvCfg<D>::NT, NWV = EvCfg<D>::NWV;
@@ -415,6 +416,12 @@ __global__ __launch_bounds__((EvCfg<D>::NT)) void k_event(
         }
     }
     __syncthreads();
+    auto keep_rows = [&](const float *Hsrc, int t) {
+        if (H_all)
+            for (int i = threadIdx.x; i < nh * LDH; i += NT)
+                H_all[((int64_t)t * g.n_hits + h0) * LDH + i] = Hsrc[i];
+    };
+    keep_rows(H, 0);
     pq_rows(H);
     __syncthreads();
 
@@ -440,10 +447,11 @@ __global__ __launch_bounds__((EvCfg<D>::NT)) void k_event(
                 acc = fmaf(p.W2[4 * v + 3], tanh_f(z.w), acc);
             }
             const float e = sigmoid_f(acc);
-            if (last)
-                e_out[s0 + j] = e;
-            else
+            if (e_all) e_all[(int64_t)t * g.n_segments + s0 + j] = e;
+            if (!last)
                 es[j] = e;
+            else if (e_out)
+                e_out[s0 + j] = e;
         }
         if (last) break;
         __syncthreads();
@@ -504,6 +512,7 @@ __global__ __launch_bounds__((EvCfg<D>::NT)) void k_event(
             for (int r = 0; r < RW; ++r) Hn[n * LDH + d0 + r] = tanh_f(acc[r]);
         }
         __syncthreads();
+        keep_rows(Hn, t + 1);
         pq_rows(Hn);                                         // nobody reads PQ or H in this step
         __syncthreads();
         float *tmp = H; H = Hn; Hn = tmp;
@@ -524,7 +533,8 @@ inline size_t event_lds_bytes(int F, int D, int64_t cap_hits, int64_t cap_segmen
 template <int F, int D>
 int run_events(const gnn_graph_t *g, const gnn_params_t *p, const int32_t *hit_ptr,
                const int32_t *seg_ptr, int64_t n_graphs, int cap_hits, int cap_segments,
-               int n_iters, float *e_out, hipStream_t s)
+               int n_iters, float *e_out, hipStream_t s, float *e_all = nullptr,
+               float *H_all = nullptr)
 {
     if (n_graphs <= 0) return 0;
     const size_t lds = event_lds_bytes(F, D, cap_hits, cap_segments);
@@ -536,7 +546,7 @@ int run_events(const gnn_graph_t *g, const gnn_params_t *p, const int32_t *hit_p
     }
     GNN_LAUNCH_SH("k_event", (k_event<F, D>), (unsigned)n_graphs, EvCfg<D>::NT, lds, s, *g, p->Win, p->bin, p->W1,
                   p->b1, p->W2, p->b2, p->W3, p->b3, p->W4, p->b4, hit_ptr, seg_ptr, n_iters, e_out,
-                  cap_hits, cap_segments);
+                  cap_hits, cap_segments, e_all, H_all);
     return 0;
 }
 
@@ -850,6 +860,26 @@ int gnn_segclf_backward(const gnn_graph_t *g, const gnn_params_t *p, int32_t n_i
         return fail(GNN_ERR_BADARG, "gnn_segclf_backward: gradient pointer missing");
     return backward(g, p, n_iters, e_all, H_all, grad_out, gr, workspace, workspace_bytes,
                     static_cast<hipStream_t>(stream));
+}
+
+int gnn_segclf_forward_train_events(const gnn_graph_t *g, const gnn_params_t *p, const int32_t *hit_ptr,
+                                    const int32_t *seg_ptr, int64_t n_graphs, int32_t max_hits,
+                                    int32_t max_segments, int32_t n_iters, float *e_all, float *H_all,
+                                    void *stream)
+{
+    if (!g || !p || n_iters < 0 || n_graphs < 0 || max_hits < 0 || max_segments < 0)
+        return fail(GNN_ERR_BADARG, "gnn_segclf_forward_train_events: bad argument");
+    if (n_graphs > 0 && (!hit_ptr || !seg_ptr)) return fail(GNN_ERR_BADARG, "gnn_segclf_forward_train_events: graph offsets missing");
+    if (g->n_segments > 0 && (!e_all || !g->src || !g->dst)) return fail(GNN_ERR_BADARG, "gnn_segclf_forward_train_events: segment arrays missing");
+    if (g->n_hits > 0 && (!H_all || !g->X || !g->in_ptr || !g->out_ptr)) return fail(GNN_ERR_BADARG, "gnn_segclf_forward_train_events: hit arrays missing");
+    if (!gnn_events_supported(p->F, p->D, max_hits, max_segments))
+        return fail(GNN_ERR_UNSUPPORTED, "events of up to %d hits / %d segments do not fit one workgroup's LDS at input_dim=%d hidden_dim=%d",
+                    max_hits, max_segments, p->F, p->D);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define X_(F_, D_) if (p->F == F_ && p->D == D_) return run_events<F_, D_>(g, p, hit_ptr, seg_ptr, n_graphs, max_hits, max_segments, n_iters, nullptr, s, e_all, H_all);
+    GNN_FOR_EACH_SHAPE(X_)
+#undef X_
+    return fail(GNN_ERR_UNSUPPORTED, "no kernel for input_dim=%d hidden_dim=%d", p->F, p->D);
 }
 
 int gnn_events_backward_supported(int32_t F, int32_t D, int64_t max_hits, int64_t max_segments)

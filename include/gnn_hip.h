@@ -174,6 +174,13 @@ int gnn_segclf_forward_train(const gnn_graph_t *g, const gnn_params_t *p, int32_
                              float *e_all, float *H_all, void *workspace, size_t workspace_bytes,
                              void *stream);
 
+/* The same for a batch of small graphs in one launch (gnn_segclf_forward_events that also keeps
+ * e_all / H_all; bit-identical to gnn_segclf_forward_train). */
+int gnn_segclf_forward_train_events(const gnn_graph_t *g, const gnn_params_t *p, const int32_t *hit_ptr,
+                                    const int32_t *seg_ptr, int64_t n_graphs, int32_t max_hits,
+                                    int32_t max_segments, int32_t n_iters, float *e_all, float *H_all,
+                                    void *stream);
+
 /* Gradient of a scalar loss w.r.t. the ten parameter tensors, given grad_out [n_segments] =
  * dLoss/d(scores) and the tensors saved by gnn_segclf_forward_train.  Replaces autograd through
  * gnn/model.py:140-156 as triggered by loss.backward() in gnn/estimator.py:58.  Adds into

@@ -680,3 +680,22 @@ def test_one_launch_backward_for_small_events(hip, F, D, T):
     big = HitGraphBatch.from_graphs([synth.layered_graph(20000, 100000, 3, seed=1)])
     lb = big.event_layout()
     assert not _lib.events_backward_supported(3, 8, lb.max_hits, lb.max_segments)
+
+
+def test_one_launch_training_forward_keeps_the_same_tensors(hip):
+    """gnn_segclf_forward_train_events: the small-event kernel also stores every pass's scores and
+    hit rows; they must equal the per-pass training forward's bit for bit (padding columns too)."""
+    from gnn_fpga_amd import _lib
+    from gnn_fpga_amd.model import SegmentClassifier
+    torch.manual_seed(5)
+    graphs = [synth.muon_graph(s) for s in range(30)]
+    b = HitGraphBatch.from_graphs(graphs)
+    src, dst = b.src.numpy().copy(), b.dst.numpy().copy()
+    src[2::7] = -1
+    dst[2::7] = -1
+    b = HitGraphBatch(b.X.numpy(), src, dst, hit_ptr=b.hit_ptr, seg_ptr=b.seg_ptr).cuda()
+    m = SegmentClassifier(input_dim=11, hidden_dim=8, n_iters=3).cuda()
+    w = [t.detach().contiguous() for t in m.state_dict().values()]
+    e1, H1 = _lib.segclf_forward_train(b, w, 11, 8, 3)
+    e2, H2 = _lib.segclf_forward_train(b, w, 11, 8, 3, layout=b.event_layout())
+    assert torch.equal(e1, e2) and torch.equal(H1, H2)
