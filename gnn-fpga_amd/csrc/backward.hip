@@ -683,6 +683,7 @@ __global__ __launch_bounds__(kBlock) void k_event_bwd(
             const bool isq = r >= D;
             float acc = isq ? 0.0f : b1[d];
             const float *w = W1 + d * 2 * C + (isq ? C : 0);
+#pragma unroll
             for (int k = 0; k < C; ++k) acc = fmaf(w[k], Hc[n * LDH + k], acc);
             PQ[n * 2 * D + r] = acc;
         }
@@ -695,7 +696,9 @@ __global__ __launch_bounds__(kBlock) void k_event_bwd(
             if (t == T) {
                 gej = grad_out[s0 + j];
             } else if (s >= 0) {
+#pragma unroll
                 for (int c = 0; c < C; ++c) gej = fmaf(gmio[d * 2 * LDH + c], Hc[s * LDH + c], gej);
+#pragma unroll
                 for (int c = 0; c < C; ++c) gej = fmaf(gmio[s * 2 * LDH + LDH + c], Hc[d * LDH + c], gej);
             }
             const float guv = gej * ev * (1.0f - ev);
@@ -750,9 +753,9 @@ __global__ __launch_bounds__(kBlock) void k_event_bwd(
                 if (o < D * 2 * C) {
                     const int d = o / (2 * C), k = o % (2 * C);
                     const float *f = fa + (k < C ? d : D + d), *h = Hc + (k < C ? k : k - C);
-                    for (int n = 0; n < nh; ++n) acc = fmaf(f[n * 2 * D], h[n * LDH], acc);
+                    _Pragma("unroll 4") for (int n = 0; n < nh; ++n) acc = fmaf(f[n * 2 * D], h[n * LDH], acc);
                 } else {
-                    for (int n = 0; n < nh; ++n) acc += fa[n * 2 * D + (o - D * 2 * C)];
+                    _Pragma("unroll 4") for (int n = 0; n < nh; ++n) acc += fa[n * 2 * D + (o - D * 2 * C)];
                 }
                 a1[u] += acc;
             }
@@ -779,6 +782,7 @@ __global__ __launch_bounds__(kBlock) void k_event_bwd(
         for (int i = tid; i < nh * D; i += NT) {             // q and gr
             const int n = i / D, d = i % D;
             float acc = b3[d];
+#pragma unroll
             for (int k = 0; k < 3 * C; ++k) acc = fmaf(W3[d * 3 * C + k], Mr[n * 3 * LDH + (k / C) * LDH + k % C], acc);
             qb[i] = tanh_f(acc);
             const float hn = Hc[n * LDH + d];
@@ -810,9 +814,9 @@ __global__ __launch_bounds__(kBlock) void k_event_bwd(
                 if (o < D * 3 * C) {
                     const int d = o / (3 * C), k = o % (3 * C);
                     const float *f = fa + D + d, *m = Mr + (k / C) * LDH + k % C;
-                    for (int n = 0; n < nh; ++n) acc = fmaf(f[n * 2 * D], m[n * 3 * LDH], acc);
+                    _Pragma("unroll 4") for (int n = 0; n < nh; ++n) acc = fmaf(f[n * 2 * D], m[n * 3 * LDH], acc);
                 } else {
-                    for (int n = 0; n < nh; ++n) acc += fa[n * 2 * D + D + (o - D * 3 * C)];
+                    _Pragma("unroll 4") for (int n = 0; n < nh; ++n) acc += fa[n * 2 * D + D + (o - D * 3 * C)];
                 }
                 a3[u] += acc;
             }
@@ -824,9 +828,9 @@ __global__ __launch_bounds__(kBlock) void k_event_bwd(
                 float acc = 0.0f;
                 if (o < D * D) {
                     const int d = o / D, k = o % D;
-                    for (int n = 0; n < nh; ++n) acc = fmaf(fa[n * 2 * D + d], qb[n * D + k], acc);
+                    _Pragma("unroll 4") for (int n = 0; n < nh; ++n) acc = fmaf(fa[n * 2 * D + d], qb[n * D + k], acc);
                 } else {
-                    for (int n = 0; n < nh; ++n) acc += fa[n * 2 * D + (o - D * D)];
+                    _Pragma("unroll 4") for (int n = 0; n < nh; ++n) acc += fa[n * 2 * D + (o - D * D)];
                 }
                 a4[u] += acc;
             }
@@ -857,9 +861,9 @@ __global__ __launch_bounds__(kBlock) void k_event_bwd(
             float acc = 0.0f;
             if (o < D * F) {
                 const int d = o / F, k = o % F;
-                for (int n = 0; n < nh; ++n) acc = fmaf(fa[n * 2 * D + d], Hc[n * LDH + D + k], acc);
+                _Pragma("unroll 4") for (int n = 0; n < nh; ++n) acc = fmaf(fa[n * 2 * D + d], Hc[n * LDH + D + k], acc);
             } else {
-                for (int n = 0; n < nh; ++n) acc += fa[n * 2 * D + (o - D * F)];
+                _Pragma("unroll 4") for (int n = 0; n < nh; ++n) acc += fa[n * 2 * D + (o - D * F)];
             }
             ain[u] += acc;
         }
