@@ -655,7 +655,8 @@ __global__ __launch_bounds__(kBlock) void k_event_bwd(
         dl[j] = sg < 0 ? -1 : g.dst[s0 + j] - h0;
     }
     for (int i = tid; i < nh * LDH; i += NT) {
-        gH[i] = 0.0f;
+        gH[i] = gHp[i] = 0.0f;                  // (padding columns stay zero: nothing writes them)
+        gmio[2 * i] = gmio[2 * i + 1] = 0.0f;
         Hc[i] = H_all[((int64_t)T * N + h0) * LDH + i];
     }
     for (int j = tid; j < ns; j += NT) ec[j] = e_all[(int64_t)T * E + s0 + j];
@@ -715,24 +716,26 @@ __global__ __launch_bounds__(kBlock) void k_event_bwd(
             gu[j] = guv;
         }
         __syncthreads();
-        // k_pq_bwd: gP = sum_out gz, gQ = sum_in gz, one (hit, unit, P|Q) per thread -> fa = [gP | gQ]
-        for (int i = tid; i < nh * 2 * D; i += NT) {
-            const int n = i / (2 * D), r = i % (2 * D), ii = r % D;
-            float acc = 0.0f;
-            if (r < D) {
-                const float own = PQ[n * 2 * D + ii];
-                for (int k = op[n]; k < op[n + 1]; ++k) {
-                    const float a = tanh_f(own + PQ[onb[k] * 2 * D + D + ii]);
-                    acc += gu[oe[k]] * W2[ii] * (1.0f - a * a);
-                }
-            } else {
-                const float own = PQ[n * 2 * D + D + ii];
-                for (int k = ip[n]; k < ip[n + 1]; ++k) {
-                    const float a = tanh_f(PQ[inb[k] * 2 * D + ii] + own);
-                    acc += gu[ie[k]] * W2[ii] * (1.0f - a * a);
-                }
+        // k_pq_bwd: gP = sum_out gz, gQ = sum_in gz, one (hit, P|Q, 4 hidden units) per thread
+        // -> fa = [gP | gQ]
+        for (int i = tid; i < nh * 2 * (D / 4); i += NT) {
+            const int n = i / (2 * (D / 4)), part = (i / (D / 4)) & 1, v = i % (D / 4);
+            const float4 own = *reinterpret_cast<const float4 *>(PQ + n * 2 * D + part * D + 4 * v);
+            const float4 w2 = *reinterpret_cast<const float4 *>(W2 + 4 * v);
+            const int32_t *el = part ? ie : oe, *nl = part ? inb : onb;
+            float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            for (int k = part ? ip[n] : op[n], k1 = part ? ip[n + 1] : op[n + 1]; k < k1; ++k) {
+                const float gk = gu[el[k]];
+                // out-walk: P[n] + Q[end hit];  in-walk: P[start hit] + Q[n]
+                const float4 o = *reinterpret_cast<const float4 *>(PQ + nl[k] * 2 * D + (part ? 0 : D) + 4 * v);
+                const float ax = tanh_f(own.x + o.x), ay = tanh_f(own.y + o.y), az = tanh_f(own.z + o.z),
+                            aw = tanh_f(own.w + o.w);
+                acc.x += gk * w2.x * (1.0f - ax * ax);
+                acc.y += gk * w2.y * (1.0f - ay * ay);
+                acc.z += gk * w2.z * (1.0f - az * az);
+                acc.w += gk * w2.w * (1.0f - aw * aw);
             }
-            fa[n * 2 * D + r] = acc;
+            *reinterpret_cast<float4 *>(fa + n * 2 * D + part * D + 4 * v) = acc;
         }
         __syncthreads();
         for (int i = tid; i < nh * C; i += NT) {            // gH += W1a^T gP + W1b^T gQ
@@ -766,17 +769,24 @@ __global__ __launch_bounds__(kBlock) void k_event_bwd(
         for (int i = tid; i < nh * LDH; i += NT) Hp[i] = H_all[((int64_t)(t - 1) * N + h0) * LDH + i];
         for (int j = tid; j < ns; j += NT) ec[j] = e_all[(int64_t)(t - 1) * E + s0 + j];
         __syncthreads();
-        for (int i = tid; i < nh * 3 * LDH; i += NT) {       // M = [mi | mo | h], rows padded to LDH
-            const int n = i / (3 * LDH), part = (i / LDH) % 3, c = i % LDH;
-            float acc = 0.0f;
-            if (part == 0) {
-                for (int k = ip[n]; k < ip[n + 1]; ++k) acc = fmaf(ec[ie[k]], Hp[inb[k] * LDH + c], acc);
-            } else if (part == 1) {
-                for (int k = op[n]; k < op[n + 1]; ++k) acc = fmaf(ec[oe[k]], Hp[onb[k] * LDH + c], acc);
+        // M = [mi | mo | h], rows padded to LDH: one (hit, part, 4-float piece) per thread
+        for (int i = tid; i < nh * 3 * (LDH / 4); i += NT) {
+            const int n = i / (3 * (LDH / 4)), part = (i / (LDH / 4)) % 3, c = i % (LDH / 4);
+            float4 m = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (part == 2) {
+                m = *reinterpret_cast<const float4 *>(Hp + n * LDH + 4 * c);
             } else {
-                acc = Hp[n * LDH + c];
+                const int32_t *el = part ? oe : ie, *nl = part ? onb : inb;
+                for (int k = part ? op[n] : ip[n], k1 = part ? op[n + 1] : ip[n + 1]; k < k1; ++k) {
+                    const float w = ec[el[k]];
+                    const float4 a = *reinterpret_cast<const float4 *>(Hp + nl[k] * LDH + 4 * c);
+                    m.x = fmaf(w, a.x, m.x);
+                    m.y = fmaf(w, a.y, m.y);
+                    m.z = fmaf(w, a.z, m.z);
+                    m.w = fmaf(w, a.w, m.w);
+                }
             }
-            Mr[i] = acc;
+            *reinterpret_cast<float4 *>(Mr + n * 3 * LDH + part * LDH + 4 * c) = m;
         }
         __syncthreads();
         for (int i = tid; i < nh * D; i += NT) {             // q and gr
@@ -836,12 +846,24 @@ __global__ __launch_bounds__(kBlock) void k_event_bwd(
             }
         }
         __syncthreads();
-        for (int i = tid; i < nh * C; i += NT) {             // k_agg_bwd_n
-            const int n = i / C, c = i % C;
-            float acc = 0.0f;
-            for (int k = op[n]; k < op[n + 1]; ++k) acc = fmaf(ec[oe[k]], gmio[onb[k] * 2 * LDH + c], acc);
-            for (int k = ip[n]; k < ip[n + 1]; ++k) acc = fmaf(ec[ie[k]], gmio[inb[k] * 2 * LDH + LDH + c], acc);
-            gHp[n * LDH + c] += acc;
+        for (int i = tid; i < nh * (LDH / 4); i += NT) {     // k_agg_bwd_n, 4 columns per thread
+            const int n = i / (LDH / 4), c = i % (LDH / 4);
+            float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            for (int k = op[n]; k < op[n + 1]; ++k) {
+                const float w = ec[oe[k]];
+                const float4 a = *reinterpret_cast<const float4 *>(gmio + onb[k] * 2 * LDH + 4 * c);
+                acc.x = fmaf(w, a.x, acc.x); acc.y = fmaf(w, a.y, acc.y);
+                acc.z = fmaf(w, a.z, acc.z); acc.w = fmaf(w, a.w, acc.w);
+            }
+            for (int k = ip[n]; k < ip[n + 1]; ++k) {
+                const float w = ec[ie[k]];
+                const float4 a = *reinterpret_cast<const float4 *>(gmio + inb[k] * 2 * LDH + LDH + 4 * c);
+                acc.x = fmaf(w, a.x, acc.x); acc.y = fmaf(w, a.y, acc.y);
+                acc.z = fmaf(w, a.z, acc.z); acc.w = fmaf(w, a.w, acc.w);
+            }
+            float4 *dst = reinterpret_cast<float4 *>(gHp + n * LDH + 4 * c);
+            const float4 old = *dst;
+            *dst = make_float4(old.x + acc.x, old.y + acc.y, old.z + acc.z, old.w + acc.w);
         }
         __syncthreads();
         float *tmp = gH; gH = gHp; gHp = tmp;
