@@ -598,6 +598,61 @@ struct EvBwd {
     static constexpr int n1 = D * 2 * C + D, n3 = D * 3 * C + D, n4 = D * D + D, nin = D * F + D;
 };
 
+// Weight gradients inside k_event_bwd: sum over the graph's hits of L (x) R, R taken in 4-float
+// pieces.  Role r of a thread (r = tid + u * 256): r < NL * NR4 -> the 4 products of L row r / NR4
+// with piece r % NR4 of R; the next NB roles -> the plain sums of L rows 0 .. NB-1 (the bias).
+template <int NL, int NR4, int NB>
+struct Outer4 {
+    static constexpr int roles = NL * NR4 + NB, NA = (roles + kBlock - 1) / kBlock;
+    float4 acc[NA];
+    __device__ __forceinline__ void clear()
+    {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) acc[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    __device__ __forceinline__ void add(int nh, const float *L, int ls, const float *R, int rs)
+    {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int r = threadIdx.x + u * kBlock;
+            if (r < NL * NR4) {
+                const float *l = L + r / NR4, *rr = R + 4 * (r % NR4);
+                float4 a = acc[u];
+                for (int n = 0; n < nh; ++n) {
+                    const float lv = l[n * ls];
+                    const float4 rv = *reinterpret_cast<const float4 *>(rr + n * rs);
+                    a.x = fmaf(lv, rv.x, a.x); a.y = fmaf(lv, rv.y, a.y);
+                    a.z = fmaf(lv, rv.z, a.z); a.w = fmaf(lv, rv.w, a.w);
+                }
+                acc[u] = a;
+            } else if (r < roles) {
+                float a = acc[u].x;
+                for (int n = 0; n < nh; ++n) a += L[n * ls + (r - NL * NR4)];
+                acc[u].x = a;
+            }
+        }
+    }
+    // index(l, kk) -> element of the gradient replica for L row l and R column kk, or -1 (padding)
+    template <typename Index>
+    __device__ __forceinline__ void flush(float *rep, Index index, int bias0) const
+    {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int r = threadIdx.x + u * kBlock;
+            if (r < NL * NR4) {
+                const float v[4] = {acc[u].x, acc[u].y, acc[u].z, acc[u].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int o = index(r / NR4, 4 * (r % NR4) + j);
+                    if (o >= 0) atomicAdd(rep + o, v[j]);
+                }
+            } else if (r < roles) {
+                atomicAdd(rep + bias0 + (r - NL * NR4), acc[u].x);
+            }
+        }
+    }
+};
+
 template <int F, int D>
 __global__ __launch_bounds__(kBlock) void k_event_bwd(
     gnn_graph_t g, gnn_params_t p, const int32_t *__restrict__ hit_ptr,
@@ -661,17 +716,15 @@ __global__ __launch_bounds__(kBlock) void k_event_bwd(
     }
     for (int j = tid; j < ns; j += NT) ec[j] = e_all[(int64_t)T * E + s0 + j];
 
-    // this thread's elements of the gradient tensors (summed over the graph's items and over t)
-    float a1[(B::n1 + NT - 1) / NT], a3[(B::n3 + NT - 1) / NT], a4[(B::n4 + NT - 1) / NT],
-        ain[(B::nin + NT - 1) / NT];
-#pragma unroll
-    for (int u = 0; u < (B::n1 + NT - 1) / NT; ++u) a1[u] = 0.0f;
-#pragma unroll
-    for (int u = 0; u < (B::n3 + NT - 1) / NT; ++u) a3[u] = 0.0f;
-#pragma unroll
-    for (int u = 0; u < (B::n4 + NT - 1) / NT; ++u) a4[u] = 0.0f;
-#pragma unroll
-    for (int u = 0; u < (B::nin + NT - 1) / NT; ++u) ain[u] = 0.0f;
+    // this thread's elements of the gradient tensors (summed over the graph's hits and over t)
+    Outer4<2 * D, LDH / 4, D> g1;               // [gP | gQ] (x) H_t      -> gW1, gb1
+    Outer4<D, 3 * LDH / 4, D> g3;               // gp (x) [mi | mo | h]   -> gW3, gb3
+    Outer4<D, D / 4, D> g4;                     // gr (x) q               -> gW4, gb4
+    Outer4<D, (LDH - D) / 4, D> gin;            // g (x) x                -> gWin, gbin
+    g1.clear();
+    g3.clear();
+    g4.clear();
+    gin.clear();
     float sW2[D], sb2 = 0.0f, spad = 0.0f;      // per-segment sums (k_edge_bwd)
 #pragma unroll
     for (int i = 0; i < D; ++i) sW2[i] = 0.0f;
@@ -748,21 +801,7 @@ __global__ __launch_bounds__(kBlock) void k_event_bwd(
             }
             gH[n * LDH + k] += acc;
         }
-#pragma unroll
-        for (int u = 0; u < (B::n1 + NT - 1) / NT; ++u) {    // gW1, gb1
-            const int o = tid + u * NT;
-            if (o < B::n1) {
-                float acc = 0.0f;
-                if (o < D * 2 * C) {
-                    const int d = o / (2 * C), k = o % (2 * C);
-                    const float *f = fa + (k < C ? d : D + d), *h = Hc + (k < C ? k : k - C);
-                    _Pragma("unroll 4") for (int n = 0; n < nh; ++n) acc = fmaf(f[n * 2 * D], h[n * LDH], acc);
-                } else {
-                    _Pragma("unroll 4") for (int n = 0; n < nh; ++n) acc += fa[n * 2 * D + (o - D * 2 * C)];
-                }
-                a1[u] += acc;
-            }
-        }
+        g1.add(nh, fa, 2 * D, Hc, LDH);                        // gW1, gb1
         __syncthreads();
         if (t == 0) break;
         // node pass t-1 -> t (k_node_bwd): H_{t-1}, e_{t-1} in; Hc = H_t holds the pass's outputs
@@ -816,35 +855,8 @@ __global__ __launch_bounds__(kBlock) void k_event_bwd(
             else if (k < 2 * C) gmio[n * 2 * LDH + LDH + (k - C)] = acc;
             else gHp[n * LDH + (k - 2 * C)] = acc;
         }
-#pragma unroll
-        for (int u = 0; u < (B::n3 + NT - 1) / NT; ++u) {    // gW3, gb3
-            const int o = tid + u * NT;
-            if (o < B::n3) {
-                float acc = 0.0f;
-                if (o < D * 3 * C) {
-                    const int d = o / (3 * C), k = o % (3 * C);
-                    const float *f = fa + D + d, *m = Mr + (k / C) * LDH + k % C;
-                    _Pragma("unroll 4") for (int n = 0; n < nh; ++n) acc = fmaf(f[n * 2 * D], m[n * 3 * LDH], acc);
-                } else {
-                    _Pragma("unroll 4") for (int n = 0; n < nh; ++n) acc += fa[n * 2 * D + D + (o - D * 3 * C)];
-                }
-                a3[u] += acc;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < (B::n4 + NT - 1) / NT; ++u) {    // gW4, gb4
-            const int o = tid + u * NT;
-            if (o < B::n4) {
-                float acc = 0.0f;
-                if (o < D * D) {
-                    const int d = o / D, k = o % D;
-                    _Pragma("unroll 4") for (int n = 0; n < nh; ++n) acc = fmaf(fa[n * 2 * D + d], qb[n * D + k], acc);
-                } else {
-                    _Pragma("unroll 4") for (int n = 0; n < nh; ++n) acc += fa[n * 2 * D + (o - D * D)];
-                }
-                a4[u] += acc;
-            }
-        }
+        g3.add(nh, fa + D, 2 * D, Mr, 3 * LDH);                // gW3, gb3
+        g4.add(nh, fa, 2 * D, qb, D);                          // gW4, gb4
         __syncthreads();
         for (int i = tid; i < nh * (LDH / 4); i += NT) {     // k_agg_bwd_n, 4 columns per thread
             const int n = i / (LDH / 4), c = i % (LDH / 4);
@@ -876,41 +888,13 @@ __global__ __launch_bounds__(kBlock) void k_event_bwd(
         fa[n * 2 * D + d] = gH[n * LDH + d] * (1.0f - h * h);
     }
     __syncthreads();
-#pragma unroll
-    for (int u = 0; u < (B::nin + NT - 1) / NT; ++u) {
-        const int o = tid + u * NT;
-        if (o < B::nin) {
-            float acc = 0.0f;
-            if (o < D * F) {
-                const int d = o / F, k = o % F;
-                _Pragma("unroll 4") for (int n = 0; n < nh; ++n) acc = fmaf(fa[n * 2 * D + d], Hc[n * LDH + D + k], acc);
-            } else {
-                _Pragma("unroll 4") for (int n = 0; n < nh; ++n) acc += fa[n * 2 * D + (o - D * F)];
-            }
-            ain[u] += acc;
-        }
-    }
-    // flush: one atomic per gradient element per graph
-#pragma unroll
-    for (int u = 0; u < (B::n1 + NT - 1) / NT; ++u) {
-        const int o = tid + u * NT;
-        if (o < B::n1) atomicAdd(rep + (o < D * 2 * C ? GL::oW1 + o : GL::ob1 + (o - D * 2 * C)), a1[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < (B::n3 + NT - 1) / NT; ++u) {
-        const int o = tid + u * NT;
-        if (o < B::n3) atomicAdd(rep + (o < D * 3 * C ? GL::oW3 + o : GL::ob3 + (o - D * 3 * C)), a3[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < (B::n4 + NT - 1) / NT; ++u) {
-        const int o = tid + u * NT;
-        if (o < B::n4) atomicAdd(rep + (o < D * D ? GL::oW4 + o : GL::ob4 + (o - D * D)), a4[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < (B::nin + NT - 1) / NT; ++u) {
-        const int o = tid + u * NT;
-        if (o < B::nin) atomicAdd(rep + (o < D * F ? GL::oWin + o : GL::obin + (o - D * F)), ain[u]);
-    }
+    gin.add(nh, fa, 2 * D, Hc + D, LDH);
+    // flush: one atomic per gradient element per graph (padding columns of the 4-float pieces skipped)
+    g1.flush(rep, [](int l, int kk) { return kk < C ? GL::oW1 + (l % D) * 2 * C + (l / D) * C + kk : -1; }, GL::ob1);
+    g3.flush(rep, [](int l, int kk) { return kk % LDH < C ? GL::oW3 + l * 3 * C + (kk / LDH) * C + kk % LDH : -1; },
+             GL::ob3);
+    g4.flush(rep, [](int l, int kk) { return GL::oW4 + l * D + kk; }, GL::ob4);
+    gin.flush(rep, [](int l, int kk) { return kk < F ? GL::oWin + l * F + kk : -1; }, GL::obin);
     {
         constexpr int NS = D + 2, NW = NT / 64;
         __shared__ float red[NW * NS];
