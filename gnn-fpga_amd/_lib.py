@@ -5,6 +5,7 @@ fallback.  If the library is missing or a tensor is not on a ROCm device the cal
 raises.  torch is used for device memory and the stream handle only.
 """
 import ctypes
+import functools
 import os
 
 import torch  # imported first: its bundled libamdhip64.so.7 is the one HIP runtime of the process
@@ -258,6 +259,7 @@ def segclf_forward(batch, weights, F, D, n_iters, out=None, workspace=None, trac
     return (out, et, Ht) if trace else out
 
 
+@functools.lru_cache(maxsize=None)
 def events_supported(F, D, max_hits, max_segments):
     """True if graphs of at most that size fit the one-workgroup-per-graph kernel."""
     return bool(load().gnn_events_supported(F, D, max_hits, max_segments))
@@ -328,6 +330,7 @@ def segclf_backward(batch, weights, F, D, n_iters, e_all, H_all, grad_out):
     return grads
 
 
+@functools.lru_cache(maxsize=None)
 def events_backward_supported(F, D, max_hits, max_segments):
     """True if graphs of at most that size fit the one-launch backward (one workgroup per graph)."""
     return bool(load().gnn_events_backward_supported(F, D, max_hits, max_segments))
