@@ -586,9 +586,10 @@ int backward_t(const gnn_graph_t *g, const gnn_params_t *p, int T, const float *
 template <int F, int D>
 struct EvBwd {
     static constexpr int C = F + D, LDH = (C + 3) & ~3;
-    // weights in LDS: W1, b1, W2, W3, b3, W4 (16-byte aligned pieces)
-    static constexpr int oW1 = 0, ob1 = oW1 + D * 2 * C, oW2 = ob1 + D, oW3 = oW2 + D,
-                         ob3 = oW3 + ((D * 3 * C + 3) & ~3), oW4 = ob3 + D, w_total = oW4 + D * D;
+    // weights in LDS: W1, b1, W2, W3, b3, W4; the rows of W1 / W3 are laid out like the feature rows
+    // they multiply (blocks of C columns padded to LDH, zeros) so that products run on 4-float pieces
+    static constexpr int oW1 = 0, ob1 = oW1 + D * 2 * LDH, oW2 = ob1 + D, oW3 = oW2 + D,
+                         ob3 = oW3 + D * 3 * LDH, oW4 = ob3 + D, w_total = oW4 + D * D;
     static constexpr int per_hit = 9 * LDH + 5 * D;     // Hc Hp gH gHp (4) + gmio (2) + M (3) | PQ fa (2D each) qb
     static size_t lds_bytes(int64_t cap_h, int64_t cap_s)
     {
@@ -678,8 +679,14 @@ __global__ __launch_bounds__(kBlock) void k_event_bwd(
     const int64_t N = g.n_hits, E = g.n_segments;
     rep = my_replica(rep, GL::stride);
 
-    for (int i = tid; i < D * 2 * C; i += NT) wl[B::oW1 + i] = p.W1[i];
-    for (int i = tid; i < D * 3 * C; i += NT) wl[B::oW3 + i] = p.W3[i];
+    for (int i = tid; i < D * 2 * LDH; i += NT) {
+        const int d = i / (2 * LDH), blk = (i / LDH) % 2, k = i % LDH;
+        wl[B::oW1 + i] = k < C ? p.W1[d * 2 * C + blk * C + k] : 0.0f;
+    }
+    for (int i = tid; i < D * 3 * LDH; i += NT) {
+        const int d = i / (3 * LDH), blk = (i / LDH) % 3, k = i % LDH;
+        wl[B::oW3 + i] = k < C ? p.W3[d * 3 * C + blk * C + k] : 0.0f;
+    }
     for (int i = tid; i < D * D; i += NT) wl[B::oW4 + i] = p.W4[i];
     for (int i = tid; i < D; i += NT) {
         wl[B::ob1 + i] = p.b1[i];
@@ -736,9 +743,14 @@ __global__ __launch_bounds__(kBlock) void k_event_bwd(
             const int n = i / (2 * D), r = i % (2 * D), d = r % D;
             const bool isq = r >= D;
             float acc = isq ? 0.0f : b1[d];
-            const float *w = W1 + d * 2 * C + (isq ? C : 0);
+            const float4 *w = reinterpret_cast<const float4 *>(W1 + d * 2 * LDH + (isq ? LDH : 0));
+            const float4 *h = reinterpret_cast<const float4 *>(Hc + n * LDH);
 #pragma unroll
-            for (int k = 0; k < C; ++k) acc = fmaf(w[k], Hc[n * LDH + k], acc);
+            for (int c = 0; c < LDH / 4; ++c) {      // (padding columns add 0 * 0: the sums are unchanged)
+                const float4 a = w[c], b = h[c];
+                acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc);
+                acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+            }
             PQ[n * 2 * D + r] = acc;
         }
         __syncthreads();
@@ -796,8 +808,8 @@ __global__ __launch_bounds__(kBlock) void k_event_bwd(
             float acc = 0.0f;
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                acc = fmaf(W1[d * 2 * C + k], fa[n * 2 * D + d], acc);
-                acc = fmaf(W1[d * 2 * C + C + k], fa[n * 2 * D + D + d], acc);
+                acc = fmaf(W1[d * 2 * LDH + k], fa[n * 2 * D + d], acc);
+                acc = fmaf(W1[d * 2 * LDH + LDH + k], fa[n * 2 * D + D + d], acc);
             }
             gH[n * LDH + k] += acc;
         }
@@ -831,8 +843,14 @@ __global__ __launch_bounds__(kBlock) void k_event_bwd(
         for (int i = tid; i < nh * D; i += NT) {             // q and gr
             const int n = i / D, d = i % D;
             float acc = b3[d];
+            const float4 *w = reinterpret_cast<const float4 *>(W3 + d * 3 * LDH);
+            const float4 *mrow = reinterpret_cast<const float4 *>(Mr + n * 3 * LDH);
 #pragma unroll
-            for (int k = 0; k < 3 * C; ++k) acc = fmaf(W3[d * 3 * C + k], Mr[n * 3 * LDH + (k / C) * LDH + k % C], acc);
+            for (int c = 0; c < 3 * LDH / 4; ++c) {
+                const float4 a = w[c], b = mrow[c];
+                acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc);
+                acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+            }
             qb[i] = tanh_f(acc);
             const float hn = Hc[n * LDH + d];
             fa[n * 2 * D + d] = gH[n * LDH + d] * (1.0f - hn * hn);
@@ -850,7 +868,7 @@ __global__ __launch_bounds__(kBlock) void k_event_bwd(
             const int n = i / (3 * C), k = i % (3 * C);
             float acc = 0.0f;
 #pragma unroll
-            for (int d = 0; d < D; ++d) acc = fmaf(W3[d * 3 * C + k], fa[n * 2 * D + D + d], acc);
+            for (int d = 0; d < D; ++d) acc = fmaf(W3[d * 3 * LDH + (k / C) * LDH + k % C], fa[n * 2 * D + D + d], acc);
             if (k < C) gmio[n * 2 * LDH + k] = acc;
             else if (k < 2 * C) gmio[n * 2 * LDH + LDH + (k - C)] = acc;
             else gHp[n * LDH + (k - 2 * C)] = acc;
