@@ -14,6 +14,7 @@ import torch.distributed as dist
 from gnn_fpga_amd import HitGraphBatch, synth, shard
 from gnn_fpga_amd.model import SegmentClassifier
 
+FUSED = os.environ.get("GNN_FUSED_ADAM", "1") == "1"      # one optimizer kernel instead of ~15
 rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 local = int(os.environ.get("LOCAL_RANK", 0))
 torch.cuda.set_device(local)
@@ -28,7 +29,7 @@ def run(n_global, steps=100, warmup=10):
     y = batch.y.to(dev)
     torch.manual_seed(0)
     m = SegmentClassifier(input_dim=11, hidden_dim=8, n_iters=3).to(dev).train()
-    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, fused=FUSED)
     bce = torch.nn.BCELoss(reduction="sum")
 
     bucket = shard.GradBucket(m.parameters())          # grads are views of one flat buffer
@@ -62,7 +63,7 @@ def run(n_global, steps=100, warmup=10):
     if world == 1:
         # the whole step (HIP forward, BCE, HIP backward, bucket, Adam) as ONE captured HIP graph:
         # the library launches on the capturing stream and allocates nothing itself
-        opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True)   # step() picks it up
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True, fused=FUSED)   # step() picks it up
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
