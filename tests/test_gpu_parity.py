@@ -651,6 +651,9 @@ def test_one_launch_backward_for_small_events(hip, F, D, T):
     torch.manual_seed(F + D + T)
     if F == 11:
         graphs = [synth.muon_graph(s) for s in range(40)]
+    elif T == 2:        # close to what one workgroup's LDS holds (111 of 128 KB)
+        graphs = [synth.layered_graph(150, 600, F, n_layers=6, seed=520 + i) for i in range(6)]
+        graphs.append(synth.layered_graph(7, 9, F, n_layers=3, seed=9))
     else:
         graphs = [synth.layered_graph(n, e, F, n_layers=L, seed=500 + i)
                   for i, (n, e, L) in enumerate([(60, 200, 6), (3, 2, 2), (40, 0, 4), (25, 90, 5), (2, 1, 2)])]
