@@ -1519,7 +1519,11 @@ template <int F, int D>
 struct MT {
     static_assert(D == 8, "fp32 matrix-core tables are laid out for D = 8");
     static constexpr int C = F + D;
-    static constexpr int NS = F <= 8 ? 4 : 5;          // k-steps of a record product
+    // F <= 4: the 8 hidden features + F inputs fit 3 k-steps of 4 slots if the last feature of each
+    // half (3 and 7) moves to lane group 2 (one ds_bpermute each) - 3 products per record table
+    // instead of 4
+    static constexpr bool PACK = F <= 4;
+    static constexpr int NS = PACK ? 3 : F <= 8 ? 4 : 5;   // k-steps of a record product
     static constexpr int o_h0 = 0;                     // [64]       input network, 1 step (FIRST)
     static constexpr int o_t = 64;                     // 3 x [NS][64]: PR, QS, U  (LAST: P|Q, -, -)
     static constexpr int t_sz = NS * 64;
@@ -1529,6 +1533,12 @@ struct MT {
     // input index k in [0, C) of slot (s, g), or -1
     static constexpr int slot_k(int s, int g)
     {
+        if (PACK) {
+            if (g == 0) return s;
+            if (g == 1) return 4 + s;
+            if (g == 2) return s == 0 ? 3 : s == 1 ? 7 : (0 < F ? D : -1);
+            return 1 + s < F ? D + 1 + s : -1;
+        }
         if (s < 4) {
             if (g == 0) return s;
             if (g == 1) return 4 + s;
@@ -1538,6 +1548,13 @@ struct MT {
         return 8 + g < F ? D + 8 + g : -1;
     }
 };
+
+template <int F, int D>
+constexpr int mt_total()
+{
+    if constexpr (D == 8) return MT<F, D>::total;
+    else return 0;
+}
 
 // one entry of the tables above from the raw weights; `last`: T0 holds [P(8) | Q(8)]
 template <int F, int D>
@@ -1727,9 +1744,10 @@ __global__ __launch_bounds__(1024) void k_iter2(
             const float *mb = mt + MTL::o_b;
             const int hit = lane & 15, g = lane >> 4;
             const float a0 = mt[MTL::o_h0 + lane];
-            float ar[4];
+            static_assert(MTL::PACK, "the fused first launch exists for F <= 3 only");
+            float ar[MTL::NS];
 #pragma unroll
-            for (int st = 0; st < 4; ++st) ar[st] = mt[MTL::o_t + MTL::t_sz * M + 64 * st + lane];
+            for (int st = 0; st < MTL::NS; ++st) ar[st] = mt[MTL::o_t + MTL::t_sz * M + 64 * st + lane];
             const f4v bias0 = *reinterpret_cast<const f4v *>(mb + 4 * g);
             const f4v biasr = *reinterpret_cast<const f4v *>(mb + 16 + 16 * M + 4 * g);
             for (int h0i = wv * 16; h0i < cnt; h0i += NWV * 16) {
@@ -1743,10 +1761,15 @@ __global__ __launch_bounds__(1024) void k_iter2(
                 for (int k = 0; k < F; ++k) b0 = (g == k) ? xs[k] : b0;
                 f4v hq = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, bias0, 0, 0, 0);
                 const float hh[4] = {tanh_f(hq.x), tanh_f(hq.y), tanh_f(hq.z), tanh_f(hq.w)};
+                // features 3 and 7 (held by lane groups 0 and 1) for lane group 2, see MT::slot_k
+                const float h3a = __int_as_float(__builtin_amdgcn_ds_bpermute(hit << 2, __float_as_int(hh[3])));
+                const float h3b = __int_as_float(__builtin_amdgcn_ds_bpermute((16 + hit) << 2, __float_as_int(hh[3])));
                 f4v c = biasr;
 #pragma unroll
-                for (int st = 0; st < 4; ++st) {
-                    const float b = g < 2 ? hh[st] : (g == 2 && st < F) ? xs[st < F ? st : 0] : 0.0f;
+                for (int st = 0; st < MTL::NS; ++st) {
+                    float b = hh[st];
+                    if (g == 2) b = st == 0 ? h3a : st == 1 ? h3b : xs[0];
+                    if (g == 3) b = 1 + st < F ? xs[1 + st < F ? 1 + st : 0] : 0.0f;
                     c = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[st], b, c, 0, 0, 0);
                 }
                 if constexpr (XP) {                    // positions 4g, 4g+1 are P (Q) entries
@@ -2024,7 +2047,20 @@ __global__ __launch_bounds__(1024) void k_iter2(
                     h = __builtin_amdgcn_mfma_f32_16x16x4f32(mt[MTL::o_w4 + 64 + lane], q1, h, 0, 0, 0);
                     const float hh[4] = {tanh_f(h.x), tanh_f(h.y), tanh_f(h.z), tanh_f(h.w)};
                     // this lane's input of step s of the record products (MT::slot_k)
+                    float h3a = 0.0f, h3b = 0.0f;       // PACK: features 3 and 7 for lane group 2
+                    if constexpr (MTL::PACK) {
+                        h3a = __int_as_float(__builtin_amdgcn_ds_bpermute(hit << 2, __float_as_int(hh[3])));
+                        h3b = __int_as_float(__builtin_amdgcn_ds_bpermute((16 + hit) << 2, __float_as_int(hh[3])));
+                    }
                     auto slot_in = [&](int st) {
+                        if constexpr (MTL::PACK) {
+                            if (g < 2) return hh[st];
+                            if (g == 2) return st == 0 ? h3a : st == 1 ? h3b : (0 < F ? xm[0] : 0.0f);
+                            float v = 0.0f;
+#pragma unroll
+                            for (int k = 1; k < F; ++k) v = (k == 1 + st) ? xm[k] : v;
+                            return v;
+                        }
                         if (st < 4) {
                             if (g < 2) return hh[st];
                             float v = 0.0f;
@@ -2250,7 +2286,7 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
                    pl->in_nbr16 && pl->out_nbr16 && pl->in_off16 && pl->out_off16 && pl->sched_a && pl->sched_b;
             capA = (int)capa;
             capB = (int)capb;
-            constexpr int mt_floats = (D == 8) ? (64 + 3 * ((F <= 8 ? 4 : 5) * 64) + 128 + 80) : 0;   // MT<F, D>::total
+            constexpr int mt_floats = mt_total<F, D>();
             it2_lds = (size_t)(L::total + (capa + capb) * 2 * D + 4 + mt_floats) * sizeof(float);
             if (it2_lds > (size_t)G::lds_bytes) use2 = false;
             // first iteration fused with the input network: + one buffer of X rows (256-byte pieces)
