@@ -1737,7 +1737,7 @@ __global__ __launch_bounds__(1024) void k_iter2(
             // On the matrix cores, exact fp32 (v_mfma_f32_16x16x4_f32 is a k-ordered fmaf chain):
             // rows = the 16 floats of a record in LDS position order, columns = 16 window hits.
             // Lane l supplies input slot l >> 4 of hit l & 15 per k-step and receives positions
-            // 4 (l >> 4) .. + 3 of that hit's record - one 16-byte LDS store.  5 MFMAs per 16 hits
+            // 4 (l >> 4) .. + 3 of that hit's record - one 16-byte LDS store.  4 MFMAs per 16 hits
             // instead of ~100 vector instructions per lane.
             typedef float f4v __attribute__((ext_vector_type(4)));
             using MTL = MT<F, D>;
