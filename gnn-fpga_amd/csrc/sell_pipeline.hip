@@ -1625,7 +1625,7 @@ __global__ __launch_bounds__(1024) void k_iter2(
     constexpr int d4 = L::d4, NT = 1024, NWV = NT / 64, NC = 3;   // NC words = 24 list steps
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *lds = smem, *bufA = smem + L::total, *bufB = bufA + (int64_t)capA * 2 * D;
-    float *xbuf = bufB + (int64_t)capB * 2 * D;      // FIRST only: X rows of the next window
+    float *xbuf = bufB + (int64_t)capB * 2 * D;      // (end of the window buffers)
     const int tid = threadIdx.x, lane = tid & 63, q = lane & 3, i16 = lane >> 2;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     if constexpr (FIRST) {
@@ -1712,15 +1712,22 @@ __global__ __launch_bounds__(1024) void k_iter2(
     // records: H0 = [tanh(Win x + bin) | x] (model.py:144-146), then [P | R] (M = 0) or [Q | S]
     // (M = 1): at D = 8 as two small fp32 matrix-core products per 16 hits, else with the
     // role_gemv blocks k_input4 / emit_now use.
-    auto xstage_issue = [&](int lo, int cnt) {
+    // The X rows land in the TAIL of the window buffer they will be turned into (the buffer is idle
+    // while they arrive, exactly like the record windows of the later iterations): no buffer of
+    // their own.  compute_window turns them into records 256 hits at a time, in ascending order;
+    // a record is >= 15 bytes longer than an X row, so the records of one round never reach the X
+    // rows of a later round, and inside a round every wave reads its rows before anyone writes.
+    auto x_image = [&](float *buf, int cap) { return buf + cap * 2 * D - (cap * F + 63) / 64 * 64; };
+    auto xstage_issue = [&](int lo, int cnt, float *buf, int cap) {
         const int pieces = (cnt * F + 63) / 64;                        // 256-byte pieces
+        float *xb = x_image(buf, cap);
         unsigned lb = (unsigned)lane * 4u;
         asm volatile("" : "+v"(lb));
         for (int c = wv; c < pieces; c += NWV)
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void *)(
                     reinterpret_cast<const char *>(X + (int64_t)lo * F + c * 64) + lb),
-                (__attribute__((address_space(3))) void *)(xbuf + c * 64), 4, 0, 0);
+                (__attribute__((address_space(3))) void *)(xb + c * 64), 4, 0, 0);
     };
     auto h0_of = [&](const float *wl, const float *x, float *hn) {
         float hl[d4];
@@ -1729,8 +1736,16 @@ __global__ __launch_bounds__(1024) void k_iter2(
         for (int i = 0; i < d4; ++i) hl[i] = tanh_f(hl[i]);
         quad_allgather<d4>(hl, hn);
     };
-    auto compute_window = [&](float *buf, int cnt, auto which) {
+    auto compute_window = [&](float *buf, int cnt, int cap, auto which) {
         constexpr int M = decltype(which)::value;
+        static_assert(2 * D * 4 - F * 4 >= 16, "a record must be longer than an X row (see x_image)");
+        const float *xb = x_image(buf, cap);
+        const int rounds = (cnt + NT / 4 - 1) / (NT / 4);          // 256 hits per round
+        // rounds whose records end below the X image need no barrier between reading and writing
+        const int x_off = (int)(xb - buf);
+        auto round_fence = [&](int r) {
+            if ((r + 1) * (NT / 4) * 2 * D > x_off) __syncthreads();
+        };
         a_wait_all();                                  // this wave's DMA pieces have landed
         __syncthreads();                               // ... and everybody else's
         if constexpr (D == 8) {
@@ -1750,12 +1765,13 @@ __global__ __launch_bounds__(1024) void k_iter2(
             for (int st = 0; st < MTL::NS; ++st) ar[st] = mt[MTL::o_t + MTL::t_sz * M + 64 * st + lane];
             const f4v bias0 = *reinterpret_cast<const f4v *>(mb + 4 * g);
             const f4v biasr = *reinterpret_cast<const f4v *>(mb + 16 + 16 * M + 4 * g);
-            for (int h0i = wv * 16; h0i < cnt; h0i += NWV * 16) {
-                const int h = h0i + hit;
+            for (int r = 0; r < rounds; ++r) {
+                const int h = (r * NWV + wv) * 16 + hit;
                 const bool live = h < cnt;
                 float xs[F];
 #pragma unroll
-                for (int k = 0; k < F; ++k) xs[k] = live ? xbuf[h * F + k] : 0.0f;
+                for (int k = 0; k < F; ++k) xs[k] = live ? xb[h * F + k] : 0.0f;
+                round_fence(r);                        // all X rows of this round are in registers
                 float b0 = 0.0f;
 #pragma unroll
                 for (int k = 0; k < F; ++k) b0 = (g == k) ? xs[k] : b0;
@@ -1781,13 +1797,17 @@ __global__ __launch_bounds__(1024) void k_iter2(
             put_null(buf, cnt, which);
             return;
         }
-        for (int h = tid >> 2; h < cnt; h += NT / 4) {
+        for (int r = 0; r < rounds; ++r) {
+            const int h = r * (NT / 4) + (tid >> 2);
+            const bool live = h < cnt;
             int woff = q * L::stride;
             asm volatile("" : "+v"(woff));
             const float *wl = lds + woff;
             float x[F], hn[D], rec[2 * d4];
 #pragma unroll
-            for (int k = 0; k < F; ++k) x[k] = xbuf[h * F + k];
+            for (int k = 0; k < F; ++k) x[k] = live ? xb[h * F + k] : 0.0f;
+            round_fence(r);                            // all X rows of this round are in registers
+            if (!live) continue;
             h0_of(wl, x, hn);
             if constexpr (d4 == 2) {
                 role_gemv_burst<D, F>(wl + L::o_m + (2 * M) * L::m_st, hn, x, rec);
@@ -1895,9 +1915,9 @@ __global__ __launch_bounds__(1024) void k_iter2(
     PreA a_cur, a_nxt;
     PreB b_cur, b_nxt;
     if constexpr (FIRST) {
-        xstage_issue(d.in_lo, d.in_cnt);
+        xstage_issue(d.in_lo, d.in_cnt, bufA, capA);
         if (slice_a(d, 0) >= 0) prefetchA(a_cur, slice_a(d, 0));
-        compute_window(bufA, d.in_cnt, WinA{});   // barrier inside: table visible
+        compute_window(bufA, d.in_cnt, capA, WinA{});   // barrier inside: table visible
     } else {
         stage_issue(PR + (int64_t)d.in_lo * 2 * D, bufA, d.in_cnt);
         if (slice_a(d, 0) >= 0) prefetchA(a_cur, slice_a(d, 0));
@@ -1915,7 +1935,7 @@ __global__ __launch_bounds__(1024) void k_iter2(
         const int rounds = (d.s_end - d.s_begin + NWV - 1) / NWV;
         // ================= phase A: in-sweeps; QS window of this tile in flight ==================
         if constexpr (FIRST)
-            xstage_issue(d.out_lo, d.out_cnt);         // xbuf is free: last read before the barrier
+            xstage_issue(d.out_lo, d.out_cnt, bufB, capB);   // bufB is idle during phase A
         else
             stage_issue(QS + (int64_t)d.out_lo * 2 * D, bufB, d.out_cnt);
         // The last round is peeled (LR = true): it requests the first slice of phase B instead of
@@ -1964,7 +1984,7 @@ __global__ __launch_bounds__(1024) void k_iter2(
         for (int r = 0; r + 1 < rounds; ++r) roundA(r, std::false_type{});
         roundA(rounds - 1, std::true_type{});
         if constexpr (FIRST)
-            compute_window(bufB, d.out_cnt, WinB{});
+            compute_window(bufB, d.out_cnt, capB, WinB{});
         else
             stage_commit(bufB, d.out_cnt, WinB{});   // also makes b_cur readable (vmcnt 0)
         if (slice_a(d, 0) >= 0) arriveB(b_cur);
@@ -1975,7 +1995,7 @@ __global__ __launch_bounds__(1024) void k_iter2(
         if (tnext < n_tiles) {
             dn = load_desc(tnext);
             if constexpr (FIRST)
-                xstage_issue(dn.in_lo, dn.in_cnt);
+                xstage_issue(dn.in_lo, dn.in_cnt, bufA, capA);
             else
                 stage_issue(PR + (int64_t)dn.in_lo * 2 * D, bufA, dn.in_cnt);
         }
@@ -2133,7 +2153,7 @@ __global__ __launch_bounds__(1024) void k_iter2(
         roundB(rounds - 1, std::true_type{});
         if (tnext >= n_tiles) break;
         if constexpr (FIRST)
-            compute_window(bufA, dn.in_cnt, WinA{});
+            compute_window(bufA, dn.in_cnt, capA, WinA{});
         else
             stage_commit(bufA, dn.in_cnt, WinA{});   // also makes a_cur readable
         if (slice_a(dn, 0) >= 0) arriveA(a_cur);
@@ -2290,10 +2310,9 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
             it2_lds = (size_t)(L::total + (capa + capb) * 2 * D + 4 + mt_floats) * sizeof(float);
             if (it2_lds > (size_t)G::lds_bytes) use2 = false;
             // first iteration fused with the input network: + one buffer of X rows (256-byte pieces)
-            const int64_t xfl = ((capa > capb ? capa : capb) * F + 63) / 64 * 64;
-            xbuf_floats = (int)xfl;
+            xbuf_floats = 0;     // (the X rows of a window are staged inside the window buffer itself)
             // + the fp32 A fragments / biases of the matrix-core window products (D = 8)
-            it2_lds_first = it2_lds + (size_t)xfl * sizeof(float);
+            it2_lds_first = it2_lds;
             // (exp-product mode only: the plain-exp variant of the fused kernel does not fit the
             // register budget without spills, and it is the rarely taken fallback anyway)
             fuse_first = G::fuse_first && XP && use2 && n_iters >= 2 && it2_lds_first <= (size_t)G::lds_bytes &&
