@@ -59,3 +59,146 @@ def test_thousands_of_tiny_graphs(model):
         tiny.append(synth.HitGraph(X, rng.integers(0, n, e).astype(np.int32),
                                    rng.integers(0, n, e).astype(np.int32), np.zeros(e, np.float32)))
     _check(model, tiny, list(range(0, 20000, 997)))
+
+
+# ---- BASELINE configs[3] ("c4") and configs[4] ("c5") at their full sizes ------------------------
+def _muon_model(dev="cuda"):
+    from gnn_fpga_amd.model import SegmentClassifier
+    torch.manual_seed(11)
+    return SegmentClassifier(input_dim=11, hidden_dim=8, n_iters=3).to(dev)
+
+
+@pytest.mark.parametrize("share", ["all 512 graphs (1 GPU)", "64 graphs (rank 3 of 8)"])
+def test_c4_muon_batch_forward(share):
+    """BASELINE configs[3]: 512 muon-schema graphs (reference gnn/prepareMuonGraphs.py:232-263 sizes:
+    tens of hits, F = 11), as one batch and as the r::8 share one GPU of eight gets: the one-launch
+    small-event kernel (k_event) against the C oracle, EVERY graph, within north_star's 1e-5."""
+    from gnn_fpga_amd import _lib, shard
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    graphs = [synth.muon_graph(s) for s in range(512)]
+    if share.startswith("64"):
+        graphs = shard.shard_graphs(graphs, 3, 8)
+        assert len(graphs) == 64
+    m = _muon_model().eval()
+    params = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    b = HitGraphBatch.from_graphs(graphs).cuda()
+    calls, real = [], _lib.segclf_forward_events
+    _lib.segclf_forward_events = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            e = m(b)
+    finally:
+        _lib.segclf_forward_events = real
+    assert calls == [1]                                    # the small-event kernel ran
+    worst = 0.0
+    for g, eg in zip(graphs, b.split_scores(e.cpu().numpy())):
+        ref = index_c.segment_classifier(g.X, g.src, g.dst, params, 3)
+        worst = max(worst, float(np.abs(eg - ref).max()))
+    assert worst < 1e-5, worst
+
+
+@pytest.mark.parametrize("share", ["all 512 graphs (1 GPU)", "64 graphs (rank 3 of 8)"])
+def test_c4_muon_training_step(share):
+    """BASELINE configs[3], the step the ranks run (reference gnn/estimator.py:49-60 with the batch
+    sharded r::8): HIP forward (k_event, stores e_t / H_t) + fused BCE + one-launch HIP backward
+    (k_event_bwd) into a GradBucket + the single-rank form of the flat all-reduce, against autograd
+    through the dense oracle (the reference's own formulation) on the same graphs.
+    Tolerances: loss 1e-6, gradients 1e-4 relative to the largest entry of each tensor."""
+    from gnn_fpga_amd import _lib, shard
+    from gnn_fpga_amd.loss import BCELoss
+    from oracle import dense_torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    graphs = [synth.muon_graph(s) for s in range(512)]
+    if share.startswith("64"):
+        graphs = shard.shard_graphs(graphs, 3, 8)
+    m = _muon_model().train()
+    ref = {k: v.detach().cpu().double().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    b = HitGraphBatch.from_graphs(graphs).cuda()
+    y = b.y.cuda()
+    bucket = shard.GradBucket(m.parameters())
+    calls, real = [], _lib.segclf_backward_events
+    _lib.segclf_backward_events = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        bucket.zero()
+        loss_sum = BCELoss(reduction="sum")(m(b), y)
+        loss_sum.backward()
+        mean = bucket.allreduce(loss_sum.detach(), y.numel())
+    finally:
+        _lib.segclf_backward_events = real
+    assert calls == [1]                                    # the one-launch backward ran
+    # oracle: the dense formulation graph by graph (float64), summed, then the same mean
+    total = torch.zeros((), dtype=torch.float64)
+    for g in graphs:
+        Xd, Ri, Ro = (torch.from_numpy(a)[None].double() for a in synth.to_dense(g))
+        out = dense_torch.segment_classifier(Xd, Ri, Ro, ref, 3)[0]
+        total = total + torch.nn.functional.binary_cross_entropy(
+            out, torch.from_numpy(g.y).double(), reduction="sum")
+    (total / b.n_segments).backward()
+    assert abs(float(mean) - float(total.detach()) / b.n_segments) < 1e-6
+    for k, p in m.named_parameters():
+        r = ref[k].grad.numpy()
+        err = np.abs(p.grad.detach().cpu().double().numpy() - r).max()
+        assert err < 1e-7 + 1e-4 * np.abs(r).max(), (k, err)
+
+
+TOL_BF16_C5 = 2e-3   # bf16 operands / fp32 accumulate (GNN_FLAG_BF16_MLP); SURVEY 8(d): the fp32
+                     # bound 1e-5 "does not apply to bf16" - stated here, measured in the assert message
+
+
+@pytest.fixture(scope="module")
+def c5():
+    """BASELINE configs[4]: mu200-shaped graphs, 50k hits / 500k segments, the model of reference
+    gnn/MPNN_Seg_ACTS_mu200.ipynb cells 15, 19 (hidden_dim 64, 6 iterations; 26 049 parameters)."""
+    from gnn_fpga_amd.model import SegmentClassifier
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    torch.manual_seed(64)
+    m = SegmentClassifier(input_dim=3, hidden_dim=64, n_iters=6).cuda().eval()
+    assert sum(p.numel() for p in m.parameters()) == 26049
+    m.use_events = False
+    params = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    graphs = [synth.layered_graph(50000, 500000, 3, seed=640 + s) for s in range(8)]
+    refs = {i: index_c.segment_classifier(graphs[i].X, graphs[i].src, graphs[i].dst, params, 6)
+            for i in (0, 5)}
+    return m, graphs, refs
+
+
+@pytest.mark.parametrize("n_graphs", [1, 8])
+def test_c5_mu200_fp32(c5, n_graphs):
+    """c5 at full size, fp32 kernels (128-register record groups, windows beyond the Infinity Cache
+    at 8 graphs): within north_star's 1e-5 of the C oracle; the single graph is the batch's graph 0
+    bit for bit (block-diagonal independence)."""
+    m, graphs, refs = c5
+    m.mlp_bf16 = False
+    b = HitGraphBatch.from_graphs(graphs[:n_graphs]).cuda()
+    with torch.no_grad():
+        e = m(b)
+    es = b.split_scores(e.cpu().numpy())
+    for i, ref in refs.items():
+        if i < n_graphs:
+            d = float(np.abs(es[i] - ref).max())
+            assert d < 1e-5, (i, d)
+    assert np.all((es[0] > 0) & (es[0] < 1))
+
+
+@pytest.mark.parametrize("n_graphs", [1, 8])
+def test_c5_mu200_bf16_matrix_cores(c5, n_graphs):
+    """c5 at full size on the matrix-core path (v_mfma_f32_16x16x32_bf16, bf16 records): within
+    TOL_BF16_C5 of the fp32 C oracle, deterministic, and a different path from fp32."""
+    m, graphs, refs = c5
+    b = HitGraphBatch.from_graphs(graphs[:n_graphs]).cuda()
+    with torch.no_grad():
+        m.mlp_bf16 = False
+        e32 = m(b)
+        m.mlp_bf16 = True
+        e16 = m(b)
+        e16b = m(b)
+    m.mlp_bf16 = False
+    assert torch.equal(e16, e16b) and not torch.equal(e16, e32)
+    es = b.split_scores(e16.cpu().numpy())
+    worst = max(float(np.abs(es[i] - ref).max()) for i, ref in refs.items() if i < n_graphs)
+    assert worst < TOL_BF16_C5, worst
+    print("c5 x %d bf16: max |score - fp32 oracle| = %.2e, mean %.2e"
+          % (n_graphs, worst, float((e16 - e32).abs().mean())))
