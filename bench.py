@@ -1,103 +1,229 @@
 """bench.py - edges/s of the SegmentClassifier forward on synthetic TrackML-shaped graphs.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload c3|c5]
 
 One "step" = one pass of the hot path (input network, T x (edge pass, node pass), final
 edge pass; reference gnn/model.py:140-156) over one batch of G synthetic graphs already
-resident in HBM, in index form.  Workload = BASELINE.json configs[2] ("c3"): 10k hits /
-100k segments per graph, F=3, D=8, T=3, G graphs per launch per GPU (SURVEY.md 8(d):
-one 100k-segment graph is cache-resident and launch-bound, so the roofline number is
-taken on a batch).  Multi-GPU: independent graphs sharded over ranks, no data-path
-collective (weak scaling); barrier + synchronize on both sides, max over ranks.
+resident in HBM, in index form.  Default workload = BASELINE.json configs[2] ("c3"): 10k
+hits / 100k segments per graph, F=3, D=8, T=3, G graphs per launch per GPU (SURVEY.md 8(d):
+one 100k-segment graph is cache-resident and launch-bound, so the roofline number is taken
+on a batch).  `--workload c5` = configs[4]: 50k hits / 500k segments, D=64, T=6, G=8, bf16
+matrix-core hit update (fp32 beside it), with the MFMA fraction next to the HBM fraction.
 
-Rank 0 prints ONE JSON line with `roofline` (dominant kernel, HIP-event timed inside the
-library on the launch stream) and `cpu_baseline` (the oracle's dense-bmm port of the
-reference algorithm, timed on this host's cores, N=1 only).
+Multi-GPU: independent graphs sharded over ranks, no data-path collective in the forward
+(weak scaling); barrier + synchronize on both sides, max over ranks.  `--gpus N` with N > 1
+and no torchrun environment starts the N ranks itself (child processes of a parent that
+never touches the GPU) and relays rank 0's line.
+
+Rank 0 prints ONE JSON line with
+  roofline      dominant kernel, HIP-event timed inside the library on the launch stream
+  cpu_baseline  the oracle's dense-bmm port of the reference algorithm on this host (N=1 only)
+  plan_ms       what the per-batch execution plan costs (outside the timed region), and the
+                rate of one forward on a FRESH batch, plan included (`value_incl_plan`)
+  train_c4      BASELINE configs[3]: 512 muon graphs sharded r::N, HIP forward + fused BCE +
+                HIP backward + ONE all-reduce of the flat gradient bucket (RCCL) + Adam
+                (reference gnn/estimator.py:49-60)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
+HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
+F32_MATRIX_TFLOPS = 157.3
 
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
-
-N_HITS, N_SEG, F, D, T = 10000, 100000, 3, 8, 3
-C = F + D
-
-
-def algorithmic_bytes(n, e):
-    """compulsory HBM bytes per kernel launch, fp32 values / int32 indices."""
-    b_in = 4 * n * F + 4 * n * D
-    b_edge = 8 * e + 4 * n * C + 4 * e
-    b_node = 8 * e + 4 * e + 4 * n * C + 4 * n * D
-    return {"k_input": b_in, "k_edge": b_edge, "k_node": b_node,
-            # fused pipeline: k_iter = one edge pass + one node pass; k_edge4 = final edge pass
-            "k_input4": b_in, "k_iter": b_edge + b_node, "k_iter2": b_edge + b_node, "k_pack": 0,
-            "forward": b_in + (T + 1) * b_edge + T * b_node}
+WORKLOADS = {
+    # name: hits, segments, F, D, T, default graphs per launch per GPU
+    "c3": dict(n=10000, e=100000, F=3, D=8, T=3, G=256,
+               text="c3 synthetic TrackML ACTS graphs: %d graphs/launch/GPU x (10k hits, 100k segments), "
+                    "F=3, D=8, 3 MP iterations + final edge pass, index form resident in HBM"),
+    "c5": dict(n=50000, e=500000, F=3, D=64, T=6, G=8,
+               text="c5 mu200-shaped graphs: %d graphs/launch/GPU x (50k hits, 500k segments), F=3, "
+                    "D=64, 6 MP iterations + final edge pass (gnn/MPNN_Seg_ACTS_mu200.ipynb cells 15, "
+                    "19), index form resident in HBM"),
+}
 
 
-def cpu_baseline(model, graph):
+def algorithmic(n, e, F, D, T, w=4):
+    """compulsory HBM bytes (w-byte values, int32 indices) and flops per kernel
+    launch and for the whole forward."""
+    C = F + D
+    b_in = w * n * F + w * n * D
+    b_edge = 8 * e + w * n * C + w * e
+    b_node = 8 * e + w * e + w * n * C + w * n * D
+    f_edge = e * (4 * C * D + 2 * D)
+    f_agg = 4 * e * C
+    f_node = n * (6 * C * D + 2 * D * D)
+    f_in = 2 * n * F * D
+    it_b, it_f = b_edge + b_node, f_edge + f_agg + f_node
+    return {"bytes": {"k_input": b_in, "k_input4": b_in, "k_edge": b_edge, "k_node": b_node, "k_iter": it_b,
+                      "k_iter2": it_b, "k_pack": 0, "k_pack16": 0,
+                      "forward": b_in + (T + 1) * b_edge + T * b_node},
+            "flops": {"k_input": f_in, "k_input4": f_in, "k_edge": f_edge, "k_node": f_agg + f_node,
+                      "k_iter": it_f, "k_iter2": it_f, "k_pack": 0, "k_pack16": 0,
+                      "forward": f_in + (T + 1) * f_edge + T * (f_agg + f_node)}}
+
+
+def cpu_baseline(model, graph, wl):
     """Oracle timed on this host: (a) the dense-bmm port of reference gnn/model.py (the
-    algorithm the reference runs), one c3 graph; (b) the index-form C oracle, all cores."""
+    algorithm the reference runs), one c3 graph; (b) the index-form C oracle, all cores.
+    c5: the dense form needs 100 GB per incidence matrix - index form only."""
+    import torch
     from oracle import dense_torch, index_c
     from gnn_fpga_amd import synth
     # the GPU box gives one GPU a 16-CPU share of a 256-thread host: do not oversubscribe
     cores = min(len(os.sched_getaffinity(0)), 16)
     torch.set_num_threads(cores)
     params = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    pn = {k: v.numpy() for k, v in params.items()}
+    T, e = wl["T"], wl["e"]
+    index_c.segment_classifier(graph.X, graph.src, graph.dst, pn, T, n_threads=cores)  # warm
+    reps = 20 if e <= 100000 else 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        index_c.segment_classifier(graph.X, graph.src, graph.dst, pn, T, n_threads=cores)
+    t_index = (time.perf_counter() - t0) / reps
+    idx_sample = ("1 graph of the workload, index-form restatement oracle/index_c (OpenMP, %d threads), "
+                  "mean of %d runs" % (cores, reps))
+    if wl["n"] * wl["e"] > 2e9:
+        return {"value": e / t_index, "unit": "edges/s", "cores": cores, "kind": "port",
+                "sample": idx_sample + "; the reference's dense [N,E] formulation cannot run at this "
+                                        "size (100 GB per incidence matrix)"}
     X, Ri, Ro = (torch.from_numpy(a)[None] for a in synth.to_dense(graph))
     t0 = time.perf_counter()
     with torch.no_grad():
         dense_torch.segment_classifier(X, Ri, Ro, params, T)
     t_dense = time.perf_counter() - t0
-    del Ri, Ro
-    pn = {k: v.numpy() for k, v in params.items()}
-    index_c.segment_classifier(graph.X, graph.src, graph.dst, pn, T, n_threads=cores)  # warm
-    reps = 20
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        index_c.segment_classifier(graph.X, graph.src, graph.dst, pn, T, n_threads=cores)
-    t_index = (time.perf_counter() - t0) / reps
-    return {"value": N_SEG / t_dense, "unit": "edges/s", "cores": cores, "kind": "port",
+    return {"value": e / t_dense, "unit": "edges/s", "cores": cores, "kind": "port",
             "sample": "1 graph of the workload (10k hits, 100k segments), dense [N,E] bmm "
                       "formulation of gnn/model.py restated in oracle/dense_torch.py, "
                       "torch CPU %d threads, 1 run (%.1f s)" % (cores, t_dense),
-            "index_form_value": N_SEG / t_index,
-            "index_form_sample": "same graph, oracle/index_c (OpenMP, %d threads), mean of %d runs"
-                                 % (cores, reps)}
+            "index_form_value": e / t_index, "index_form_sample": idx_sample}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--graphs", type=int, default=256, help="graphs per launch per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true",
-                    help="experiment: replay the forward from a captured HIP graph")
-    ap.add_argument("--global-gather", action="store_true",
-                    help="experiment: disable the LDS windows (gather records from global memory)")
-    ap.add_argument("--pmc-traffic", default=os.path.join(REPO, "profiles", "pmc_traffic.json"),
-                    help="per-kernel HBM bytes per launch from separate rocprofv3 --pmc passes of "
-                         "this same command (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md), "
-                         "written by tools/profile_bench.sh; `traffic` is null without it")
-    args = ap.parse_args()
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a torchrun environment: this parent has made NO GPU call
+    (importing torch is not one); it starts the N ranks as children through torch.distributed.run,
+    relays their output (rank 0 prints the JSON line) and exits with their code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "4")
+    sys.stderr.write("bench.py: starting %d ranks: %s\n" % (args.gpus, " ".join(cmd)))
+    return subprocess.call(cmd, env=env)
+
+
+def time_steps(step, steps, sync_all):
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync_all()
+    return time.perf_counter() - t0
+
+
+def train_c4(dev, rank, world, rehearse, steps=60, warmup=15, n_global=512):
+    """BASELINE configs[3] as the ranks run it: 512 muon-schema graphs (F=11, D=8, T=3) sharded
+    r::world, one training step = HIP forward (keeps e_t / H_t) + BCE(sum) + HIP backward into the
+    flat GradBucket + ONE all-reduce of that bucket (RCCL over xGMI when world > 1) + Adam."""
+    import torch
+    import torch.distributed as dist
+    from gnn_fpga_amd import HitGraphBatch, shard, synth
+    from gnn_fpga_amd.loss import BCELoss
+    from gnn_fpga_amd.model import SegmentClassifier
+    graphs = shard.shard_graphs([synth.muon_graph(s) for s in range(n_global)], rank, world)
+    batch = HitGraphBatch.from_graphs(graphs).to(dev)
+    y = batch.y.to(dev)
+    torch.manual_seed(0)
+    m = SegmentClassifier(input_dim=11, hidden_dim=8, n_iters=3).to(dev).train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, fused=True)
+    bce = BCELoss(reduction="sum")
+    bucket = shard.GradBucket(m.parameters())
+
+    def step():
+        bucket.zero()
+        loss = bce(m(batch), y)             # local SUM; the all-reduce turns it into the global mean
+        loss.backward()
+        mean = bucket.allreduce(loss.detach(), y.numel())
+        opt.step()
+        return mean
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    first = float(step())
+    for _ in range(warmup):
+        step()
+    dt = time_steps(step, steps, sync_all)
+    last = float(step())
+    seg = torch.tensor([float(batch.n_segments), dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        segs = seg.clone()
+        dist.all_reduce(segs, op=dist.ReduceOp.SUM)
+        dist.all_reduce(seg, op=dist.ReduceOp.MAX)
+        n_seg, dt = float(segs[0]), float(seg[1])
+    else:
+        n_seg = float(seg[0])
+    # did the collective see all ranks?  all-reduce of ones over the same backend
+    ones = torch.ones(1, device=dev)
+    if world > 1:
+        dist.all_reduce(ones)
+    rec = {"workload": "c4: %d muon-schema graphs (F=11, D=8, T=3) sharded r::%d, %d per rank"
+                       % (n_global, world, len(graphs)),
+           "us_per_step": dt / steps * 1e6, "segments_per_s": n_seg * steps / dt,
+           "segments_per_step": int(n_seg), "steps": steps,
+           "collective": ("one all-reduce(sum) of the flat gradient bucket per step, %d floats, backend %s"
+                          % (bucket.flat.numel(), ("gloo (rehearsal)" if rehearse else "nccl (RCCL)")
+                             if world > 1 else "none (single rank)")),
+           "rccl_ranks": int(ones.item()), "loss_first": first, "loss_last": last,
+           "mode": "eager"}
+    if world == 1:
+        # the whole step as ONE captured HIP graph (the library launches on the capturing stream and
+        # allocates nothing; Adam capturable)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True, fused=True)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        cg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cg):
+            step()
+        for _ in range(warmup):
+            cg.replay()
+        dg = time_steps(cg.replay, steps, sync_all)
+        rec["us_per_step_hip_graph"] = dg / steps * 1e6
+        rec["segments_per_s_hip_graph"] = n_seg * steps / dg
+    return rec
+
+
+def run(args):
+    import numpy as np  # noqa: F401
+    import torch
+    import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run "
-                         "--nproc-per-node %d" % (args.gpus, world, args.gpus))
-    import torch.distributed as dist
     # GNN_BENCH_REHEARSE=1: rehearsal of the N > 1 code path on a box with fewer GPUs than ranks
     # (ranks share devices, gloo instead of RCCL); the numbers of such a run mean nothing
     rehearse = os.environ.get("GNN_BENCH_REHEARSE") == "1"
@@ -113,15 +239,22 @@ def main():
     from gnn_fpga_amd import HitGraphBatch, _lib, synth
     from gnn_fpga_amd.model import SegmentClassifier
 
-    G = args.graphs
+    wl = WORKLOADS[args.workload]
+    N_HITS, N_SEG, F, D, T = wl["n"], wl["e"], wl["F"], wl["D"], wl["T"]
+    G = args.graphs or wl["G"]
+    bf16 = args.workload == "c5" and args.dtype != "f32"
     graphs = [synth.layered_graph(N_HITS, N_SEG, F, seed=rank * G + i) for i in range(G)]
     batch = HitGraphBatch.from_graphs(graphs).to(dev)
+    limits = {"iter_records": 0, "edge_records": 0} if args.global_gather else None
+    torch.cuda.synchronize()
     t_plan = time.perf_counter()
-    plan = batch.build_plan(D, {"iter_records": 0, "edge_records": 0} if args.global_gather else None)     # relabel + SELL-16 lists: once per batch, like the CSR build
+    plan = batch.build_plan(D, limits)     # relabel + SELL-16 lists: once per batch, like the CSR build
     torch.cuda.synchronize()
     t_plan = time.perf_counter() - t_plan
     torch.manual_seed(0)
     model = SegmentClassifier(input_dim=F, hidden_dim=D, n_iters=T).to(dev).eval()
+    model.use_events = False
+    model.mlp_bf16 = bf16
 
     def sync_all():
         torch.cuda.synchronize()
@@ -132,7 +265,7 @@ def main():
     with torch.no_grad():
         # one-off, before the W warm-up steps: first launches load the code objects, size the
         # workspace and let the clocks leave idle (a cold 1-ms step was seen to run 40 % long)
-        for _ in range(10):
+        for _ in range(10 if args.workload == "c3" else 2):
             model(batch)
         torch.cuda.synchronize()
         for _ in range(args.warmup):
@@ -145,21 +278,72 @@ def main():
                 model(batch)
             step = cg.replay
             step()
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        sync_all()
-        elapsed = time.perf_counter() - t0
+        elapsed = time_steps(step, args.steps, sync_all)
         # per-kernel durations: HIP events recorded by the library around every launch,
         # on the launch stream, in a separate pass (events perturb the timed region)
-        with _lib.profile(capacity=16 * args.steps) as prof:
+        with _lib.profile(capacity=32 * args.steps) as prof:
             for _ in range(args.steps):
                 model(batch)
+        other = None
+        if args.workload == "c5":           # the other arithmetic beside it
+            model.mlp_bf16 = not bf16
+            for _ in range(2):
+                model(batch)
+            other = time_steps(step, max(args.steps // 4, 2), sync_all) / max(args.steps // 4, 2)
+            model.mlp_bf16 = bf16
+        # the per-batch plan on the record: a second, fresh batch of the same graphs (code objects
+        # and allocator warm), then one forward on it - what a stream of never-repeated batches pays
+        e_tot_local = batch.n_segments
+        fresh = HitGraphBatch.from_graphs(graphs).to(dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fresh.build_plan(D, limits)
+        torch.cuda.synchronize()
+        t_plan_warm = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        model(fresh)
+        torch.cuda.synchronize()
+        t_fresh_fwd = time.perf_counter() - t0
+        pruned = None
+        if args.workload == "c3" and world == 1 and not args.no_pruned:
+            # the same model with masks that kill half of every layer's units (whole
+            # rows / columns, the pattern of the reference's pruned model): compact_dead_units hands
+            # the hidden_dim-4 kernels a narrower network that computes the same function
+            C = F + D
+            me = [torch.ones(D, 2 * C), torch.ones(1, D)]
+            mn = [torch.ones(D, 3 * C), torch.ones(D, D)]
+            for n, i in enumerate((1, 3, 4, 6)):
+                (me[0].__setitem__((i, slice(None)), 0) if n % 2 == 0 else me[1].__setitem__((0, i), 0))
+            for n, i in enumerate((0, 2, 5, 7)):
+                (mn[0].__setitem__((i, slice(None)), 0) if n % 2 == 0 else mn[1].__setitem__((slice(None), i), 0))
+            for k in (2, 3, 5, 6):
+                for blk, msk in ((2, me[0]), (3, mn[0])):
+                    for b in range(blk):
+                        msk[:, b * C + k] = 0
+            torch.manual_seed(0)
+            pm = SegmentClassifier(input_dim=F, hidden_dim=D, n_iters=T, masks_e=me, masks_n=mn).to(dev).eval()
+            pm.use_events = False
+            info = pm.pruned_info()
+            ps = max(args.steps // 4, 5)
+            times = {}
+            for on in (False, True):
+                pm.prune_dead_units = on
+                pm.invalidate()
+                for _ in range(3):
+                    pm(fresh)
+                times[on] = time_steps(lambda: pm(fresh), ps, sync_all) / ps
+            pruned = {"masks": "4 of 8 edge hidden units, 4 of 8 node hidden units and 4 of 8 hit "
+                               "features dead (whole rows / columns masked)",
+                      "kernels_hidden_dim": info and info["hidden_dim"],
+                      "ms_per_step_full_width": times[False] * 1e3, "ms_per_step": times[True] * 1e3,
+                      "speedup": times[False] / times[True], "value": e_tot_local / times[True]}
+        del fresh
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+
+    train = None if args.no_train else train_c4(dev, rank, world, rehearse)
 
     if rank == 0:
         per = {}
@@ -173,60 +357,124 @@ def main():
         seq_ms = [[prof.records[i][0], round(sum(prof.records[j][1] for j in range(i, len(prof.records), lps))
                                              / args.steps, 4)] for i in range(lps)] if lps else []
         n_tot, e_tot = batch.n_hits, batch.n_segments
-        ab = algorithmic_bytes(n_tot, e_tot)
+        alg = algorithmic(n_tot, e_tot, F, D, T, w=2 if bf16 else 4)
+        ab, af = alg["bytes"], alg["flops"]
         # algorithmic bytes of the dominant kernel's launches in one step; when the input network
         # is fused into the first iteration launch (no k_input4 launch), its bytes ride along
         n_dom = len(per[dom]) // args.steps
-        ab_dom_step = n_dom * ab[dom]
+        ab_dom_step, af_dom_step = n_dom * ab[dom], n_dom * af[dom]
         if dom == "k_iter2" and "k_input4" not in per:
             ab_dom_step += ab["k_input4"]
-        ab_dom = ab_dom_step / n_dom                       # average per launch
-        achieved = ab_dom / (avg_ms[dom] * 1e-3) / 1e9
+            af_dom_step += af["k_input4"]
+        ab_dom, af_dom = ab_dom_step / n_dom, af_dom_step / n_dom          # average per launch
+        t_dom = avg_ms[dom] * 1e-3
+        gbs = ab_dom / t_dom / 1e9
+        tfs = af_dom / t_dom / 1e12
         ms_step = elapsed / args.steps * 1e3
-        traffic = None
-        if args.pmc_traffic and os.path.exists(args.pmc_traffic) and G == 256:
+        traffic = traffic_source = None
+        if args.pmc_traffic and os.path.exists(args.pmc_traffic) and G == 256 and args.workload == "c3":
             with open(args.pmc_traffic) as f:
-                pk = json.load(f)["kernels"]
+                pj = json.load(f)
+            pk = pj["kernels"]
             # the dominant kernel has template variants (first / middle / last iteration move
             # different amounts): launch-weighted mean over the profiled run
             vs = [v for k, v in pk.items() if k.startswith(dom + "<")]
             if vs:
                 traffic = (sum(v["hbm_bytes_per_launch"] * v.get("launches", 1) for v in vs) /
                            sum(v.get("launches", 1) for v in vs))
+                traffic_source = ("%s (%s): rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of this "
+                                  "command, committed - not measured in this run"
+                                  % (os.path.relpath(args.pmc_traffic, REPO), pj.get("source", "?")))
         value = world * e_tot * args.steps / elapsed
+        roof = {"kernel": dom, "algorithmic_bytes_per_launch": ab_dom,
+                "algorithmic_flops_per_launch": af_dom, "avg_launch_ms": avg_ms[dom],
+                "traffic": traffic, "traffic_source": traffic_source,
+                "kernel_ms": {k: round(v, 4) for k, v in avg_ms.items()},
+                "launches_per_step": {k: len(v) // args.steps for k, v in per.items()},
+                "launch_sequence_ms": seq_ms,
+                "forward_algorithmic_GBps": ab["forward"] / (ms_step * 1e-3) / 1e9,
+                "forward_frac": ab["forward"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if args.workload == "c5":
+            # c5's dense contractions make the matrix cores the bounding roofline of the
+            # reference's formulation; report the MFMA fraction AND the HBM fraction
+            peak = BF16_PEAK_TFLOPS if bf16 else F32_MATRIX_TFLOPS
+            roof = dict({"bound": "mfma", "achieved": tfs, "peak": peak, "unit": "TFLOP/s",
+                         "frac": tfs / peak, "hbm_achieved_GBps": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
+                         "forward_algorithmic_TFLOPs": af["forward"] / (ms_step * 1e-3) / 1e12,
+                         "forward_mfma_frac": af["forward"] / (ms_step * 1e-3) / 1e12 / peak,
+                         "note": "algorithmic flops = the reference's per-segment contraction (SURVEY 8(d)); "
+                                 "the kernels execute the per-hit P/Q form, E/N = 10x fewer multiply-adds"},
+                        **roof)
+        else:
+            roof = dict({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs / HBM_PEAK_GBS}, **roof)
         out = {
             "metric": "edges/sec (EdgeNet+NodeNet fwd) on 100k-edge TrackML graphs; % HBM roofline",
             "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "c3 synthetic TrackML ACTS graphs: %d graphs/launch/GPU x "
-                                   "(10k hits, 100k segments), F=3, D=8, 3 MP iterations + final "
-                                   "edge pass, index form resident in HBM" % G,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32",
+            "data": "synthetic",
+            "config": {"workload": wl["text"] % G,
                        "graphs_per_gpu": G, "hits_per_graph": N_HITS,
                        "segments_per_graph": N_SEG,
                        "plan": "hits relabelled by degree, SELL-16 lists (padding %.1f%%), built "
-                               "once per batch on the GPU (torch sorts / scatters) in %.2f s, "
-                               "outside the timed region like the CSR build"
-                               % (100 * plan.padding, t_plan),
+                               "once per batch on the GPU, outside the timed region like the CSR build "
+                               "(plan_ms below)" % (100 * plan.padding),
                        "sharding": "independent graphs per rank, "
                        "no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic,
-                         "algorithmic_bytes_per_launch": ab_dom,
-                         "avg_launch_ms": avg_ms[dom],
-                         "kernel_ms": {k: round(v, 4) for k, v in avg_ms.items()},
-                         "launches_per_step": {k: len(v) // args.steps for k, v in per.items()},
-                         "launch_sequence_ms": seq_ms,
-                         "forward_algorithmic_GBps": ab["forward"] / (ms_step * 1e-3) / 1e9,
-                         "forward_frac": ab["forward"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "roofline": roof,
+            "plan_ms": {"cold": t_plan * 1e3, "warm": t_plan_warm * 1e3,
+                        "builder": type(plan).__name__,
+                        "fresh_batch_forward_ms": t_fresh_fwd * 1e3},
+            "value_incl_plan": e_tot / (t_plan_warm + t_fresh_fwd),
+            "value_incl_plan_note": "one forward on a never-seen batch: warm plan build + first forward; "
+                                    "`value` replays one resident batch (plan amortised)",
         }
+        if other is not None:
+            out["other_dtype"] = {"dtype": "f32" if bf16 else "bf16", "ms_per_step": other * 1e3,
+                                  "value": e_tot / other}
+        if pruned is not None:
+            out["pruned"] = pruned
+        if train is not None:
+            out["train_c4"] = train
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, graphs[0])
-        print(json.dumps(out))
+            out["cpu_baseline"] = cpu_baseline(model, graphs[0], wl)
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
+    ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16", help="c5 only")
+    ap.add_argument("--graphs", type=int, default=0, help="graphs per launch per GPU (default: 256 c3, 8 c5)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the train_c4 sub-record")
+    ap.add_argument("--no-pruned", action="store_true", help="skip the pruned-model sub-record (c3, N=1)")
+    ap.add_argument("--graph", action="store_true",
+                    help="experiment: replay the forward from a captured HIP graph")
+    ap.add_argument("--global-gather", action="store_true",
+                    help="experiment: disable the LDS windows (gather records from global memory)")
+    ap.add_argument("--pmc-traffic", default=os.path.join(REPO, "profiles", "pmc_traffic.json"),
+                    help="per-kernel HBM bytes per launch from separate rocprofv3 --pmc passes of "
+                         "this same command (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md), "
+                         "written by tools/profile_bench.sh; `traffic` is null without it")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    world = os.environ.get("WORLD_SIZE")
+    if world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+    if int(world or 1) != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%s: launch with torch.distributed.run "
+                         "--nproc-per-node %d, or unset WORLD_SIZE and bench.py starts the ranks itself"
+                         % (args.gpus, world, args.gpus))
+    run(args)
 
 
 if __name__ == "__main__":

@@ -127,16 +127,50 @@ def _check(rc):
         raise GnnHipError("libgnn_hip: %s (code %d)" % (load().gnn_last_error().decode(), rc))
 
 
+_cur_dev = None     # device of the call in progress (set by `_on`); _dev() checks tensors against it
+
+
 def _dev(t, dtype, what):
     if not torch.is_tensor(t) or not t.is_cuda:
         raise GnnHipError("%s must be a tensor on a ROCm device (no CPU path exists)" % what)
     if t.dtype != dtype or not t.is_contiguous():
         raise GnnHipError("%s must be contiguous %s" % (what, dtype))
+    if _cur_dev is not None and t.device != _cur_dev:
+        raise GnnHipError("%s is on %s but this call runs on %s: every tensor of one call must live "
+                          "on one device" % (what, t.device, _cur_dev))
     return t.data_ptr()
 
 
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
+class _on:
+    """`with _on(tensor_or_device) as stream:` - makes that device CURRENT for the library call (the
+    kernels launch on the current device; a stream of another device would be an invalid handle and
+    another device's pointers an illegal address), hands out ITS current stream, and lets _dev()
+    refuse tensors that live elsewhere.  Structs built earlier carry `_device` and are checked too."""
+
+    def __init__(self, where, *structs):
+        dev = where.device if torch.is_tensor(where) else torch.device(where)
+        if dev.type != "cuda":
+            raise GnnHipError("tensors must be on a ROCm device (no CPU path exists); got %s" % dev)
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        for st in structs:
+            sd = getattr(st, "_device", None)
+            if st is not None and sd is not None and sd != dev:
+                raise GnnHipError("%s was built for %s but this call runs on %s"
+                                  % (type(st).__name__, sd, dev))
+        self.dev = dev
+        self.ctx = torch.cuda.device(dev)
+
+    def __enter__(self):
+        global _cur_dev
+        self.ctx.__enter__()
+        self.prev, _cur_dev = _cur_dev, self.dev
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def __exit__(self, *exc):
+        global _cur_dev
+        _cur_dev = self.prev
+        return self.ctx.__exit__(*exc)
 
 
 def shape_supported(F, D):
@@ -157,6 +191,11 @@ def graph_struct(batch):
     for k in ("src", "dst", "in_ptr", "in_eid", "in_nbr", "out_ptr", "out_eid", "out_nbr"):
         setattr(g, k, _dev(getattr(batch, k), i32, k))
     g.n_hits, g.n_segments = batch.n_hits, batch.n_segments
+    g._device = batch.X.device
+    devs = {getattr(batch, k).device for k in ("src", "dst", "in_ptr", "in_eid", "in_nbr",
+                                               "out_ptr", "out_eid", "out_nbr")}
+    if devs != {g._device}:
+        raise GnnHipError("the arrays of a batch must live on one device, got %s" % sorted(map(str, devs)))
     return g
 
 
@@ -177,6 +216,10 @@ def params_struct(weights, F, D, flags=0):
     for name, w in zip(("Win", "bin", "W1", "b1", "W2", "b2", "W3", "b3", "W4", "b4"), weights):
         setattr(p, name, _dev(w, torch.float32, name))
     p.F, p.D, p.flags = F, D, flags
+    devs = {w.device for w in weights}
+    if len(devs) != 1:
+        raise GnnHipError("the weight tensors must live on one device, got %s" % sorted(map(str, devs)))
+    p._device = devs.pop()
     return p
 
 
@@ -184,8 +227,9 @@ def exp_product_bound(weights, F, D, x_absmax):
     """max |P'|, |Q'| bound (python float; synchronises).  <= 60 permits GNN_FLAG_EXP_PRODUCT."""
     out = torch.empty(1, dtype=torch.float32, device=x_absmax.device)
     p = params_struct(weights, F, D)
-    _check(load().gnn_exp_product_bound(ctypes.byref(p), _dev(x_absmax, torch.float32, "x_absmax"),
-                                        out.data_ptr(), _stream()))
+    with _on(x_absmax, p) as st:
+        _check(load().gnn_exp_product_bound(ctypes.byref(p), _dev(x_absmax, torch.float32, "x_absmax"),
+                                            out.data_ptr(), st))
     return float(out.item())
 
 
@@ -195,9 +239,10 @@ def input_fwd(X, Win, bin_):
     D = Win.shape[0]
     ldh = h_stride(F, D)
     H = torch.empty((n, ldh), dtype=torch.float32, device=X.device)
-    _check(load().gnn_input_fwd(_dev(X, torch.float32, "X"), _dev(Win, torch.float32, "Win"),
-                                _dev(bin_, torch.float32, "bin"), H.data_ptr(), n, F, D, ldh,
-                                _stream()))
+    with _on(X) as st:
+        _check(load().gnn_input_fwd(_dev(X, torch.float32, "X"), _dev(Win, torch.float32, "Win"),
+                                    _dev(bin_, torch.float32, "bin"), H.data_ptr(), n, F, D, ldh,
+                                    st))
     return H
 
 
@@ -207,11 +252,12 @@ def edge_fwd(H, src, dst, W1, b1, W2, b2, F, D):
     E = src.shape[0]
     e = torch.empty(E, dtype=torch.float32, device=H.device)
     pq = torch.empty((max(n, 1), 2 * D), dtype=torch.float32, device=H.device)
-    _check(load().gnn_edge_fwd(_dev(H, torch.float32, "H"), ldh, _dev(src, torch.int32, "src"),
-                               _dev(dst, torch.int32, "dst"), _dev(W1, torch.float32, "W1"),
-                               _dev(b1, torch.float32, "b1"), _dev(W2, torch.float32, "W2"),
-                               _dev(b2, torch.float32, "b2"), e.data_ptr(), pq.data_ptr(),
-                               n, E, F, D, _stream()))
+    with _on(H) as st:
+        _check(load().gnn_edge_fwd(_dev(H, torch.float32, "H"), ldh, _dev(src, torch.int32, "src"),
+                                   _dev(dst, torch.int32, "dst"), _dev(W1, torch.float32, "W1"),
+                                   _dev(b1, torch.float32, "b1"), _dev(W2, torch.float32, "W2"),
+                                   _dev(b2, torch.float32, "b2"), e.data_ptr(), pq.data_ptr(),
+                                   n, E, F, D, st))
     return e
 
 
@@ -220,10 +266,11 @@ def node_fwd(H, e, batch, W3, b3, W4, b4, F, D):
     n, ldh = H.shape
     Hn = torch.zeros_like(H)
     g = graph_struct(batch)
-    _check(load().gnn_node_fwd(_dev(H, torch.float32, "H"), ldh, _dev(e, torch.float32, "e"),
-                               ctypes.byref(g), _dev(W3, torch.float32, "W3"),
-                               _dev(b3, torch.float32, "b3"), _dev(W4, torch.float32, "W4"),
-                               _dev(b4, torch.float32, "b4"), Hn.data_ptr(), F, D, _stream()))
+    with _on(H, g) as st:
+        _check(load().gnn_node_fwd(_dev(H, torch.float32, "H"), ldh, _dev(e, torch.float32, "e"),
+                                   ctypes.byref(g), _dev(W3, torch.float32, "W3"),
+                                   _dev(b3, torch.float32, "b3"), _dev(W4, torch.float32, "W4"),
+                                   _dev(b4, torch.float32, "b4"), Hn.data_ptr(), F, D, st))
     return Hn
 
 
@@ -251,11 +298,12 @@ def segclf_forward(batch, weights, F, D, n_iters, out=None, workspace=None, trac
         Ht = torch.empty((n_iters + 1, N, F + D), dtype=torch.float32, device=dev)
     g = graph_struct(batch)
     p = params_struct(weights, F, D)
-    _check(load().gnn_segclf_forward(ctypes.byref(g), ctypes.byref(p), n_iters,
-                                     _dev(out, torch.float32, "out"),
-                                     et.data_ptr() if trace else None,
-                                     Ht.data_ptr() if trace else None,
-                                     workspace.data_ptr(), workspace.numel(), _stream()))
+    with _on(batch.X, g, p) as st:
+        _check(load().gnn_segclf_forward(ctypes.byref(g), ctypes.byref(p), n_iters,
+                                         _dev(out, torch.float32, "out"),
+                                         et.data_ptr() if trace else None,
+                                         Ht.data_ptr() if trace else None,
+                                         workspace.data_ptr(), workspace.numel(), st))
     return (out, et, Ht) if trace else out
 
 
@@ -273,10 +321,11 @@ def segclf_forward_events(batch, layout, weights, F, D, n_iters, out=None, param
         out = torch.empty(batch.n_segments, dtype=torch.float32, device=dev)
     g = cached_graph_struct(batch)
     p = params if params is not None else params_struct(weights, F, D)
-    _check(load().gnn_segclf_forward_events(
-        ctypes.byref(g), ctypes.byref(p), _dev(layout.hit_ptr, torch.int32, "hit_ptr"),
-        _dev(layout.seg_ptr, torch.int32, "seg_ptr"), batch.n_graphs, layout.max_hits,
-        layout.max_segments, n_iters, _dev(out, torch.float32, "out"), _stream()))
+    with _on(batch.X, g, p) as st:
+        _check(load().gnn_segclf_forward_events(
+            ctypes.byref(g), ctypes.byref(p), _dev(layout.hit_ptr, torch.int32, "hit_ptr"),
+            _dev(layout.seg_ptr, torch.int32, "seg_ptr"), batch.n_graphs, layout.max_hits,
+            layout.max_segments, n_iters, _dev(out, torch.float32, "out"), st))
     return out
 
 
@@ -291,18 +340,20 @@ def segclf_forward_train(batch, weights, F, D, n_iters, layout=None):
     if layout is not None:
         g = cached_graph_struct(batch)
         p = params_struct(weights, F, D)
-        _check(load().gnn_segclf_forward_train_events(
-            ctypes.byref(g), ctypes.byref(p), _dev(layout.hit_ptr, torch.int32, "hit_ptr"),
-            _dev(layout.seg_ptr, torch.int32, "seg_ptr"), batch.n_graphs, layout.max_hits,
-            layout.max_segments, n_iters, _dev(e_all, torch.float32, "e_all"),
-            _dev(H_all, torch.float32, "H_all"), _stream()))
+        with _on(batch.X, g, p) as st:
+            _check(load().gnn_segclf_forward_train_events(
+                ctypes.byref(g), ctypes.byref(p), _dev(layout.hit_ptr, torch.int32, "hit_ptr"),
+                _dev(layout.seg_ptr, torch.int32, "seg_ptr"), batch.n_graphs, layout.max_hits,
+                layout.max_segments, n_iters, _dev(e_all, torch.float32, "e_all"),
+                _dev(H_all, torch.float32, "H_all"), st))
         return e_all, H_all
     ws = torch.empty(workspace_bytes(N, E, F, D), dtype=torch.uint8, device=dev)
     g = cached_graph_struct(batch)
     p = params_struct(weights, F, D)
-    _check(load().gnn_segclf_forward_train(ctypes.byref(g), ctypes.byref(p), n_iters,
-                                           e_all.data_ptr(), H_all.data_ptr(), ws.data_ptr(),
-                                           ws.numel(), _stream()))
+    with _on(batch.X, g, p) as st:
+        _check(load().gnn_segclf_forward_train(ctypes.byref(g), ctypes.byref(p), n_iters,
+                                               e_all.data_ptr(), H_all.data_ptr(), ws.data_ptr(),
+                                               ws.numel(), st))
     return e_all, H_all
 
 
@@ -322,11 +373,12 @@ def segclf_backward(batch, weights, F, D, n_iters, e_all, H_all, grad_out):
     ws = torch.empty(need, dtype=torch.uint8, device=dev)
     g = cached_graph_struct(batch)
     p = params_struct(weights, F, D)
-    _check(load().gnn_segclf_backward(ctypes.byref(g), ctypes.byref(p), n_iters,
-                                      _dev(e_all, torch.float32, "e_all"),
-                                      _dev(H_all, torch.float32, "H_all"),
-                                      _dev(grad_out, torch.float32, "grad_out"),
-                                      ctypes.byref(gs), ws.data_ptr(), ws.numel(), _stream()))
+    with _on(batch.X, g, p) as st:
+        _check(load().gnn_segclf_backward(ctypes.byref(g), ctypes.byref(p), n_iters,
+                                          _dev(e_all, torch.float32, "e_all"),
+                                          _dev(H_all, torch.float32, "H_all"),
+                                          _dev(grad_out, torch.float32, "grad_out"),
+                                          ctypes.byref(gs), ws.data_ptr(), ws.numel(), st))
     return grads
 
 
@@ -350,11 +402,12 @@ def segclf_backward_events(batch, layout, weights, F, D, n_iters, e_all, H_all, 
     ws = torch.empty(int(load().gnn_backward_events_workspace_bytes(F, D)), dtype=torch.uint8, device=dev)
     g = cached_graph_struct(batch)
     p = params_struct(weights, F, D)
-    _check(load().gnn_segclf_backward_events(
-        ctypes.byref(g), ctypes.byref(p), _dev(layout.hit_ptr, torch.int32, "hit_ptr"),
-        _dev(layout.seg_ptr, torch.int32, "seg_ptr"), batch.n_graphs, layout.max_hits, layout.max_segments,
-        n_iters, _dev(e_all, torch.float32, "e_all"), _dev(H_all, torch.float32, "H_all"),
-        _dev(grad_out, torch.float32, "grad_out"), ctypes.byref(gs), ws.data_ptr(), ws.numel(), _stream()))
+    with _on(batch.X, g, p) as st:
+        _check(load().gnn_segclf_backward_events(
+            ctypes.byref(g), ctypes.byref(p), _dev(layout.hit_ptr, torch.int32, "hit_ptr"),
+            _dev(layout.seg_ptr, torch.int32, "seg_ptr"), batch.n_graphs, layout.max_hits, layout.max_segments,
+            n_iters, _dev(e_all, torch.float32, "e_all"), _dev(H_all, torch.float32, "H_all"),
+            _dev(grad_out, torch.float32, "grad_out"), ctypes.byref(gs), ws.data_ptr(), ws.numel(), st))
     return grads
 
 
@@ -365,9 +418,10 @@ def bce_loss(e, y, scale, want_grad=True):
     loss = torch.empty(1, dtype=torch.float32, device=dev)
     grad = torch.empty(n, dtype=torch.float32, device=dev) if want_grad else None
     ws = torch.empty(256, dtype=torch.float32, device=dev)          # GNN_BCE_WORKSPACE_BYTES
-    _check(load().gnn_bce_loss(_dev(e, torch.float32, "scores"), _dev(y, torch.float32, "targets"), n,
-                               float(scale), loss.data_ptr(), grad.data_ptr() if want_grad else None,
-                               ws.data_ptr(), _stream()))
+    with _on(e) as st:
+        _check(load().gnn_bce_loss(_dev(e, torch.float32, "scores"), _dev(y, torch.float32, "targets"), n,
+                                   float(scale), loss.data_ptr(), grad.data_ptr() if want_grad else None,
+                                   ws.data_ptr(), st))
     return loss, grad
 
 
@@ -395,6 +449,7 @@ def plan_struct(plan):
     g.n_lds_tiles, g.tile_hits_max = plan.n_lds_tiles, plan.tile_hits_max
     g.iter_lds_in, g.iter_lds_out = plan.iter_lds_in, plan.iter_lds_out
     g.max_list_steps = plan.max_list_steps
+    g._device = plan.X.device
     return g
 
 
@@ -423,9 +478,10 @@ def segclf_forward_plan(plan, weights, F, D, n_iters, out=None, workspace=None, 
         plan._struct_dev = dev
     p = params if params is not None else params_struct(weights, F, D, flags)
     p.flags = flags
-    _check(load().gnn_segclf_forward_plan(ctypes.byref(g), ctypes.byref(p), n_iters,
-                                          _dev(out, torch.float32, "out"),
-                                          workspace.data_ptr(), workspace.numel(), _stream()))
+    with _on(plan.X, g, p) as st:
+        _check(load().gnn_segclf_forward_plan(ctypes.byref(g), ctypes.byref(p), n_iters,
+                                              _dev(out, torch.float32, "out"),
+                                              workspace.data_ptr(), workspace.numel(), st))
     return out
 
 

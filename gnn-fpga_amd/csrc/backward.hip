@@ -958,12 +958,10 @@ int backward_events_t(const gnn_graph_t *g, const gnn_params_t *p, const int32_t
     hipError_t err = hipMemsetAsync(rp, 0, (size_t)kReplicas * GL::stride * sizeof(float), s);
     if (err != hipSuccess) return fail(-(int)err, "memset of the gradient replicas failed");
     if (n_graphs > 0) {
-        static bool attr_done = false;
-        if (!attr_done) {
+        static DevOnce attr_done;
+        if (attr_done.need())
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_event_bwd<F, D>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEventBwdLdsMax);
-            attr_done = true;
-        }
         using B = EvBwd<F, D>;
         const size_t lds = B::lds_bytes(cap_h, cap_s);
         GNN_LAUNCH_SH("k_event_bwd", (k_event_bwd<F, D>), (unsigned)n_graphs, kBlock, lds, s, *g, *p, hit_ptr,

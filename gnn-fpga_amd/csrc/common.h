@@ -38,6 +38,37 @@ void prof_post(hipStream_t s);
 
 constexpr int kBlock = 256;   // 4 waves of 64
 
+// One-time per-DEVICE set-up (hipFuncSetAttribute opt-ins for > 64 KB of dynamic LDS, CU counts):
+// a process may drive several devices, and a function attribute set while device 0 was current
+// says nothing about device 1.  `static DevOnce once; if (once.need()) { ... }`.
+struct DevOnce {
+    unsigned long long done = 0;
+    bool need()
+    {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess) return true;
+        const unsigned long long bit = 1ull << (d & 63);
+        if (done & bit) return false;
+        done |= bit;
+        return true;
+    }
+};
+
+// CU count of the CURRENT device (cached per device)
+inline int device_cus()
+{
+    static int cus[64] = {0};
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) return 256;
+    int &c = cus[d & 63];
+    if (!c) {
+        hipDeviceProp_t prop;
+        c = (hipGetDeviceProperties(&prop, d) == hipSuccess && prop.multiProcessorCount > 0)
+                ? prop.multiProcessorCount : 256;
+    }
+    return c;
+}
+
 // one item per thread; grids beyond 8 workgroups are rounded up to a multiple of 8 so that
 // xcd_block() below is a bijection (the surplus workgroups find nothing to do)
 inline unsigned grid_for(int64_t n)

@@ -538,12 +538,10 @@ int run_events(const gnn_graph_t *g, const gnn_params_t *p, const int32_t *hit_p
 {
     if (n_graphs <= 0) return 0;
     const size_t lds = event_lds_bytes(F, D, cap_hits, cap_segments);
-    static bool attr_done = false;     // dynamic LDS above 64 KB must be opted into, once
-    if (!attr_done) {
+    static DevOnce attr_done;     // dynamic LDS above 64 KB must be opted into, once per device
+    if (attr_done.need())
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_event<F, D>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEventLdsMax);
-        attr_done = true;
-    }
     GNN_LAUNCH_SH("k_event", (k_event<F, D>), (unsigned)n_graphs, EvCfg<D>::NT, lds, s, *g, p->Win, p->bin, p->W1,
                   p->b1, p->W2, p->b2, p->W3, p->b3, p->W4, p->b4, hit_ptr, seg_ptr, n_iters, e_out,
                   cap_hits, cap_segments, e_all, H_all);

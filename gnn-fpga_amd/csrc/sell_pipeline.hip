@@ -1746,6 +1746,13 @@ __global__ __launch_bounds__(1024) void k_iter2(
         auto round_fence = [&](int r) {
             if ((r + 1) * (NT / 4) * 2 * D > x_off) __syncthreads();
         };
+        // the NULL record sits right behind the last record: when that slot reaches into the X
+        // image (a full last round of a window whose records end exactly at the image), the wave
+        // that writes it must wait until every wave has read its X rows of the last round
+        // (workgroup-uniform condition)
+        auto null_fence = [&]() {
+            if ((cnt + 1) * 2 * D > x_off) __syncthreads();
+        };
         a_wait_all();                                  // this wave's DMA pieces have landed
         __syncthreads();                               // ... and everybody else's
         if constexpr (D == 8) {
@@ -1794,6 +1801,7 @@ __global__ __launch_bounds__(1024) void k_iter2(
                 }
                 if (live) *reinterpret_cast<f4v *>(buf + h * 2 * D + 4 * g) = c;
             }
+            null_fence();
             put_null(buf, cnt, which);
             return;
         }
@@ -1821,6 +1829,7 @@ __global__ __launch_bounds__(1024) void k_iter2(
                 for (int i = 0; i < d4; ++i) rec[i] = __builtin_amdgcn_exp2f(rec[i]);
             store_vec<2 * d4>(buf + h * 2 * D + q * 2 * d4, rec);
         }
+        null_fence();
         put_null(buf, cnt, which);
     };
 
@@ -2283,14 +2292,17 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
         const int nt = (int)pl->n_tiles;
         const int tpx = (nt + 7) / 8;
         const size_t it_lds = (size_t)(L::total + (G::it_rec > 0 ? pl->iter_lds_records : 0) * 2 * D + 4) * sizeof(float);
-        static bool attr_done = false;     // dynamic LDS above 64 KB must be opted into, once
-        if (!attr_done) {
+        static DevOnce attr_done;     // dynamic LDS above 64 KB must be opted into, once per device
+        if (attr_done.need()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter<F, D, true, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter<F, D, false, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
-            attr_done = true;
         }
-        const char *ab = getenv("GNN_ABLATE");   // timing diagnostics only (results invalid)
+#ifdef GNN_DIAG
+        const char *ab = getenv("GNN_ABLATE");   // timing diagnostics only (results invalid): diag builds
         const int ablate = ab ? atoi(ab) : 0;
+#else
+        const int ablate = 0;                    // the shipped library never skips work
+#endif
         // persistent phase-split kernel when every tile runs in LDS mode and both windows fit LDS;
         // otherwise the general kernel
         bool use2 = false, fuse_first = false;
@@ -2317,13 +2329,9 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
             // register budget without spills, and it is the rarely taken fallback anyway)
             fuse_first = G::fuse_first && XP && use2 && n_iters >= 2 && it2_lds_first <= (size_t)G::lds_bytes &&
                          !getenv("GNN_NO_FUSE_FIRST");
-            static int n_cu = 0;
-            if (!n_cu) {
-                int dev = 0;
-                hipDeviceProp_t prop;
-                if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-                    n_cu = prop.multiProcessorCount;
-                if (n_cu <= 0) n_cu = 256;
+            const int n_cu = device_cus();
+            static DevOnce it2_attr;
+            if (it2_attr.need()) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter2<F, D, true, XP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter2<F, D, false, XP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
                 if constexpr (XP && G::fuse_first)
@@ -2336,11 +2344,9 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
             if (bf && G::pack_first) {      // records of iteration 0 on the matrix cores too
                 using B = BL<F, D>;
                 const size_t lds_in = (size_t)(B::template tm_words<false>() + 5 * D + 4 * 16 * B::tr_stride) * 4;
-                static bool in_attr = false;
-                if (!in_attr) {
+                static DevOnce in_attr;
+                if (in_attr.need())
                     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_input4_bf<F, D, false, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
-                    in_attr = true;
-                }
                 const int64_t g_need = (Np * 4 + 255) / 256;
                 GNN_LAUNCH_SH("k_input4", (k_input4_bf<F, D, false, XP>), (unsigned)(g_need < 512 ? g_need : 512), 256,
                               lds_in, s, pl->X, w.table, w.t16, PR, QS, w.U, w.Pc, w.Qc, Np);
@@ -2382,11 +2388,10 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
                 if (bf) {           // matrix-core hit update (bf16 operands, fp32 accumulate)
                     using B = BL<F, D>;
                     const size_t trw = (size_t)(G::NT / 64) * 16 * B::tr_stride;
-                    static bool bf_attr = false;
-                    if (!bf_attr) {
+                    static DevOnce bf_attr;
+                    if (bf_attr.need()) {
                         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter<F, D, true, XP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
                         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter<F, D, false, XP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
-                        bf_attr = true;
                     }
                     if (t + 1 == n_iters)
                         GNN_LAUNCH_SH("k_iter", (k_iter<F, D, true, XP, true>), 8 * tpx, G::NT,
@@ -2418,11 +2423,9 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
         const int nc = (int)pl->n_chunks;
         const int cpx = (nc + 7) / 8;
         const size_t ed_lds = (size_t)((G::ed_rec > 0 ? pl->edge_lds_rows : 0) * D + 4) * sizeof(float);
-        static bool edge_attr = false;
-        if (!edge_attr) {
+        static DevOnce edge_attr;
+        if (edge_attr.need())
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_edge<F, D, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
-            edge_attr = true;
-        }
         GNN_LAUNCH_SH("k_edge", (k_edge<F, D, XP>), 8 * cpx, G::NT, ed_lds, s, pl->chunks, pl->src, pl->dst, pl->sd16, w.Pc,
                    w.Qc, w.table, e_out, Np, cpx, nc);
     }

@@ -170,26 +170,77 @@ class HitGraphBatch:
 
     # -- constructors ------------------------------------------------------------------
     @classmethod
-    def from_graphs(cls, graphs):
-        """Index-form batcher: block-diagonal concatenation, no padding.
+    def from_graphs(cls, graphs, pad_segments=False):
+        """Index-form batcher: block-diagonal concatenation.
 
         Replaces the zero-padding `merge_graphs` (reference
         gnn/trainSegmentClassifier.py:66-95): batch composition order is the list
         order (`graphs[j:j+batch_size]`, :103-104), features cast to float32 (:38-44).
+        `pad_segments=False`: no padding at all (scores [E_total]).
+        `pad_segments=True`: every graph's segment list is padded to the batch's E_max with
+        `src = dst = -1` columns and `dense_shape = (B, N_max, E_max)` is set, so the model
+        returns the reference's [B, E_max] layout (padded columns score sigmoid(W2 tanh(b1) + b2)
+        and carry target 0, exactly like merge_graphs' zero columns); hits are never padded.
         """
-        hit_ptr = np.zeros(len(graphs) + 1, dtype=np.int64)
-        seg_ptr = np.zeros(len(graphs) + 1, dtype=np.int64)
+        B = len(graphs)
+        hit_ptr = np.zeros(B + 1, dtype=np.int64)
+        seg_ptr = np.zeros(B + 1, dtype=np.int64)
+        e_max = max((int(np.asarray(g.src).shape[0]) for g in graphs), default=0)
         for i, g in enumerate(graphs):
             hit_ptr[i + 1] = hit_ptr[i] + g.X.shape[0]
-            seg_ptr[i + 1] = seg_ptr[i] + g.src.shape[0]
+            seg_ptr[i + 1] = seg_ptr[i] + (e_max if pad_segments else g.src.shape[0])
         X = np.concatenate([np.asarray(g.X, dtype=np.float32) for g in graphs])
-        src = np.concatenate([np.asarray(g.src, dtype=np.int64) + hit_ptr[i]
-                              for i, g in enumerate(graphs)])
-        dst = np.concatenate([np.asarray(g.dst, dtype=np.int64) + hit_ptr[i]
-                              for i, g in enumerate(graphs)])
         ys = [getattr(g, "y", None) for g in graphs]
-        y = None if any(v is None for v in ys) else np.concatenate(ys)
-        return cls(X, src, dst, y=y, hit_ptr=hit_ptr, seg_ptr=seg_ptr)
+        have_y = not any(v is None for v in ys)
+
+        def cat(field, offset):
+            parts = []
+            for i, g in enumerate(graphs):
+                a = np.asarray(getattr(g, field), dtype=np.int64)
+                a = np.where(a >= 0, a + (hit_ptr[i] if offset else 0), -1)
+                if pad_segments and a.shape[0] < e_max:
+                    a = np.concatenate([a, np.full(e_max - a.shape[0], -1, dtype=np.int64)])
+                parts.append(a)
+            return np.concatenate(parts) if parts else np.zeros(0, np.int64)
+
+        src, dst = cat("src", True), cat("dst", True)
+        y = None
+        if have_y:
+            parts = []
+            for v in ys:
+                v = np.asarray(v, dtype=np.float32)
+                if pad_segments and v.shape[0] < e_max:
+                    v = np.concatenate([v, np.zeros(e_max - v.shape[0], np.float32)])
+                parts.append(v)
+            y = np.concatenate(parts) if parts else np.zeros(0, np.float32)
+        dense_shape = None
+        if pad_segments:
+            n_max = max((int(g.X.shape[0]) for g in graphs), default=0)
+            dense_shape = (B, n_max, e_max)
+        return cls(X, src, dst, y=y, hit_ptr=hit_ptr, seg_ptr=seg_ptr, dense_shape=dense_shape)
+
+    def to_padded(self, flat, fill=0.0):
+        """[E_total] values in this batch's segment order -> [B, E_max] (the reference's target /
+        score layout, gnn/trainSegmentClassifier.py:86,110); `fill` in the padded entries."""
+        if self.dense_shape is not None:
+            return flat.reshape(self.dense_shape[0], self.dense_shape[2])
+        counts = np.diff(self.seg_ptr)
+        B, e_max = self.n_graphs, int(counts.max(initial=0))
+        out = flat.new_full((B, e_max), fill) if torch.is_tensor(flat) else np.full((B, e_max), fill,
+                                                                                 dtype=np.asarray(flat).dtype)
+        for i in range(B):
+            out[i, :counts[i]] = flat[self.seg_ptr[i]:self.seg_ptr[i + 1]]
+        return out
+
+    def from_padded(self, padded, counts=None):
+        """[B, E_max] -> flat values of the real segments, graph by graph (`counts`: segments per
+        graph; default: this batch's own when it is unpadded)."""
+        if counts is None:
+            if self.dense_shape is not None:
+                raise ValueError("a padded batch does not know its graphs' true segment counts")
+            counts = np.diff(self.seg_ptr)
+        parts = [padded[i, :int(c)] for i, c in enumerate(counts)]
+        return torch.cat(parts) if torch.is_tensor(padded) else np.concatenate(parts)
 
     @classmethod
     def from_sparse_arrays(cls, X, Ri_rows, Ri_cols, Ro_rows, Ro_cols, y=None):
@@ -227,11 +278,16 @@ class HitGraphBatch:
 
     @classmethod
     def from_npz(cls, filename):
-        """Read one graph file written by the reference's `save_graph` (gnn/graph.py:179-194)."""
+        """Read one graph file written by the reference's `save_graph` (gnn/graph.py:179-194) or its
+        muon variant (gnn/Muon_graph.py:198-217, `SparseGraphProp`: + `pt`, `eta`)."""
         with np.load(filename) as f:  # allow_pickle stays False
-            return cls.from_sparse_arrays(f["X"], f["Ri_rows"], f["Ri_cols"],
-                                          f["Ro_rows"], f["Ro_cols"],
-                                          y=f["y"] if "y" in f.files else None)
+            b = cls.from_sparse_arrays(f["X"], f["Ri_rows"], f["Ri_cols"],
+                                       f["Ro_rows"], f["Ro_cols"],
+                                       y=f["y"] if "y" in f.files else None)
+            # the muon writer adds the generated muon's pt and eta (gnn/Muon_graph.py:198-205)
+            b.pt = float(f["pt"]) if "pt" in f.files else None
+            b.eta = float(f["eta"]) if "eta" in f.files else None
+            return b
 
     @classmethod
     def from_dense(cls, X, Ri, Ro, y=None):
@@ -279,6 +335,7 @@ class HitGraphBatch:
             self._csr = tuple(a.to(device) for a in self._csr)
         if self.plan is not None:
             self.plan.to(device)
+        self._gstruct = None         # cached C struct of raw device pointers (_lib.cached_graph_struct)
         return self
 
     def cuda(self, device=None):

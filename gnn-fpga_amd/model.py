@@ -138,6 +138,73 @@ def _require_tanh(act):
             "reference uses Tanh); got %r" % (act,))
 
 
+def compact_dead_units(weights, F, D, allowed_dims):
+    """Structured-pruning specialisation: drop the units a mask has killed entirely.
+
+    The reference's masks (gnn/model.py:14-33; built from |W| > threshold in
+    gnn/MPNN_Seg_ACTS_maskedlinear.ipynb cells 21-22, 34) zero individual weights; when a whole ROW
+    or COLUMN goes - rows 3 and 4 of the first edge layer in that notebook's own pruned model - a
+    unit is dead and a narrower network computes the same function:
+
+      edge hidden unit i   W2[0,i] = 0 -> dropped;  W1[i,:] = 0 -> the constant W2[0,i] tanh(b1[i]),
+                           folded into b2
+      node hidden unit i   W4[:,i] = 0 -> dropped;  W3[i,:] = 0 -> W4[:,i] tanh(b3[i]) folded into b4
+      hit feature k        columns k, C+k of W1 and k, C+k, 2C+k of W3 all zero -> nobody reads
+                           H'_k: row k of W4 / Win and b4[k] / bin[k] dropped
+
+    The three widths are padded (with inert zero units) to the smallest hidden_dim D' in
+    `allowed_dims` that holds them all; the kernels of that narrower shape then run on weights
+    compacted here, on the host, once per weight version.  The dropped terms are exact zeros; the
+    folded constants move a sum by one rounding (1e-8).  `weights`: the ten EFFECTIVE tensors
+    (masks applied) in state_dict order.  Returns (weights', D', info) or None when nothing shrinks.
+    """
+    import numpy as np
+    dev = weights[0].device
+    Win, bin_, W1, b1, W2, b2, W3, b3, W4, b4 = [w.detach().cpu().double().numpy() for w in weights]
+    C = F + D
+    h_used = np.zeros(D, dtype=bool)
+    for k in range(D):
+        h_used[k] = (np.any(W1[:, k] != 0) or np.any(W1[:, C + k] != 0) or np.any(W3[:, k] != 0) or
+                     np.any(W3[:, C + k] != 0) or np.any(W3[:, 2 * C + k] != 0))
+    keep_h = np.flatnonzero(h_used)
+    e_const = ~np.any(W1 != 0, axis=1)                      # unit is tanh(b1_i) for every segment
+    e_drop = W2[0] == 0
+    keep_e = np.flatnonzero(~e_const & ~e_drop)
+    q_const = ~np.any(W3 != 0, axis=1)
+    q_drop = ~np.any(W4[keep_h] != 0, axis=0) if keep_h.size else np.ones(D, dtype=bool)
+    keep_q = np.flatnonzero(~q_const & ~q_drop)
+    need = max(len(keep_h), len(keep_e), len(keep_q), 1)
+    fits = [d for d in sorted(allowed_dims) if d >= need]
+    if not fits or fits[0] >= D:
+        return None
+    Dn = fits[0]
+    Cn = F + Dn
+    b2n = b2 + sum(W2[0, i] * np.tanh(b1[i]) for i in np.flatnonzero(e_const & ~e_drop))
+    b4n = b4 + sum(W4[:, i] * np.tanh(b3[i]) for i in np.flatnonzero(q_const & ~q_drop))
+
+    def cols(W, blocks):                      # remap the feature columns of every [H | X] block
+        out = np.zeros((W.shape[0], blocks * Cn))
+        for b in range(blocks):
+            out[:, b * Cn:b * Cn + len(keep_h)] = W[:, b * C + keep_h]
+            out[:, b * Cn + Dn:(b + 1) * Cn] = W[:, b * C + D:(b + 1) * C]
+        return out
+
+    def rows(A, keep):
+        out = np.zeros((Dn,) + A.shape[1:])
+        out[:len(keep)] = A[keep]
+        return out
+
+    W4n = np.zeros((Dn, Dn))
+    W4n[:len(keep_h), :len(keep_q)] = W4[np.ix_(keep_h, keep_q)]
+    W2n = np.zeros((1, Dn))
+    W2n[0, :len(keep_e)] = W2[0, keep_e]
+    new = [rows(Win, keep_h), rows(bin_, keep_h), rows(cols(W1, 2), keep_e), rows(b1, keep_e), W2n, b2n,
+           rows(cols(W3, 3), keep_q), rows(b3, keep_q), W4n, rows(b4n, keep_h)]
+    info = {"hidden_dim": Dn, "hit_features": len(keep_h), "edge_units": len(keep_e),
+            "node_units": len(keep_q)}
+    return [torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev) for a in new], Dn, info
+
+
 class SegmentClassifier(nn.Module):
     """Segment classification GNN (reference gnn/model.py:127-156), HIP forward."""
 
@@ -160,8 +227,10 @@ class SegmentClassifier(nn.Module):
         self.exp_product = True   # allow GNN_FLAG_EXP_PRODUCT when the bound check passes
         self.mlp_bf16 = False     # hidden_dim 32 / 64: hit update on the matrix cores (bf16 operands,
                                   # fp32 accumulate; scores move by ~1e-3 - opt-in, GNN_FLAG_BF16_MLP)
-        self._xp_cache = None     # (key, flag): the bound check synchronises, so it is cached
-        self._w_cache = None      # (key, weights, GnnParams): rebuilt when a parameter changes
+        self.prune_dead_units = True   # masked models: run the narrower kernels when the masks kill
+                                       # whole units (compact_dead_units; inference paths only)
+        self._xp_cache = None     # (key, flag): the last exp-product decision (kept on the plan)
+        self._w_cache = None      # (key, weights, GnnParams, D_run, info): rebuilt when a parameter changes
 
     def effective_weights(self):
         """The ten tensors the kernels consume, in state_dict order, masks applied."""
@@ -177,23 +246,49 @@ class SegmentClassifier(nn.Module):
                 tuple((l.mask_flag, id(l.mask)) for l in layers))
 
     def _cached_weights(self):
+        """(weights, GnnParams, D_run): the tensors the inference kernels consume and the hidden_dim
+        they run at - the module's own, or the narrower one left after `compact_dead_units` when
+        masks are set.  Rebuilt when `_param_key()` changes; in-place edits through `.data` (of a
+        weight or of a mask tensor) do not change the key: call `invalidate()` after those."""
         key = self._param_key()
         if self._w_cache is None or self._w_cache[0] != key:
-            w = self.effective_weights()
-            self._w_cache = (key, w, _lib.params_struct(w, self.input_dim, self.hidden_dim))
-        return self._w_cache[1], self._w_cache[2]
+            w, D_run, info = self.effective_weights(), self.hidden_dim, None
+            layers = [self.edge_network.network[0], self.edge_network.network[2],
+                      self.node_network.network[0], self.node_network.network[2]]
+            if self.prune_dead_units and any(l.mask_flag for l in layers) and w[0].is_cuda:
+                dims = [d for d in (4, 8, 16, 32, 64) if d < self.hidden_dim and
+                        _lib.plan_shape_supported(self.input_dim, d)]
+                hit = compact_dead_units(w, self.input_dim, self.hidden_dim, dims) if dims else None
+                if hit is not None:
+                    w, D_run, info = hit
+            self._w_cache = (key, w, _lib.params_struct(w, self.input_dim, D_run), D_run, info)
+        return self._w_cache[1], self._w_cache[2], self._w_cache[3]
+
+    def invalidate(self):
+        """Forget the cached effective weights (and the pruned specialisation derived from them)."""
+        self._w_cache = None
+
+    def pruned_info(self):
+        """None, or what `compact_dead_units` left: {'hidden_dim', 'hit_features', 'edge_units',
+        'node_units'} (evaluates the cache for the current weights)."""
+        self._cached_weights()
+        return self._w_cache[4]
 
     def _exp_product_flag(self, plan, weights):
         """GNN_FLAG_EXP_PRODUCT iff max|P'|, |Q'| <= 60 is PROVEN for these weights and this
-        batch's feature range (include/gnn_hip.h).  Re-evaluated only when a parameter changed
-        in place (tensor._version), was replaced, or another plan is used."""
+        batch's feature range (include/gnn_hip.h).  The decision is kept ON THE PLAN OBJECT (its
+        feature range is part of the bound; an id()-keyed cache would hand a freed plan's decision
+        to the next batch that reuses the id) and re-evaluated when a parameter changed in place
+        (tensor._version), was replaced, or (un)masked."""
         if not self.exp_product:
             return 0
-        key = (id(plan),) + self._param_key()
-        if self._xp_cache is None or self._xp_cache[0] != key:
+        key = self._param_key()
+        cached = getattr(plan, "_xp", None)
+        if cached is None or cached[0] is not self or cached[1] != key:
             bound = _lib.exp_product_bound(weights, self.input_dim, self.hidden_dim, plan.x_absmax)
-            self._xp_cache = (key, _lib.GNN_FLAG_EXP_PRODUCT if bound <= 60.0 else 0)
-        return self._xp_cache[1]
+            cached = plan._xp = (self, key, _lib.GNN_FLAG_EXP_PRODUCT if bound <= 60.0 else 0)
+        self._xp_cache = (key, cached[2])       # last decision taken (tests / diagnostics)
+        return cached[2]
 
     def forward(self, inputs, trace=False):
         """Apply forward pass of the model: inputs = [X, Ri, Ro] or a HitGraphBatch."""
@@ -209,12 +304,17 @@ class SegmentClassifier(nn.Module):
         if not batch.X.is_cuda:
             raise _lib.GnnHipError("SegmentClassifier.forward needs tensors on a ROCm device; "
                                    "there is no CPU path")
+        if not _lib.shape_supported(F, D):
+            raise _lib.GnnHipError("no HIP kernel for input_dim=%d hidden_dim=%d" % (F, D))
+        if not trace:
+            # inference: cached effective weights; D = the hidden_dim the kernels run at (narrower
+            # than the module's when masks have killed whole units)
+            weights, pstruct, D = self._cached_weights()
         # small events (muon graphs): one launch, one workgroup per graph, everything in LDS
         # (up to ~1k graphs: beyond that the tiled pipeline's throughput wins, tools/latency_probe.py)
         lay = batch.event_layout() if (self.use_events and not trace and batch.n_graphs <= 1024 and
                                        _lib.shape_supported(F, D)) else None
         if lay is not None and _lib.events_supported(F, D, lay.max_hits, lay.max_segments):
-            weights, pstruct = self._cached_weights()
             e = _lib.segclf_forward_events(batch, lay, weights, F, D, self.n_iters, params=pstruct)
             if batch.dense_shape:
                 e = e.view(batch.dense_shape[0], batch.dense_shape[2])
@@ -224,12 +324,12 @@ class SegmentClassifier(nn.Module):
             plan = batch.build_plan(D)
             need = _lib.plan_workspace_bytes(plan.n_pad, plan.n_segments, F, D)
         else:
+            D = self.hidden_dim
             need = _lib.workspace_bytes(batch.n_hits, batch.n_segments, F, D)
         if (self._workspace is None or self._workspace.numel() < need or
                 self._workspace.device != batch.X.device):
             self._workspace = torch.empty(need, dtype=torch.uint8, device=batch.X.device)
         if fused:     # relabel + SELL-16 plan, fused iteration kernels (csrc/sell_pipeline.hip)
-            weights, pstruct = self._cached_weights()
             res = _lib.segclf_forward_plan(plan, weights, F, D, self.n_iters,
                                            workspace=self._workspace,
                                            flags=(self._exp_product_flag(plan, weights) |

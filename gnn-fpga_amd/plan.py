@@ -423,6 +423,10 @@ class SellPlan:
     def to(self, device):
         for k in self._TENSORS:
             setattr(self, k, getattr(self, k).to(device))
+        # cached C structs hold raw device pointers of the tensors just replaced
+        self._struct = None
+        self._ws_need = None
+        self._xp = None
         return self
 
     @property

@@ -135,12 +135,164 @@ def padded_batch(name, graphs, D, T, seed):
     save(name, **arrays)
 
 
+def pruned(name, graph, D, T, seed, dead_e, dead_q, dead_h):
+    """Masks that remove WHOLE units (the pattern of the reference's own pruned model: rows 3, 4 of
+    the first edge layer are zero in gnn/MPNN_Seg_ACTS_maskedlinear.ipynb cell 34):
+      dead_e  edge-network hidden units: half of them lose their ROW of the first edge layer (the
+              unit becomes the constant tanh(b1_i)), the other half their entry of the second
+      dead_q  node-network hidden units, same two ways (row of layer 0 / column of layer 2)
+      dead_h  hit features H'_k never read by any layer (their columns of both first layers)
+    plus the random element-wise masks of `make_reference(masked=True)` on what is left."""
+    F = graph.X.shape[1]
+    C = D + F
+    g = torch.Generator().manual_seed(20_000 + seed)
+    me = [(torch.rand(D, 2 * C, generator=g) < 0.8).float(), torch.ones(1, D)]
+    mn = [(torch.rand(D, 3 * C, generator=g) < 0.8).float(), (torch.rand(D, D, generator=g) < 0.9).float()]
+    for n, i in enumerate(dead_e):
+        if n % 2 == 0:
+            me[0][i, :] = 0
+        else:
+            me[1][0, i] = 0
+    for n, i in enumerate(dead_q):
+        if n % 2 == 0:
+            mn[0][i, :] = 0
+        else:
+            mn[1][:, i] = 0
+    for k in dead_h:
+        me[0][:, k] = 0
+        me[0][:, C + k] = 0
+        mn[0][:, k] = 0
+        mn[0][:, C + k] = 0
+        mn[0][:, 2 * C + k] = 0
+    torch.manual_seed(seed)
+    m = ref_model.SegmentClassifier(input_dim=F, hidden_dim=D, n_iters=T, masks_e=me, masks_n=mn)
+    X, Ri, Ro = (torch.from_numpy(a)[None] for a in synth.to_dense(graph))
+    out, es, H = run_traced(m, X, Ri, Ro)
+    save(name, X=graph.X, src=graph.src, dst=graph.dst, n_iters=np.int32(T), scores=out[0].numpy(),
+         e_trace=np.stack([e[0].numpy() for e in es]), H_trace=np.stack([h[0].numpy() for h in H]),
+         dead_e=np.asarray(dead_e, np.int32), dead_q=np.asarray(dead_q, np.int32),
+         dead_h=np.asarray(dead_h, np.int32), **pack_model(m, (me, mn)))
+
+
+def ref_written_files():
+    """Graph files written BY THE REFERENCE'S OWN WRITERS, and what its model scores on them.
+
+    tests/golden/ref_written/graph000000.npz       gnn/graph.py:179-181  save_graph((SparseGraph, segments), f)
+    tests/golden/ref_written/graph_muon_000000.npz gnn/Muon_graph.py:198-205 save_graph(graph, particle, f): + pt, eta
+    The SparseGraph comes from the reference's make_sparse_graph (Ri.nonzero(), gnn/graph.py:23-26) on
+    dense matrices filled by its rule (gnn/graph.py:132-135); expected scores: the reference model on
+    graph_from_sparse(load_graph(f, SparseGraph)) (gnn/graph.py:28-35,188-194)."""
+    import collections
+    import graph as ref_graph
+    import Muon_graph as ref_muon
+    d = os.path.join(OUT, "ref_written")
+    os.makedirs(d, exist_ok=True)
+    for kind, g, seed in (("sector", synth.layered_graph(120, 400, 3, seed=31), 31),
+                          ("muon", synth.muon_graph(7), 32)):
+        X, Ri, Ro = synth.to_dense(g, dtype=np.uint8)
+        if kind == "sector":
+            sp = ref_graph.make_sparse_graph(X, Ri, Ro, g.y)
+            fn = os.path.join(d, "graph000000")
+            ref_graph.save_graph((sp, None), fn)
+            back = ref_graph.load_graph(fn + ".npz", ref_graph.SparseGraph)
+            dense = ref_graph.graph_from_sparse(back)
+        else:
+            sp = ref_muon.make_sparse_graph(X, Ri, Ro, g.y)
+            fn = os.path.join(d, "graph_muon_000000")
+            particle = collections.namedtuple("P", ["vp_pt", "vp_eta"])(np.float32(23.5), np.float32(-1.7))
+            ref_muon.save_graph((sp, None), particle, fn)
+            back = ref_muon.load_graph(fn + ".npz", ref_muon.SparseGraphProp)
+            dense = ref_muon.graph_from_sparse_prop(back)
+        F = g.X.shape[1]
+        m, masks = make_reference(F, 8, 3, seed)
+        Xt, Rit, Rot = (torch.from_numpy(np.asarray(a, dtype=np.float32))[None]
+                        for a in (dense.X, dense.Ri, dense.Ro))
+        with torch.no_grad():
+            out = m([Xt, Rit, Rot])
+        save("refnpz_%s" % kind, filename=np.array(os.path.basename(fn) + ".npz"), n_iters=np.int32(3),
+             scores=out[0].numpy(), Ri=np.asarray(dense.Ri), Ro=np.asarray(dense.Ro), **pack_model(m, masks))
+        print("   wrote", fn + ".npz", sorted(np.load(fn + ".npz").files))
+
+
+def batch_generator_fixture(name, graphs, n_samples, batch_size, D, T, seed):
+    """What the reference's batch_generator hands the model, batch by batch
+    (gnn/trainSegmentClassifier.py:97-111): graphs[j:j+batch_size] densified by the IMPORTED
+    graph.graph_from_sparse (gnn/graph.py:28-35), merged by merge_graphs' rule (:66-95, restated
+    here line by line - the CLI module itself does not import: SURVEY 2 row 5), cast to float32
+    (:38-44); the reference model's scores [B, E_max] and BCELoss per batch."""
+    import graph as ref_graph
+    sparse = []
+    for g in graphs:
+        X, Ri, Ro = synth.to_dense(g, dtype=np.uint8)
+        sparse.append(ref_graph.make_sparse_graph(X, Ri, Ro, g.y))
+
+    def merge_graphs(gs):                                      # trainSegmentClassifier.py:66-95
+        if len(gs) == 1:
+            g = gs[0]
+            return g.X[None], g.Ri[None], g.Ro[None], g.y[None]
+        n_nodes = np.array([g.X.shape[0] for g in gs])
+        n_edges = np.array([g.y.shape[0] for g in gs])
+        bX = np.zeros((len(gs), n_nodes.max(), gs[0].X.shape[1]), dtype=np.float32)
+        bRi = np.zeros((len(gs), n_nodes.max(), n_edges.max()), dtype=np.uint8)
+        bRo = np.zeros((len(gs), n_nodes.max(), n_edges.max()), dtype=np.uint8)
+        by = np.zeros((len(gs), n_edges.max()), dtype=np.uint8)
+        for i, g in enumerate(gs):
+            bX[i, :n_nodes[i]] = g.X
+            bRi[i, :n_nodes[i], :n_edges[i]] = g.Ri
+            bRo[i, :n_nodes[i], :n_edges[i]] = g.Ro
+            by[i, :n_edges[i]] = g.y
+        return bX, bRi, bRo, by
+
+    F = graphs[0].X.shape[1]
+    m, masks = make_reference(F, D, T, seed)
+    arrays = dict(n_graphs=np.int32(len(graphs)), n_samples=np.int32(n_samples),
+                  batch_size=np.int32(batch_size), n_iters=np.int32(T), **pack_model(m, masks))
+    for i, sp in enumerate(sparse):
+        for k, v in sp._asdict().items():
+            arrays["s%d.%s" % (i, k)] = np.asarray(v)
+    for b, j in enumerate(np.arange(0, n_samples, batch_size)):     # :99-103
+        bg = [ref_graph.graph_from_sparse(g) for g in sparse[j:j + batch_size]]
+        bX, bRi, bRo, by = merge_graphs(bg)
+        to_t = lambda a: torch.from_numpy(a.astype(np.float32))     # :38-44
+        with torch.no_grad():
+            out = m([to_t(bX), to_t(bRi), to_t(bRo)])
+            loss = torch.nn.BCELoss()(out, to_t(by))
+        arrays["b%d.scores" % b] = out.numpy()
+        arrays["b%d.y" % b] = by.astype(np.float32)
+        arrays["b%d.loss" % b] = np.float32(loss.item())
+    arrays["n_batches"] = np.int32(b + 1)
+    save(name, **arrays)
+
+
+def round2():
+    """Fixtures added in round 2: whole-unit pruning, files written by the
+    reference's own writers, the batch generator's batches."""
+    pruned("pruned_units_d8_s0", synth.layered_graph(100, 250, 3, seed=0), D=8, T=4, seed=40,
+           dead_e=[1, 3, 4, 6], dead_q=[0, 2, 5, 7], dead_h=[2, 3, 5, 6])
+    pruned("pruned_units_d16_s0", synth.layered_graph(150, 500, 3, seed=1), D=16, T=2, seed=41,
+           dead_e=list(range(0, 16, 2)) + [1, 3], dead_q=list(range(1, 16, 2)) + [0],
+           dead_h=list(range(4, 13)))
+    pruned("pruned_units_muon_s0", synth.muon_graph(2), D=8, T=3, seed=42,
+           dead_e=[0, 2, 5, 7], dead_q=[1, 3, 4, 6], dead_h=[0, 1, 6, 7])
+    pruned("pruned_edge_only_d8_s0", synth.layered_graph(100, 250, 3, seed=2), D=8, T=3, seed=43,
+           dead_e=[3, 4], dead_q=[], dead_h=[])      # the notebook's own pattern: nothing to shrink to
+    ref_written_files()
+    batch_generator_fixture("batchgen_sector_b2", [synth.layered_graph(50 + 15 * i, 120 + 35 * i, 3, seed=50 + i)
+                                                   for i in range(5)], n_samples=5, batch_size=2, D=8, T=3, seed=13)
+    batch_generator_fixture("batchgen_muon_b4", [synth.muon_graph(20 + s) for s in range(8)],
+                            n_samples=8, batch_size=4, D=8, T=3, seed=14)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--with-c3-full", action="store_true",
                     help="also run the dense reference at N=10k,E=100k (about 25 s, 16 GB)")
+    ap.add_argument("--only-round2", action="store_true",
+                    help="write only the fixtures added in round 2 (the others are unchanged)")
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
+    if args.only_round2:
+        return round2()
     import io
     import contextlib
     with contextlib.redirect_stdout(io.StringIO()):   # Estimator prints the model
@@ -180,6 +332,7 @@ def main():
                      [synth.layered_graph(60 + 20 * i, 150 + 40 * i, 3, seed=20 + i)
                       for i in range(3)], D=8, T=2, seed=12)
     print("muon_batch4_train, sector_batch3_train written")
+    round2()
     if args.with_c3_full:
         g = synth.layered_graph(10000, 100000, 3, seed=0)
         m, masks = make_reference(3, 8, 3, 0)

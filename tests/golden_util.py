@@ -8,9 +8,13 @@ from gnn_fpga_amd import synth
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
-SINGLE = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
-                if "batch" not in p and "c3_full" not in p)
-BATCHES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*batch*.npz")))
+_ALL = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+# refnpz_*: scores for the files in ref_written/ (written by the reference's own save_graph);
+# batchgen_*: the reference batch generator's batches - both have their own tests
+SINGLE = [n for n in _ALL if "batch" not in n and "c3_full" not in n and not n.startswith("refnpz_")]
+BATCHES = [n for n in _ALL if "batch" in n and not n.startswith("batchgen_")]
+PRUNED = [n for n in _ALL if n.startswith("pruned_")]
+REF_WRITTEN = os.path.join(GOLDEN, "ref_written")
 
 
 class Fixture:

@@ -243,3 +243,24 @@ def test_csr_is_built_on_first_use_only():
     assert np.array_equal(inb.numpy(), src[ie.numpy()])
     assert np.all(np.diff(dst[ie.numpy()]) >= 0)            # grouped by end hit
     assert np.array_equal(b.out_nbr.numpy(), dst[b.out_eid.numpy()])
+
+
+def test_calls_refuse_tensors_of_another_device():
+    """_lib._on makes the tensors' device current for a call and refuses structs / tensors that
+    live elsewhere (a launch on device 0 with device-1 pointers is a GPU fault, not an exception)."""
+    import torch
+    from gnn_fpga_amd import _lib
+    with pytest.raises(_lib.GnnHipError):
+        _lib._on(torch.zeros(3))                                   # CPU tensor: no CPU path
+    g = _lib.GnnGraph()
+    g._device = torch.device("cuda", 1)
+    with pytest.raises(_lib.GnnHipError):
+        _lib._on(torch.device("cuda", 0), g)                       # struct built for another device
+    _lib._on(torch.device("cuda", 1), g)                           # same device: accepted (not entered)
+    # while a call on cuda:1 is in progress, a cuda:0 / CPU tensor is refused by _dev()
+    _lib._cur_dev = torch.device("cuda", 1)
+    try:
+        with pytest.raises(_lib.GnnHipError):
+            _lib._dev(torch.zeros(3), torch.float32, "x")
+    finally:
+        _lib._cur_dev = None

@@ -1,0 +1,109 @@
+"""Host-side checks (no GPU) of the two data formats either side of the hot path:
+
+* graph files written by the REFERENCE'S OWN writers (`graph.save_graph`, gnn/graph.py:179-181;
+  `Muon_graph.save_graph`, gnn/Muon_graph.py:198-205, with pt / eta) - tests/golden/ref_written/,
+  produced by oracle/gen_golden.py - through `HitGraphBatch.from_npz`;
+* the batches of the reference's `batch_generator` (gnn/trainSegmentClassifier.py:97-111), captured
+  by oracle/gen_golden.py through the imported `graph.graph_from_sparse` - `batchgen_*.npz` -
+  against `gnn_fpga_amd.batch_generator`: composition order, [B, E_max] targets, padding.
+"""
+import collections
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gnn_fpga_amd
+from gnn_fpga_amd import HitGraphBatch, synth
+from golden_util import GOLDEN, REF_WRITTEN
+from oracle import index_c
+
+SparseGraph = collections.namedtuple("SparseGraph", ["X", "Ri_rows", "Ri_cols", "Ro_rows", "Ro_cols", "y"])
+
+
+def _fx(name):
+    with np.load(os.path.join(GOLDEN, name + ".npz")) as f:
+        return {k: f[k] for k in f.files}
+
+
+def _sparse_graphs(d):
+    return [SparseGraph(*[d["s%d.%s" % (i, k)] for k in SparseGraph._fields])
+            for i in range(int(d["n_graphs"]))]
+
+
+@pytest.mark.parametrize("kind", ["sector", "muon"])
+def test_file_written_by_the_reference_loads_as_csr(kind):
+    d = _fx("refnpz_" + kind)
+    b = HitGraphBatch.from_npz(os.path.join(REF_WRITTEN, str(d["filename"])))
+    Ri, Ro = d["Ri"], d["Ro"]                     # the reference's graph_from_sparse of the same file
+    n, e = Ri.shape
+    assert (b.n_hits, b.n_segments) == (n, e)
+    # dense <-> index round trip (gnn/GraphConstructionDev_mu200.ipynb cells 41-44)
+    Ri_reco = np.zeros_like(Ri)
+    Ro_reco = np.zeros_like(Ro)
+    Ri_reco[b.dst.numpy(), np.arange(e)] = 1
+    Ro_reco[b.src.numpy(), np.arange(e)] = 1
+    assert (Ri_reco == Ri).all() and (Ro_reco == Ro).all()
+    # the file's order IS the CSR order (nonzero() is row-major): rowptr by bincount, no sort
+    in_ptr, in_eid = b.in_ptr.numpy(), b.in_eid.numpy()
+    for hit in range(n):
+        assert sorted(in_eid[in_ptr[hit]:in_ptr[hit + 1]]) == list(np.flatnonzero(Ri[hit]))
+    assert np.array_equal(b.in_nbr.numpy(), b.src.numpy()[in_eid])
+    assert np.array_equal(b.out_nbr.numpy(), b.dst.numpy()[b.out_eid.numpy()])
+    if kind == "muon":
+        assert b.n_features == 11 and abs(b.pt - 23.5) < 1e-6 and abs(b.eta + 1.7) < 1e-6
+    else:
+        assert b.pt is None and b.eta is None
+    # and the oracle on what was loaded reproduces the reference model's scores on that file
+    params = {k[2:]: v for k, v in d.items() if k.startswith("p.")}
+    ref = index_c.segment_classifier(b.X.numpy(), b.src.numpy(), b.dst.numpy(), params, int(d["n_iters"]))
+    assert np.abs(ref - d["scores"]).max() < 1e-5
+
+
+@pytest.mark.parametrize("name", ["batchgen_sector_b2", "batchgen_muon_b4"])
+@pytest.mark.parametrize("layout", ["padded", "flat"])
+def test_batch_generator_yields_the_reference_batches(name, layout):
+    d = _fx(name)
+    graphs = _sparse_graphs(d)
+    n_samples, bs, nb = int(d["n_samples"]), int(d["batch_size"]), int(d["n_batches"])
+    gen = gnn_fpga_amd.batch_generator(graphs, n_samples=n_samples, batch_size=bs, layout=layout)
+    params = {k[2:]: v for k, v in d.items() if k.startswith("p.")}
+    seen = []
+    for epoch in range(2):                        # the generator loops over epochs for ever
+        for b in range(nb):
+            batch, y = next(gen)
+            ref_y, ref_scores = d["b%d.y" % b], d["b%d.scores" % b]
+            members = graphs[b * bs:(b + 1) * bs]              # graphs[j:j+batch_size], :103-104
+            assert batch.n_graphs == len(members)
+            assert np.array_equal(batch.X.numpy(), np.concatenate([g.X for g in members]))
+            if layout == "padded":
+                assert tuple(y.shape) == ref_y.shape and y.dtype == torch.float32
+                assert np.array_equal(y.numpy(), ref_y)
+                assert batch.dense_shape[0] == ref_y.shape[0] and batch.dense_shape[2] == ref_y.shape[1]
+                want = ref_scores.reshape(-1)
+            else:
+                counts = [g.y.shape[0] for g in members]
+                assert np.array_equal(batch.to_padded(y).numpy(), ref_y)
+                assert torch.equal(batch.from_padded(batch.to_padded(y), counts), y)
+                want = np.concatenate([ref_scores[i, :c] for i, c in enumerate(counts)])
+            # the oracle on this batch's index form gives the reference's scores, padded columns too
+            # (the C oracle scores a padded column like the reference: sigmoid(W2 tanh(b1) + b2))
+            e = index_c.segment_classifier(batch.X.numpy(), batch.src.numpy(), batch.dst.numpy(),
+                                           params, int(d["n_iters"]))
+            assert np.abs(e - want).max() < 1e-5
+            seen.append(id(batch))
+    assert seen[:nb] == seen[nb:]                 # epochs reuse the batches (plans / CSRs with them)
+
+
+def test_padded_batch_from_hit_graphs_matches_the_dense_adapter():
+    graphs = [synth.muon_graph(s) for s in (3, 4, 5, 6)]
+    b = HitGraphBatch.from_graphs(graphs, pad_segments=True)
+    Nmax = max(g.X.shape[0] for g in graphs)
+    Emax = max(g.src.shape[0] for g in graphs)
+    assert b.dense_shape == (4, Nmax, Emax) and b.n_segments == 4 * Emax
+    for i, g in enumerate(graphs):
+        s = b.src.numpy()[i * Emax:(i + 1) * Emax]
+        assert np.array_equal(s[:g.src.shape[0]] - b.hit_ptr[i], g.src) and np.all(s[g.src.shape[0]:] == -1)
+    lay = b.event_layout()
+    assert lay is not None and lay.max_segments == Emax

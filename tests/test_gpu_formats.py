@@ -1,0 +1,72 @@
+"""GPU parity for the data formats either side of the hot path, through the
+C ABI: a graph file written by the reference's own `save_graph` -> `from_npz` -> HIP scores, and the
+reference batch generator's batches -> `gnn_fpga_amd.batch_generator` -> HIP scores [B, E_max] and
+the reference's BCELoss over all B x E_max entries.  Expected values: oracle/gen_golden.py (the
+imported reference)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gnn_fpga_amd
+from gnn_fpga_amd import HitGraphBatch
+from golden_util import REF_WRITTEN
+from test_batcher_host import _fx, _sparse_graphs
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5          # north_star: edge scores within 1e-5 of the CPU reference
+
+
+def _model(d, F, dev="cuda"):
+    from gnn_fpga_amd.model import SegmentClassifier
+    params = {k[2:]: torch.from_numpy(v) for k, v in d.items() if k.startswith("p.")}
+    D = params["input_network.0.weight"].shape[0]
+    m = SegmentClassifier(input_dim=F, hidden_dim=D, n_iters=int(d["n_iters"]))
+    m.load_state_dict(params)
+    return m.to(dev)
+
+
+@pytest.mark.parametrize("kind", ["sector", "muon"])
+@pytest.mark.parametrize("route", ["events", "plan", "modules"])
+def test_npz_written_by_the_reference_to_scores(hip, kind, route):
+    d = _fx("refnpz_" + kind)
+    b = HitGraphBatch.from_npz(os.path.join(REF_WRITTEN, str(d["filename"]))).cuda()
+    m = _model(d, b.n_features).eval()
+    m.use_events, m.use_plan = route == "events", route != "modules"
+    with torch.no_grad():
+        e = m(b)
+    assert e.shape == (b.n_segments,)
+    assert np.abs(e.cpu().numpy() - d["scores"]).max() < TOL
+
+
+@pytest.mark.parametrize("name", ["batchgen_sector_b2", "batchgen_muon_b4"])
+def test_batch_generator_batches_score_like_the_reference(hip, name):
+    from gnn_fpga_amd.loss import BCELoss
+    d = _fx(name)
+    graphs = _sparse_graphs(d)
+    gen = gnn_fpga_amd.batch_generator(graphs, n_samples=int(d["n_samples"]),
+                                       batch_size=int(d["batch_size"]), device="cuda")
+    m = _model(d, graphs[0].X.shape[1]).eval()
+    for b in range(int(d["n_batches"])):
+        batch, y = next(gen)
+        assert y.is_cuda and batch.X.is_cuda
+        for events in (True, False):
+            m.use_events = events
+            with torch.no_grad():
+                out = m(batch)
+            assert tuple(out.shape) == d["b%d.scores" % b].shape                # [B, E_max]
+            assert np.abs(out.cpu().numpy() - d["b%d.scores" % b]).max() < TOL
+            # the reference's loss: BCELoss mean over ALL B x E_max entries, padded ones included
+            loss = BCELoss()(out, y)
+            assert abs(loss.item() - float(d["b%d.loss" % b])) < 1e-6
+    # flat layout: the same real-segment scores without any padding
+    gen = gnn_fpga_amd.batch_generator(graphs, n_samples=int(d["n_samples"]),
+                                       batch_size=int(d["batch_size"]), device="cuda", layout="flat")
+    batch, y = next(gen)
+    with torch.no_grad():
+        out = m(batch)
+    ref = d["b0.scores"]
+    counts = np.diff(batch.seg_ptr)
+    want = np.concatenate([ref[i, :c] for i, c in enumerate(counts)])
+    assert np.abs(out.cpu().numpy() - want).max() < TOL

@@ -268,6 +268,52 @@ def test_exp_product_bound_and_fallback(hip):
     assert not torch.equal(e, e_big)
 
 
+def test_exp_product_decision_belongs_to_the_batch_not_to_a_recycled_id(hip):
+    """An inference loop `model(HitGraphBatch.from_graphs(g).to(dev))` frees every plan after its
+    forward, and CPython hands the freed object's id() to the next one: the exp-product decision
+    (taken from the batch's |X| range) must not travel with the id.  A small-|X| batch, freed, then
+    a batch whose features make 2^P' overflow: the exact kernels must run and match the oracle."""
+    from gnn_fpga_amd.model import SegmentClassifier
+    torch.manual_seed(3)
+    m = SegmentClassifier(input_dim=3, hidden_dim=8, n_iters=2).cuda().eval()
+    m.use_events = False
+    params = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    small = synth.layered_graph(300, 1500, 3, seed=9)
+    big = synth.HitGraph(small.X * 400.0, small.src, small.dst, small.y)     # |X| up to 400
+    seen = []
+    with torch.no_grad():
+        for _ in range(4):                       # ids of freed plans get reused within a few rounds
+            for g, want in ((small, hip.GNN_FLAG_EXP_PRODUCT), (big, 0)):
+                e = m(HitGraphBatch.from_graphs([g]).cuda())
+                seen.append(m._xp_cache[1])
+                assert m._xp_cache[1] == want
+                ref = index_c.segment_classifier(g.X, g.src, g.dst, params, 2)
+                assert np.abs(e.cpu().numpy() - ref).max() < TOL
+    assert seen == [hip.GNN_FLAG_EXP_PRODUCT, 0] * 4
+
+
+def test_batch_moved_between_devices_rebuilds_its_cached_structs(hip):
+    """cuda -> cpu -> cuda: the cached C structs hold raw device pointers of tensors that no longer
+    exist; HitGraphBatch.to() / SellPlan.to() must drop them."""
+    from gnn_fpga_amd.model import SegmentClassifier
+    torch.manual_seed(2)
+    m = SegmentClassifier(input_dim=3, hidden_dim=8, n_iters=2).cuda().eval()
+    graphs = [synth.layered_graph(500, 3000, 3, seed=70 + i) for i in range(3)]
+    for events in (False, True):
+        m.use_events = events
+        b = HitGraphBatch.from_graphs(graphs if not events else
+                                      [synth.layered_graph(40, 120, 3, seed=5)]).cuda()
+        with torch.no_grad():
+            e1 = m(b).clone()
+            b.to("cpu")
+            junk = [torch.empty(1 << 20, device="cuda") for _ in range(8)]   # reuse the freed blocks
+            for j in junk:
+                j.fill_(-1.0)
+            b.to("cuda")
+            e2 = m(b)
+        assert torch.equal(e1, e2)
+
+
 def _random_graph(n, e, F, seed, self_loops=True):
     """Not layered: arbitrary endpoints, multi-edges, cycles and (optionally) self loops."""
     rng = np.random.default_rng(seed)
