@@ -49,6 +49,20 @@ class GnnPlan(ctypes.Structure):
                 ("max_list_steps", _i64)]
 
 
+class GnnPlanSizes(ctypes.Structure):
+    _fields_ = [(n, _i64) for n in ("n_pad", "n_tiles", "n_slices", "n_chunks", "in_total", "out_total",
+                                    "in16_words", "out16_words", "n_sched", "iter_lds_records",
+                                    "edge_lds_rows", "n_lds_tiles", "n_lds_chunks", "iter_lds_in",
+                                    "iter_lds_out", "tile_hits_max", "max_list_steps", "n_valid",
+                                    "max_level", "status")]
+
+
+class GnnPlanOut(ctypes.Structure):
+    _fields_ = [(n, _f) for n in ("X", "x_absmax", "src", "dst", "sd16", "in_off", "in_nbr", "out_off",
+                                  "out_nbr", "in_off16", "in_nbr16", "out_off16", "out_nbr16", "tiles",
+                                  "chunks", "sched_a", "sched_b", "perm", "src_abs", "dst_abs", "level")]
+
+
 # name -> (restype, argtypes); must list every function include/gnn_hip.h declares
 SIGNATURES = {
     "gnn_abi_version": (ctypes.c_int, []),
@@ -85,6 +99,11 @@ SIGNATURES = {
     "gnn_plan_shape_supported": (ctypes.c_int, [_i32, _i32]),
     "gnn_plan_limits": (ctypes.c_int, [_i32, _i32, ctypes.POINTER(_i32)]),
     "gnn_exp_product_bound": (ctypes.c_int, [ctypes.POINTER(GnnParams), _f, _f, _f]),
+    "gnn_plan_build_workspace_bytes": (_sz, [_i64, _i64, _i32]),
+    "gnn_plan_build_sizes": (ctypes.c_int, [_f, _f, _f, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _f, _sz,
+                                            _f, _f]),
+    "gnn_plan_build_fill": (ctypes.c_int, [_f, _i32, _f, _f, _i64, _i64, _i32, ctypes.POINTER(GnnPlanSizes),
+                                           _f, _sz, ctypes.POINTER(GnnPlanOut), _f]),
     "gnn_profile_begin": (ctypes.c_int, [_i32]),
     "gnn_profile_end": (ctypes.c_int, [ctypes.POINTER(ctypes.c_char_p),
                                        ctypes.POINTER(ctypes.c_float), _i32]),
@@ -483,6 +502,41 @@ def segclf_forward_plan(plan, weights, F, D, n_iters, out=None, workspace=None, 
                                               _dev(out, torch.float32, "out"),
                                               workspace.data_ptr(), workspace.numel(), st))
     return out
+
+
+def plan_build_workspace_bytes(n_hits, n_segments, chunk_segments):
+    return int(load().gnn_plan_build_workspace_bytes(n_hits, n_segments, chunk_segments))
+
+
+def plan_build_sizes(src, dst, hit_ptr, n_hits, n_segments, n_graphs, tile_hits, iter_records,
+                     chunk_segments, edge_records, workspace):
+    """Stage 1 of the GPU plan builder (csrc/plan_build.hip).  Returns a GnnPlanSizes read back from
+    the device - the ONE host synchronisation of a plan build."""
+    sizes = torch.zeros(ctypes.sizeof(GnnPlanSizes) // 8, dtype=torch.int64, device=src.device)
+    with _on(src) as st:
+        _check(load().gnn_plan_build_sizes(
+            _dev(src, torch.int32, "src"), _dev(dst, torch.int32, "dst"), _dev(hit_ptr, torch.int64, "hit_ptr"),
+            n_hits, n_segments, n_graphs, tile_hits, iter_records, chunk_segments, edge_records,
+            workspace.data_ptr(), workspace.numel(), sizes.data_ptr(), st))
+    host = sizes.cpu()
+    out = GnnPlanSizes()
+    ctypes.memmove(ctypes.byref(out), host.data_ptr(), ctypes.sizeof(GnnPlanSizes))
+    return out
+
+
+def plan_build_fill(X, src, dst, n_hits, n_segments, chunk_segments, sizes, workspace, arrays):
+    """Stage 2: `arrays` maps the GnnPlanOut field names to the tensors to fill (src_abs, dst_abs,
+    level optional)."""
+    out = GnnPlanOut()
+    with _on(X) as st:
+        for name, _ in GnnPlanOut._fields_:
+            t = arrays.get(name)
+            if t is not None:
+                setattr(out, name, _dev(t, torch.float32 if name in ("X", "x_absmax") else torch.int32, name))
+        _check(load().gnn_plan_build_fill(
+            _dev(X, torch.float32, "X"), X.shape[1], _dev(src, torch.int32, "src"),
+            _dev(dst, torch.int32, "dst"), n_hits, n_segments, chunk_segments, ctypes.byref(sizes),
+            workspace.data_ptr(), workspace.numel(), ctypes.byref(out), st))
 
 
 class profile:

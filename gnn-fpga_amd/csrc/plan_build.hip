@@ -1,0 +1,1055 @@
+// plan_build.hip - the execution plan of the fused pipeline (gnn-fpga_amd/plan.py), built on the GPU.
+//
+// What it replaces: the reference builds every batch on the host - graph_from_sparse densifies each
+// graph into two [N, E] matrices and merge_graphs zero-pads them (gnn/graph.py:28-35,
+// gnn/trainSegmentClassifier.py:66-111).  The index-form counterpart of that per-batch work is the
+// plan of plan.py (levels, tiles, windows, SELL-16 lists, wave schedules, edge chunks).  plan.py is
+// the specification (numpy); plan_device.py runs the same recipe as ~300 torch ops (0.2 s for
+// 25.6 M segments); this file is the same plan, ARRAY FOR ARRAY, as a few dozen HIP kernels:
+//
+//   degrees (atomics) -> topological levels (Jacobi sweeps with early exit, same fixpoint and the
+//   same 64-sweep cap as plan.topological_levels) -> hits sorted by (graph, level, -in, -out)
+//   [radix sort] -> (graph, level) units -> tiles (the sequential greedy packing, one thread,
+//   units staged through LDS) -> degree sort inside tiles [radix sort] -> padded new ids ->
+//   segments sorted by end / start hit [2 radix sorts of (key, other end) pairs: a hit's
+//   neighbours come out contiguous, in ascending segment order] -> windows per tile -> SELL-16
+//   slice lengths and offsets [one scan of 4-vectors] -> edge chunks (run detection, marks, equal
+//   parts) and their windows -> sizes.              (gnn_plan_build_sizes, one host read-back)
+//   Then, into arrays the caller allocates from those sizes: lists (32-bit and 16-bit packed),
+//   tile / chunk descriptors, wave schedules (the two-phase greedy of plan.py in float64, one
+//   wavefront per tile), renumbered X, endpoints.              (gnn_plan_build_fill)
+//
+// Device-wide radix sorts and scans are rocPRIM's (plain library primitives, like a library GEMM);
+// everything else is hand-written.  All kernels are grid-stride on bounded grids (an early-exit
+// sweep costs a launch, not a dispatch of 100 k idle workgroups).  Integer work: bit-exact against
+// plan.py (tests/test_plan_hip.py compares every array).
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "common.h"
+
+namespace {
+using namespace gnn;
+
+constexpr int TB = 256;
+constexpr int SLICE = 16;
+constexpr int kMaxLevelIters = 64;     // plan.topological_levels(max_iter=64)
+constexpr int kMaxSlicesPerTile = 128; // tile_hits <= 2048
+
+inline unsigned gs(int64_t n)
+{
+    int64_t g = (n + TB - 1) / TB;
+    return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+#define GS_LOOP(I, N) \
+    for (int64_t I = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; I < (N); I += (int64_t)gridDim.x * blockDim.x)
+
+// device header (int64 slots) - counts that later kernels read and the final sizes are made from
+enum Hdr {
+    H_NVALID, H_NUNITS, H_NTILES, H_NPAD, H_TILEMAX, H_NSCHED, H_NRUNS, H_NMARKS, H_NCHUNKS, H_STATUS,
+    H_LDSREC, H_NLDSTILES, H_LDSIN, H_LDSOUT, H_EDGEROWS, H_NLDSCHUNKS, H_MAXSTEPS, H_MAXLEVEL, H_COUNT = 32
+};
+enum Status { ST_OK = 0, ST_DEGREE = 1, ST_TILES = 2, ST_PAD = 4, ST_CHUNKS = 8, ST_SLICES = 16, ST_I32 = 32 };
+
+struct I2 { int a, b; };
+struct I4 { int a, b, c, d; };
+struct PlusI2 { __host__ __device__ I2 operator()(const I2 &x, const I2 &y) const { return {x.a + y.a, x.b + y.b}; } };
+struct PlusI4 {
+    __host__ __device__ I4 operator()(const I4 &x, const I4 &y) const { return {x.a + y.a, x.b + y.b, x.c + y.c, x.d + y.d}; }
+};
+
+// ---- workspace ------------------------------------------------------------------------------------
+struct Bounds { int64_t nt_max, np_max, ns_max, m_max, c_max; };
+inline Bounds bounds_of(int64_t n, int64_t E, int CH)
+{
+    Bounds b;
+    b.nt_max = n / 16 + 1024;               // average tile of >= 16 hits, else ST_TILES (caller falls back)
+    b.np_max = n + 15 * b.nt_max;
+    b.np_max = (b.np_max + 15) / 16 * 16;
+    b.ns_max = b.np_max / 16;
+    b.m_max = 8 * (E / (CH > 0 ? CH : 1)) + 16;        // marks: two per run of >= CH/4 segments
+    b.c_max = 9 * (E / (CH > 0 ? CH : 1)) + 32;        // chunks: one per CH segments + one per mark
+    return b;
+}
+
+struct Ws {
+    int64_t *hdr;
+    int *chg;                                  // [kMaxLevelIters] "this sweep raised a level"
+    // hits
+    int *deg_in, *deg_out, *gid, *lvA, *lvB, *down, *iota, *base, *oor, *tpos, *uflag, *uscan, *ustart, *inv;
+    unsigned long long *k64a, *k64b;
+    // tiles
+    int *tile_bounds, *tpad_off, *sbase, *t_desc;      // t_desc: [nt_max][8]
+    // padded hits / slices
+    I2 *degn, *ptr;                            // (in, out) degree and CSR pointer per new id
+    I4 *sl4, *off4;                            // per slice: (16 steps_in, 16 steps_out, 16 ceil8 in, 16 ceil8 out), scanned
+    // segments
+    int *src_new, *dst_new, *kscr, *sv_in, *sv_out, *c_scan, *rb;
+    int *mscan, *marks, *parts, *pscan, *cb, *c_desc;  // c_desc: [c_max][8]
+    void *temp;
+    size_t temp_bytes;
+    size_t bytes;
+};
+
+size_t rocprim_temp_bytes(int64_t n, int64_t E, const Bounds &b)
+{
+    size_t m = 0, t = 0;
+    auto up = [&](size_t x) { if (x > m) m = x; };
+    (void)rocprim::radix_sort_pairs(nullptr, t, (const unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                                    (const int *)nullptr, (int *)nullptr, (size_t)n, 0u, 64u, (hipStream_t)0, false);
+    up(t);
+    (void)rocprim::radix_sort_pairs(nullptr, t, (const int *)nullptr, (int *)nullptr, (const int *)nullptr,
+                                    (int *)nullptr, (size_t)E, 0u, 32u, (hipStream_t)0, false);
+    up(t);
+    (void)rocprim::exclusive_scan(nullptr, t, (const int *)nullptr, (int *)nullptr, 0, (size_t)(E > n ? E : n) + 1,
+                                  rocprim::plus<int>(), (hipStream_t)0, false);
+    up(t);
+    (void)rocprim::inclusive_scan(nullptr, t, (const int *)nullptr, (int *)nullptr, (size_t)E + 1,
+                                  rocprim::maximum<int>(), (hipStream_t)0, false);
+    up(t);
+    (void)rocprim::exclusive_scan(nullptr, t, (const I2 *)nullptr, (I2 *)nullptr, I2{0, 0}, (size_t)b.np_max + 1, PlusI2(),
+                                  (hipStream_t)0, false);
+    up(t);
+    (void)rocprim::exclusive_scan(nullptr, t, (const I4 *)nullptr, (I4 *)nullptr, I4{0, 0, 0, 0}, (size_t)b.ns_max + 1,
+                                  PlusI4(), (hipStream_t)0, false);
+    up(t);
+    return m + 256;
+}
+
+Ws carve(char *p, int64_t n, int64_t E, int CH)
+{
+    const Bounds b = bounds_of(n, E, CH);
+    Ws w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char *q = p ? p + off : nullptr;
+        off += align256(bytes);
+        return q;
+    };
+    auto ints = [&](int64_t k) { return reinterpret_cast<int *>(take((size_t)k * sizeof(int))); };
+    w.hdr = reinterpret_cast<int64_t *>(take(H_COUNT * sizeof(int64_t)));
+    w.chg = ints(kMaxLevelIters + 2);
+    w.deg_in = ints(n); w.deg_out = ints(n);                    // (one memset clears hdr .. lvB)
+    w.lvA = ints(n); w.lvB = ints(n);
+    w.gid = ints(n); w.down = ints(n);
+    w.iota = ints(n); w.base = ints(n); w.oor = ints(n); w.tpos = ints(n); w.uflag = ints(n + 1); w.uscan = ints(n + 1);
+    w.ustart = ints(n + 2); w.inv = ints(n + 1);
+    w.k64a = reinterpret_cast<unsigned long long *>(take((size_t)n * 8));
+    w.k64b = reinterpret_cast<unsigned long long *>(take((size_t)n * 8));
+    w.tile_bounds = ints(b.nt_max + 2); w.tpad_off = ints(b.nt_max + 2); w.sbase = ints(b.nt_max + 2);
+    w.t_desc = ints((b.nt_max + 1) * 8);
+    w.degn = reinterpret_cast<I2 *>(take((size_t)(b.np_max + 1) * sizeof(I2)));
+    w.ptr = reinterpret_cast<I2 *>(take((size_t)(b.np_max + 1) * sizeof(I2)));
+    w.sl4 = reinterpret_cast<I4 *>(take((size_t)(b.ns_max + 1) * sizeof(I4)));
+    w.off4 = reinterpret_cast<I4 *>(take((size_t)(b.ns_max + 1) * sizeof(I4)));
+    w.src_new = ints(E); w.dst_new = ints(E); w.kscr = ints(E + 1); w.sv_in = ints(E); w.sv_out = ints(E);
+    w.c_scan = ints(E + 1); w.rb = ints(E + 2);
+    w.mscan = ints(E + 1);
+    w.marks = ints(b.m_max + 2); w.parts = ints(b.m_max + 2); w.pscan = ints(b.m_max + 2);
+    w.cb = ints(b.c_max + 2); w.c_desc = ints((b.c_max + 1) * 8);
+    w.temp_bytes = rocprim_temp_bytes(n, E, b);
+    w.temp = take(w.temp_bytes);
+    w.bytes = off;
+    return w;
+}
+
+__device__ __forceinline__ void set_status(int64_t *hdr, int bit)
+{
+    atomicOr(reinterpret_cast<unsigned long long *>(hdr + H_STATUS), (unsigned long long)bit);
+}
+__device__ __forceinline__ void hdr_max(int64_t *hdr, int slot, long long v)     // v >= 0
+{
+    atomicMax(reinterpret_cast<unsigned long long *>(hdr + slot), (unsigned long long)v);
+}
+__device__ __forceinline__ void hdr_add(int64_t *hdr, int slot, long long v)
+{
+    atomicAdd(reinterpret_cast<unsigned long long *>(hdr + slot), (unsigned long long)v);
+}
+
+// ---- stage 1 kernels ------------------------------------------------------------------------------
+__global__ __launch_bounds__(TB) void pb_degrees(const int *__restrict__ src, const int *__restrict__ dst, int64_t E,
+                                                 int *deg_in, int *deg_out, int64_t *hdr)
+{
+    int cnt = 0;
+    GS_LOOP(j, E) {
+        const int s = src[j];
+        if (s >= 0) {
+            atomicAdd(&deg_out[s], 1);
+            atomicAdd(&deg_in[dst[j]], 1);
+            ++cnt;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if ((threadIdx.x & 63) == 0 && cnt) hdr_add(hdr, H_NVALID, cnt);
+}
+
+// gid[i] = number of interior graph boundaries hit_ptr[1..G-1] that are <= i   (plan.py: add.at + cumsum)
+__global__ __launch_bounds__(TB) void pb_gid(const int64_t *__restrict__ hit_ptr, int64_t G, int64_t n, int *gid)
+{
+    GS_LOOP(i, n) {
+        int64_t lo = 1, hi = G;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (hit_ptr[mid] <= i) lo = mid + 1; else hi = mid;
+        }
+        gid[i] = (int)(lo - 1);
+    }
+}
+
+// Sweep t (1-based) of the Jacobi longest-path relaxation of plan.topological_levels, IN PLACE and
+// without atomics.  From an all-zero start the Jacobi iterate is level_t[v] = min(t, longest walk
+// ending at v): sweep t changes exactly the hits that go from t-1 to t, those with a segment from a
+// hit that stood at t-1 - and a hit below t-1 at the start of sweep t never changes again.  So
+// "level[s] >= t-1 -> level[d] = t" on ONE buffer is the Jacobi sweep: every writer stores the same
+// value, and a reader that sees a start hit already raised to t draws the same conclusion as one
+// that sees t-1.  (Values only come from earlier launches or are this very t: no stale-cache case.)
+// A sweep that stored nothing (chg[t] == 0) found the fixpoint; all later sweeps return at once.
+__global__ __launch_bounds__(TB) void pb_level_sweep(const int *__restrict__ src, const int *__restrict__ dst, int64_t E,
+                                                     int *level, int *chg, int t)
+{
+    if (t > 1 && chg[t - 1] == 0) return;
+    int any = 0;
+    GS_LOOP(j, E) {
+        const int s = src[j];
+        if (s < 0) continue;
+        if (level[s] >= t - 1) {
+            level[dst[j]] = t;
+            any = 1;
+        }
+    }
+    if (__any(any) && (threadIdx.x & 63) == 0 && chg[t] == 0) chg[t] = 1;
+}
+
+// Small batches: all sweeps in ONE launch by one workgroup (its waves share the CU's L1, so a
+// workgroup barrier orders the stores of sweep t before the loads of sweep t + 1) - 64 launches
+// would cost more than the sweeps themselves.
+constexpr int64_t kSmallSweepSegments = 1 << 15;   // (100 k segments: 0.69 ms in one workgroup, 0.41 ms as 64 launches)
+__global__ __launch_bounds__(1024) void pb_levels_small(const int *__restrict__ src, const int *__restrict__ dst, int E,
+                                                        int *level)
+{
+    for (int t = 1; t <= kMaxLevelIters; ++t) {
+        int any = 0;
+        for (int j = threadIdx.x; j < E; j += 1024) {
+            const int s = src[j];
+            if (s >= 0 && level[s] >= t - 1) {
+                level[dst[j]] = t;
+                any = 1;
+            }
+        }
+        if (!__syncthreads_or(any)) break;
+    }
+}
+
+__global__ __launch_bounds__(TB) void pb_fill_i32(int *a, int64_t n, int v) { GS_LOOP(i, n) a[i] = v; }
+
+// (only hits without incoming segments use it: one segment in ten of a layered graph)
+__global__ __launch_bounds__(TB) void pb_down(const int *__restrict__ src, const int *__restrict__ dst, int64_t E,
+                                              const int *__restrict__ level, const int *__restrict__ deg_in, int *down)
+{
+    GS_LOOP(j, E) {
+        const int s = src[j];
+        if (s >= 0 && deg_in[s] == 0) atomicMin(&down[s], level[dst[j]]);
+    }
+}
+
+// hits without incoming segments sit one level below their nearest end hit; sort key 1
+__global__ __launch_bounds__(TB) void pb_key1(int64_t n, const int *__restrict__ deg_in, const int *__restrict__ deg_out,
+                                              const int *__restrict__ gid, int *level, const int *__restrict__ down,
+                                              unsigned long long *key, int *iota, int64_t *hdr)
+{
+    int bad = 0, lmax = 0;
+    GS_LOOP(i, n) {
+        const int di = deg_in[i], dout = deg_out[i];
+        int lv = level[i];
+        if (di == 0 && dout > 0) {
+            lv = down[i] - 1;
+            if (lv < 0) lv = 0;
+            level[i] = lv;
+        }
+        if (di > 0xFFFF || dout > 0xFFFF || lv > 127) bad = 1;
+        lmax = lv > lmax ? lv : lmax;
+        key[i] = ((unsigned long long)(unsigned)gid[i] << 39) | ((unsigned long long)(lv & 127) << 32) |
+                 ((unsigned long long)(0xFFFF - (di & 0xFFFF)) << 16) | (unsigned long long)(0xFFFF - (dout & 0xFFFF));
+        iota[i] = (int)i;
+    }
+    if (bad) set_status(hdr, ST_DEGREE);
+    hdr_max(hdr, H_MAXLEVEL, lmax);
+}
+
+__global__ __launch_bounds__(TB) void pb_unit_flags(int64_t n, const unsigned long long *__restrict__ key, int *flag)
+{
+    GS_LOOP(p, n + 1) flag[p] = (p < n && (p == 0 || (key[p] >> 32) != (key[p - 1] >> 32))) ? 1 : 0;
+}
+
+// ordered compaction: out[scan[p]] = p where flag[p]; count = scan[n] (flag / scan have n + 1 entries)
+__global__ __launch_bounds__(TB) void pb_compact(int64_t n, const int *__restrict__ flag, const int *__restrict__ scan,
+                                                 int *out, int64_t *hdr, int slot)
+{
+    GS_LOOP(p, n + 1) {
+        if (p < n) {
+            if (flag[p]) out[scan[p]] = (int)p;
+        } else {
+            out[scan[n]] = (int)n;               // end sentinel
+            hdr[slot] = scan[n];
+        }
+    }
+}
+
+// plan.py's sequential packing of (graph, level) units into tiles of <= T hits.  The greedy rule
+// (start a new tile when the next unit would not fit; a unit larger than T is split) makes a tile
+// that starts at unit i end before the first unit j > i with ustart[j + 1] - ustart[i] > T: all
+// threads compute that jump for the units of a chunk staged in LDS (binary search), one thread then
+// follows the chain - one LDS read per TILE instead of a dependent step per unit.  A tile still open
+// at the end of a chunk is carried over by its start position.
+constexpr int kCutChunk = 4096;
+__global__ __launch_bounds__(1024) void pb_cut_tiles(const int *__restrict__ ustart, int n, int T, int *tile_bounds,
+                                                     int64_t *hdr, int nt_max)
+{
+    __shared__ int st[kCutChunk + 1], nxt[kCutChunk];
+    const int nu = (int)hdr[H_NUNITS];
+    int nb = 0, last = 0;
+    bool over = false;
+    auto push = [&](int v) {
+        if (nb <= nt_max) tile_bounds[nb] = v; else over = true;
+        ++nb;
+        last = v;
+    };
+    // first j in [lo, cnt) with st[j + 1] > lim, or cnt
+    auto first_over = [&](int lo, int cnt, int lim) {
+        int hi = cnt;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (st[mid + 1] > lim) hi = mid; else lo = mid + 1;
+        }
+        return lo;
+    };
+    if (threadIdx.x == 0) push(0);
+    int anchor = -1;                               // start position of a tile carried into this chunk
+    for (int b0 = 0; b0 < nu; b0 += kCutChunk) {
+        const int cnt = nu - b0 < kCutChunk ? nu - b0 : kCutChunk;
+        __syncthreads();
+        for (int i = threadIdx.x; i <= cnt; i += blockDim.x) st[i] = ustart[b0 + i];
+        __syncthreads();
+        for (int i = threadIdx.x; i < cnt; i += blockDim.x) nxt[i] = first_over(i, cnt, st[i] + T);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int i = 0;
+            if (anchor >= 0) {                     // the open tile ends inside this chunk, or goes on
+                const int j = first_over(0, cnt, anchor + T);
+                if (j < cnt) { push(st[j]); anchor = -1; }
+                i = j;
+            }
+            while (i < cnt) {
+                const int s0 = st[i], sz = st[i + 1] - s0;
+                if (sz > T) {                      // split a big unit (a tile boundary stands at s0 already)
+                    for (int a = s0 + T; a < s0 + sz; a += T) push(a);
+                    push(s0 + sz);
+                    ++i;
+                    continue;
+                }
+                const int j = nxt[i];
+                if (j < cnt) { push(st[j]); i = j; }
+                else { anchor = s0; i = cnt; }     // still open at the end of the chunk
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (n && last != n) push(n);
+        if (over) { set_status(hdr, ST_TILES); nb = 1; }
+        hdr[H_NTILES] = nb - 1;
+    }
+}
+
+__device__ __forceinline__ int tile_of(const int *__restrict__ bounds, int nt, int p)
+{
+    int lo = 0, hi = nt;                 // last t with bounds[t] <= p
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (bounds[mid] <= p) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(TB) void pb_key2(int64_t n, const int *__restrict__ base, const int *__restrict__ deg_in,
+                                              const int *__restrict__ deg_out, const int *__restrict__ tile_bounds,
+                                              const int64_t *__restrict__ hdr, int *tpos, unsigned long long *key)
+{
+    const int nt = (int)hdr[H_NTILES];
+    GS_LOOP(p, n) {
+        const int old = base[p];
+        const int t = tile_of(tile_bounds, nt, (int)p);
+        tpos[p] = t;
+        key[p] = ((unsigned long long)(unsigned)t << 32) |
+                 ((unsigned long long)(0xFFFF - ((deg_in[old] + 3) >> 2)) << 16) | (unsigned long long)(0xFFFF - deg_out[old]);
+    }
+}
+
+// per tile: padded size, padded offset (exclusive scan), slices, schedule base; one workgroup
+__global__ __launch_bounds__(1024) void pb_tile_offsets(const int *__restrict__ tile_bounds, int *tpad_off, int *sbase,
+                                                        int64_t *hdr, int64_t np_max)
+{
+    __shared__ int sa[1024], sb[1024];
+    const int nt = (int)hdr[H_NTILES];
+    int carry_a = 0, carry_b = 0, tmax = 0;
+    for (int b0 = 0; b0 < nt; b0 += 1024) {
+        const int t = b0 + threadIdx.x;
+        int pad = 0, sch = 0;
+        if (t < nt) {
+            pad = (tile_bounds[t + 1] - tile_bounds[t] + SLICE - 1) / SLICE * SLICE;
+            sch = ((pad / SLICE + 15) / 16) * 16;
+            tmax = pad > tmax ? pad : tmax;
+        }
+        sa[threadIdx.x] = pad;
+        sb[threadIdx.x] = sch;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {            // Hillis-Steele inclusive scan
+            int xa = 0, xb = 0;
+            if ((int)threadIdx.x >= o) { xa = sa[threadIdx.x - o]; xb = sb[threadIdx.x - o]; }
+            __syncthreads();
+            sa[threadIdx.x] += xa;
+            sb[threadIdx.x] += xb;
+            __syncthreads();
+        }
+        if (t < nt) {
+            tpad_off[t] = carry_a + sa[threadIdx.x] - pad;
+            sbase[t] = carry_b + sb[threadIdx.x] - sch;
+        }
+        carry_a += sa[1023];
+        carry_b += sb[1023];
+        __syncthreads();
+    }
+    for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(tmax, o, 64); tmax = x > tmax ? x : tmax; }
+    if ((threadIdx.x & 63) == 0) hdr_max(hdr, H_TILEMAX, tmax);
+    if (threadIdx.x == 0) {
+        tpad_off[nt] = carry_a;
+        sbase[nt] = carry_b;
+        hdr[H_NPAD] = carry_a;
+        hdr[H_NSCHED] = carry_b + 16;
+        if (carry_a > np_max) set_status(hdr, ST_PAD);
+    }
+}
+
+// rank r of the tile-major, degree-sorted order -> padded new id; degrees in new ids
+__global__ __launch_bounds__(TB) void pb_new_ids(int64_t n, const int *__restrict__ oor, const int *__restrict__ tpos,
+                                                 const int *__restrict__ tile_bounds, const int *__restrict__ tpad_off,
+                                                 const int *__restrict__ deg_in, const int *__restrict__ deg_out,
+                                                 int *inv, I2 *degn, const int64_t *__restrict__ hdr)
+{
+    if (hdr[H_STATUS]) return;
+    GS_LOOP(r, n + 1) {
+        if (r == n) { inv[n] = (int)hdr[H_NPAD]; continue; }
+        const int old = oor[r], t = tpos[r];
+        const int nw = tpad_off[t] + ((int)r - tile_bounds[t]);
+        inv[old] = nw;
+        degn[nw] = I2{deg_in[old], deg_out[old]};
+    }
+}
+
+__global__ __launch_bounds__(TB) void pb_renumber(const int *__restrict__ src, const int *__restrict__ dst, int64_t E,
+                                                  const int *__restrict__ inv, int n, int *src_new, int *dst_new,
+                                                  const int64_t *__restrict__ hdr)
+{
+    if (hdr[H_STATUS]) return;
+    GS_LOOP(j, E) {
+        const int s = src[j];
+        src_new[j] = inv[s >= 0 ? s : n];
+        dst_new[j] = inv[s >= 0 ? dst[j] : n];
+    }
+}
+
+// per slice: SELL-16 steps (max degree of its 16 hits), in entries: (16 L_in, 16 L_out, 16 ceil8 L_in, 16 ceil8 L_out)
+__global__ __launch_bounds__(TB) void pb_slices(int64_t ns_max, const I2 *__restrict__ degn, I4 *sl4, int64_t *hdr)
+{
+    const int64_t ns = hdr[H_STATUS] ? 0 : hdr[H_NPAD] / SLICE;
+    int mx = 0;
+    GS_LOOP(s, ns_max + 1) {
+        int li = 0, lo = 0;
+        if (s < ns) {
+#pragma unroll
+            for (int i = 0; i < SLICE; ++i) {
+                const I2 d = degn[s * SLICE + i];
+                li = d.a > li ? d.a : li;
+                lo = d.b > lo ? d.b : lo;
+            }
+        }
+        sl4[s] = I4{li * SLICE, lo * SLICE, (li + 7) / 8 * 8 * SLICE, (lo + 7) / 8 * 8 * SLICE};
+        mx = li > mx ? li : mx;
+        mx = lo > mx ? lo : mx;
+    }
+    for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(mx, o, 64); mx = x > mx ? x : mx; }
+    if ((threadIdx.x & 63) == 0 && mx) hdr_max(hdr, H_MAXSTEPS, mx);
+}
+
+// windows of a tile: min / max new id over the start hits of its incoming (end hits of its outgoing)
+// segments - read from the sorted neighbour lists, no atomics.  One workgroup per tile.
+__global__ __launch_bounds__(TB) void pb_tile_windows(const int *__restrict__ tpad_off, const int *__restrict__ sbase,
+                                                      const I2 *__restrict__ degn, const I2 *__restrict__ ptr,
+                                                      const int *__restrict__ sv_in, const int *__restrict__ sv_out,
+                                                      int iter_records, int *t_desc, int64_t *hdr)
+{
+    if (hdr[H_STATUS]) return;
+    const int nt = (int)hdr[H_NTILES];
+    __shared__ int red[4][TB / 64];
+    for (int t = blockIdx.x; t < nt; t += gridDim.x) {
+        const int h0 = tpad_off[t], h1 = tpad_off[t + 1];
+        int ilo = 0x7FFFFFFF, ihi = -1, olo = 0x7FFFFFFF, ohi = -1;
+        for (int h = h0 + threadIdx.x; h < h1; h += TB) {
+            const I2 d = degn[h], p = ptr[h];
+            for (int k = 0; k < d.a; ++k) { const int v = sv_in[p.a + k]; ilo = v < ilo ? v : ilo; ihi = v > ihi ? v : ihi; }
+            for (int k = 0; k < d.b; ++k) { const int v = sv_out[p.b + k]; olo = v < olo ? v : olo; ohi = v > ohi ? v : ohi; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            int x = __shfl_xor(ilo, o, 64); ilo = x < ilo ? x : ilo;
+            x = __shfl_xor(ihi, o, 64); ihi = x > ihi ? x : ihi;
+            x = __shfl_xor(olo, o, 64); olo = x < olo ? x : olo;
+            x = __shfl_xor(ohi, o, 64); ohi = x > ohi ? x : ohi;
+        }
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) {
+            const int w = threadIdx.x >> 6;
+            red[0][w] = ilo; red[1][w] = ihi; red[2][w] = olo; red[3][w] = ohi;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < TB / 64; ++w) {
+                ilo = red[0][w] < ilo ? red[0][w] : ilo; ihi = red[1][w] > ihi ? red[1][w] : ihi;
+                olo = red[2][w] < olo ? red[2][w] : olo; ohi = red[3][w] > ohi ? red[3][w] : ohi;
+            }
+            const int icnt = ihi >= 0 ? ihi - ilo + 1 : 0, ocnt = ohi >= 0 ? ohi - olo + 1 : 0;
+            const int mode = (icnt + ocnt + 2) <= iter_records ? 1 : 0;
+            int *d = t_desc + (int64_t)t * 8;
+            d[0] = h0 / SLICE; d[1] = h1 / SLICE;
+            d[2] = icnt > 0 ? ilo : 0; d[3] = icnt;
+            d[4] = ocnt > 0 ? olo : 0; d[5] = ocnt;
+            d[6] = mode; d[7] = sbase[t];
+            if (mode) {
+                hdr_max(hdr, H_LDSREC, icnt + ocnt + 2);
+                hdr_max(hdr, H_LDSIN, icnt);
+                hdr_max(hdr, H_LDSOUT, ocnt);
+                hdr_add(hdr, H_NLDSTILES, 1);
+            }
+        }
+    }
+}
+
+// ---- edge chunks (plan._chunk_bounds) ---------------------------------------------------------------
+__global__ __launch_bounds__(TB) void pb_valid_idx(const int *__restrict__ src, int64_t E, int *idx)
+{
+    GS_LOOP(j, E) idx[j] = src[j] >= 0 ? (int)j : 0;
+}
+
+// run starts of the (graph, start level) key; padded segments join the run before them: k[j] = key of
+// the last valid segment at or before j (or of segment 0 when there is none)
+__global__ __launch_bounds__(TB) void pb_run_flags(const int *__restrict__ src, int64_t E, const int *__restrict__ idx,
+                                                   const int *__restrict__ gid, const int *__restrict__ level, int *flag)
+{
+    auto key_at = [&](int j) {
+        const int s = src[j];
+        return s >= 0 ? (long long)gid[s] * 128 + level[s] : -1ll;
+    };
+    GS_LOOP(j, E + 1) {
+        int f = 0;
+        if (j < E) f = (j == 0) ? 1 : (key_at(idx[j]) != key_at(idx[j - 1]) ? 1 : 0);
+        flag[j] = f;
+    }
+}
+
+// marks = run starts that begin or follow a run of >= CH/4 segments (+ 0 and E)
+__global__ __launch_bounds__(TB) void pb_mark_flags(const int *__restrict__ rb, int64_t E, int CH, int *flag,
+                                                    const int64_t *__restrict__ hdr)
+{
+    const int64_t nr = hdr[H_NRUNS];
+    const int thr = CH / 4 > 1 ? CH / 4 : 1;
+    GS_LOOP(r, E + 1) {
+        int f = 0;
+        if (r < nr) {
+            const bool big = rb[r + 1] - rb[r] >= thr;
+            const bool big_prev = r > 0 && rb[r] - rb[r - 1] >= thr;
+            f = (r == 0 || big || big_prev) ? 1 : 0;
+        }
+        flag[r] = f;
+    }
+}
+
+// marks[scan[r]] = rb[r] for flagged runs; marks[n_marks] = E
+__global__ __launch_bounds__(TB) void pb_marks(const int *__restrict__ rb, int64_t E, const int *__restrict__ flag,
+                                               const int *__restrict__ scan, int *marks, int64_t m_max, int64_t *hdr)
+{
+    const int64_t nr = hdr[H_NRUNS];
+    const int64_t nm = scan[nr];
+    if (nm + 1 > m_max) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) { set_status(hdr, ST_CHUNKS); hdr[H_NMARKS] = 0; }
+        return;
+    }
+    GS_LOOP(r, nr + 1) {
+        if (r < nr) {
+            if (flag[r]) marks[scan[r]] = rb[r];
+        } else {
+            marks[nm] = (int)E;
+            hdr[H_NMARKS] = nm;
+        }
+    }
+}
+
+// one workgroup: parts per mark interval, their scan, the chunk bounds (equal parts of <= CH)
+__global__ __launch_bounds__(1024) void pb_chunk_bounds(const int *__restrict__ marks, int CH, int *parts, int *pscan, int *cb,
+                                                        int64_t c_max, int64_t *hdr)
+{
+    __shared__ int sa[1024];
+    if (hdr[H_STATUS]) { if (threadIdx.x == 0) hdr[H_NCHUNKS] = 0; return; }
+    const int nm = (int)hdr[H_NMARKS];
+    int carry = 0;
+    for (int b0 = 0; b0 < nm; b0 += 1024) {
+        const int i = b0 + threadIdx.x;
+        int p = 0;
+        if (i < nm) p = (marks[i + 1] - marks[i] + CH - 1) / CH;
+        sa[threadIdx.x] = p;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            int x = 0;
+            if ((int)threadIdx.x >= o) x = sa[threadIdx.x - o];
+            __syncthreads();
+            sa[threadIdx.x] += x;
+            __syncthreads();
+        }
+        if (i < nm) { parts[i] = p; pscan[i] = carry + sa[threadIdx.x] - p; }
+        carry += sa[1023];
+        __syncthreads();
+    }
+    const bool over = carry + 1 > c_max;
+    if (threadIdx.x == 0) {
+        hdr[H_NCHUNKS] = over ? 0 : carry;
+        if (over) set_status(hdr, ST_CHUNKS);
+        cb[0] = 0;
+    }
+    if (over) return;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nm; i += 1024) {
+        const long long a = marks[i], len = marks[i + 1] - marks[i];
+        const int p = parts[i], o = pscan[i];
+        for (int k = 1; k <= p; ++k) cb[o + k] = (int)(a + ((long long)k * len) / p);
+    }
+}
+
+// windows of a chunk of the final edge pass; one workgroup per chunk
+__global__ __launch_bounds__(TB) void pb_chunk_windows(const int *__restrict__ cb, const int *__restrict__ src,
+                                                       const int *__restrict__ src_new, const int *__restrict__ dst_new,
+                                                       int edge_records, int *c_desc, int64_t *hdr)
+{
+    if (hdr[H_STATUS]) return;
+    const int nc = (int)hdr[H_NCHUNKS];
+    __shared__ int red[4][TB / 64];
+    for (int c = blockIdx.x; c < nc; c += gridDim.x) {
+        const int e0 = cb[c], e1 = cb[c + 1];
+        int slo = 0x7FFFFFFF, shi = -1, dlo = 0x7FFFFFFF, dhi = -1;
+        for (int j = e0 + threadIdx.x; j < e1; j += TB) {
+            if (src[j] >= 0) {
+                const int s = src_new[j], d = dst_new[j];
+                slo = s < slo ? s : slo; shi = s > shi ? s : shi;
+                dlo = d < dlo ? d : dlo; dhi = d > dhi ? d : dhi;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            int x = __shfl_xor(slo, o, 64); slo = x < slo ? x : slo;
+            x = __shfl_xor(shi, o, 64); shi = x > shi ? x : shi;
+            x = __shfl_xor(dlo, o, 64); dlo = x < dlo ? x : dlo;
+            x = __shfl_xor(dhi, o, 64); dhi = x > dhi ? x : dhi;
+        }
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) {
+            const int w = threadIdx.x >> 6;
+            red[0][w] = slo; red[1][w] = shi; red[2][w] = dlo; red[3][w] = dhi;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < TB / 64; ++w) {
+                slo = red[0][w] < slo ? red[0][w] : slo; shi = red[1][w] > shi ? red[1][w] : shi;
+                dlo = red[2][w] < dlo ? red[2][w] : dlo; dhi = red[3][w] > dhi ? red[3][w] : dhi;
+            }
+            const int scnt = shi >= 0 ? shi - slo + 1 : 0, dcnt = dhi >= 0 ? dhi - dlo + 1 : 0;
+            const int mode = (scnt + dcnt + 2) <= edge_records ? 1 : 0;
+            int *d = c_desc + (int64_t)c * 8;
+            d[0] = e0; d[1] = e1;
+            d[2] = scnt > 0 ? slo : 0; d[3] = scnt;
+            d[4] = dcnt > 0 ? dlo : 0; d[5] = dcnt;
+            d[6] = mode; d[7] = 0;
+            if (mode) {
+                hdr_max(hdr, H_EDGEROWS, scnt + dcnt + 2);
+                hdr_add(hdr, H_NLDSCHUNKS, 1);
+            }
+        }
+    }
+}
+
+__global__ void pb_sizes(const int64_t *__restrict__ hdr, const I4 *__restrict__ off4, gnn_plan_sizes_t *out, int64_t np_max,
+                         int64_t ns_max)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    gnn_plan_sizes_t s;
+    const int64_t st = hdr[H_STATUS];
+    const int64_t npad = st ? 0 : hdr[H_NPAD];
+    const int64_t ns = npad / SLICE;
+    const I4 tot = off4[ns <= ns_max ? ns : 0];
+    s.n_pad = npad; s.n_tiles = st ? 0 : hdr[H_NTILES]; s.n_slices = ns; s.n_chunks = hdr[H_NCHUNKS];
+    s.in_total = tot.a; s.out_total = tot.b; s.in16_words = tot.c / 2; s.out16_words = tot.d / 2;
+    s.n_sched = hdr[H_NSCHED];
+    s.iter_lds_records = hdr[H_LDSREC]; s.edge_lds_rows = hdr[H_EDGEROWS];
+    s.n_lds_tiles = hdr[H_NLDSTILES]; s.n_lds_chunks = hdr[H_NLDSCHUNKS];
+    s.iter_lds_in = hdr[H_LDSIN]; s.iter_lds_out = hdr[H_LDSOUT];
+    s.tile_hits_max = hdr[H_TILEMAX]; s.max_list_steps = hdr[H_MAXSTEPS];
+    s.n_valid = hdr[H_NVALID]; s.max_level = hdr[H_MAXLEVEL];
+    s.status = st;
+    *out = s;
+}
+
+// ---- stage 2 kernels ------------------------------------------------------------------------------
+template <int F_MAX>
+__global__ __launch_bounds__(TB) void pb_fill_hits(int64_t n, int F, const float *__restrict__ X, const int *__restrict__ oor,
+                                                   const int *__restrict__ inv, float *Xp, int *perm, unsigned *absmax)
+{
+    float mx[F_MAX];
+#pragma unroll
+    for (int k = 0; k < F_MAX; ++k) mx[k] = 0.0f;
+    GS_LOOP(r, n) {
+        const int old = oor[r], nw = inv[old];
+        perm[nw] = old;
+#pragma unroll
+        for (int k = 0; k < F_MAX; ++k)
+            if (k < F) {
+                const float v = X[(int64_t)old * F + k];
+                Xp[(int64_t)nw * F + k] = v;
+                mx[k] = fmaxf(mx[k], fabsf(v));
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < F_MAX; ++k) {
+        if (k >= F) break;
+        float v = mx[k];
+        for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+        if ((threadIdx.x & 63) == 0 && v > 0.0f) atomicMax(&absmax[k], __float_as_uint(v));   // >= 0: bit order = value order
+    }
+}
+
+__global__ __launch_bounds__(TB) void pb_fill_offsets(int64_t ns, const I4 *__restrict__ off4, int *in_off, int *out_off,
+                                                      int *in_off16, int *out_off16)
+{
+    GS_LOOP(s, ns + 1) {
+        const I4 o = off4[s];
+        in_off[s] = o.a; out_off[s] = o.b; in_off16[s] = o.c / 2; out_off16[s] = o.d / 2;
+    }
+}
+
+// SELL-16 lists of one direction, 32-bit and 16-bit packed: one lane per padded hit, entry k of hit
+// i of slice s at off[s] + 16 k + i (16 lanes write 64 contiguous bytes per step)
+template <bool IN>
+__global__ __launch_bounds__(TB) void pb_fill_lists(int64_t n_pad, const I2 *__restrict__ degn, const I2 *__restrict__ ptr,
+                                                    const I4 *__restrict__ sl4, const I4 *__restrict__ off4,
+                                                    const int *__restrict__ sv, const int *__restrict__ t_desc,
+                                                    const int *__restrict__ tpad_off, int nt, int *nbr, int *nbr16)
+{
+    GS_LOOP(h, n_pad) {
+        const int64_t s = h / SLICE;
+        const int i = (int)(h % SLICE);
+        const int t = tile_of(tpad_off, nt, (int)h);
+        const int *td = t_desc + (int64_t)t * 8;
+        const bool lds = td[6] != 0;
+        const int lo = IN ? td[2] : td[4], cnt = IN ? td[3] : td[5];
+        const int null = lds ? cnt : (int)n_pad;
+        const int deg = IN ? degn[h].a : degn[h].b;
+        const int p0 = IN ? ptr[h].a : ptr[h].b;
+        const I4 sl = sl4[s], of = off4[s];
+        const int steps = (IN ? sl.a : sl.b) / SLICE, steps8 = (IN ? sl.c : sl.d) / SLICE;
+        int *o32 = nbr + (IN ? of.a : of.b) + i;
+        int *o16 = nbr16 + (IN ? of.c : of.d) / 2 + i;
+        for (int k = 0; k < steps8; k += 2) {
+            int v[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int kk = k + u;
+                int x = null;
+                if (kk < deg) { x = sv[p0 + kk]; if (lds) x -= lo; }
+                v[u] = x;
+                if (kk < steps) o32[kk * SLICE] = x;
+            }
+            o16[(k >> 1) * SLICE] = (int)(((unsigned)v[0] & 0xFFFFu) | (((unsigned)v[1] & 0xFFFFu) << 16));
+        }
+    }
+}
+
+__global__ __launch_bounds__(TB) void pb_copy_i32(const int *__restrict__ a, int *b, int64_t n) { GS_LOOP(i, n) b[i] = a[i]; }
+
+// wave schedules of one tile (plan.py schedule / schedule_two_phase); one wavefront per tile.
+// float64 arithmetic exactly as numpy evaluates it: no contraction into fma.
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(64) void pb_schedule(int nt, const int *__restrict__ t_desc, const I4 *__restrict__ sl4,
+                                                  int *sched_a, int *sched_b)
+{
+    __shared__ int ga[kMaxSlicesPerTile], gb[kMaxSlicesPerTile], by_ab[kMaxSlicesPerTile], by_tot[kMaxSlicesPerTile];
+    __shared__ int rk[kMaxSlicesPerTile];
+    const int lane = threadIdx.x;
+    for (int t = blockIdx.x; t < nt; t += gridDim.x) {
+        const int *td = t_desc + (int64_t)t * 8;
+        const int s0 = td[0], nsl = td[1] - td[0], sb = td[7];
+        __syncthreads();
+        for (int i = lane; i < nsl; i += 64) {
+            const I4 sl = sl4[s0 + i];
+            ga[i] = (sl.a / SLICE + 3) / 4;
+            gb[i] = (sl.b / SLICE + 3) / 4;
+        }
+        __syncthreads();
+        // sched_b: heaviest out-phase first (stable), dealt in snake order over the 16 waves
+        for (int i = lane; i < nsl; i += 64) {
+            int r = 0;
+            for (int j = 0; j < nsl; ++j) r += (gb[j] > gb[i] || (gb[j] == gb[i] && j < i)) ? 1 : 0;
+            const int rd = r / 16, c = r % 16;
+            sched_b[sb + rd * 16 + ((rd & 1) ? 15 - c : c)] = s0 + i;
+            // rank by (in groups, out groups) descending, stable
+            int q = 0;
+            for (int j = 0; j < nsl; ++j) {
+                const bool before = ga[j] > ga[i] || (ga[j] == ga[i] && (gb[j] > gb[i] || (gb[j] == gb[i] && j < i)));
+                q += before ? 1 : 0;
+            }
+            by_ab[q] = i;
+            rk[i] = q;
+        }
+        __syncthreads();
+        // inside each round of 16: heaviest total first, stable in by_ab order
+        for (int i = lane; i < nsl; i += 64) {
+            const int q = rk[i], rd = q / 16;
+            const double tot = (double)ga[i] + ((double)gb[i] + 2.6);
+            int r2 = 0;
+            const int q0 = rd * 16, q1 = q0 + 16 < nsl ? q0 + 16 : nsl;
+            for (int qq = q0; qq < q1; ++qq) {
+                const int j = by_ab[qq];
+                const double tj = (double)ga[j] + ((double)gb[j] + 2.6);
+                r2 += (tj > tot || (tj == tot && qq < q)) ? 1 : 0;
+            }
+            by_tot[q0 + r2] = i;
+        }
+        __syncthreads();
+        // greedy: the next slice goes to the free wave that raises max A + max B least
+        double A = 0.0, B = 0.0;                    // lane w < 16 holds wave w's phase loads
+        const double inf = __builtin_huge_val();
+        const int rounds = (nsl + 15) / 16;
+        for (int rd = 0; rd < rounds; ++rd) {
+            bool used = false;
+            for (int j = 0; j < 16; ++j) {
+                const int idx = rd * 16 + j;
+                if (idx >= nsl) break;
+                const int sl = by_tot[idx];
+                const double a = (double)ga[sl], b = (double)gb[sl] + 2.6;
+                double mA = lane < 16 ? A : -inf, mB = lane < 16 ? B : -inf;
+                for (int o = 8; o > 0; o >>= 1) {
+                    const double xa = __shfl_xor(mA, o, 64), xb = __shfl_xor(mB, o, 64);
+                    mA = xa > mA ? xa : mA;
+                    mB = xb > mB ? xb : mB;
+                }
+                const double t1 = (A + a) > mA ? (A + a) : mA;
+                const double t2 = (B + b) > mB ? (B + b) : mB;
+                const double t3 = 1e-3 * (A + B);
+                double sc = (t1 + t2) + t3;
+                if (used || lane >= 16) sc = inf;
+                int w = lane;
+                for (int o = 8; o > 0; o >>= 1) {
+                    const double xs = __shfl_xor(sc, o, 64);
+                    const int xw = __shfl_xor(w, o, 64);
+                    if (xs < sc || (xs == sc && xw < w)) { sc = xs; w = xw; }
+                }
+                w = __shfl(w, 0, 64);
+                if (lane == w) { A = A + a; B = B + b; used = true; }
+                if (lane == 0) sched_a[sb + rd * 16 + w] = s0 + sl;
+            }
+        }
+    }
+}
+#pragma clang fp contract(on)
+
+// endpoints of the final edge pass in the caller's segment order (window-relative in LDS chunks)
+__global__ __launch_bounds__(TB) void pb_fill_chunks(int nc, const int *__restrict__ c_desc, const int *__restrict__ src,
+                                                     const int *__restrict__ src_new, const int *__restrict__ dst_new,
+                                                     int *chunks, int *src_st, int *dst_st, int *sd16)
+{
+    for (int c = blockIdx.x; c < nc; c += gridDim.x) {
+        const int *d = c_desc + (int64_t)c * 8;
+        if (threadIdx.x < 8) chunks[(int64_t)c * 8 + threadIdx.x] = d[threadIdx.x];
+        const int e0 = d[0], e1 = d[1], slo = d[2], scnt = d[3], dlo = d[4], dcnt = d[5], mode = d[6];
+        for (int j = e0 + threadIdx.x; j < e1; j += TB) {
+            const bool ok = src[j] >= 0;
+            int s = src_new[j], t = dst_new[j];
+            unsigned w = 0;
+            if (mode) {
+                s = ok ? s - slo : scnt;
+                t = ok ? t - dlo : dcnt;
+                w = ((unsigned)t << 16) | ((unsigned)s & 0xFFFFu);
+            }
+            src_st[j] = s;
+            dst_st[j] = t;
+            sd16[j] = (int)w;
+        }
+    }
+}
+
+inline unsigned bit_width(uint64_t v)
+{
+    unsigned b = 0;
+    while (v) { ++b; v >>= 1; }
+    return b ? b : 1;
+}
+
+#define HIP_OK(CALL, WHAT)                                                                            \
+    do {                                                                                              \
+        hipError_t e_ = (CALL);                                                                       \
+        if (e_ != hipSuccess) return fail(-(int)e_, "%s failed: %s", WHAT, hipGetErrorString(e_));   \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+size_t gnn_plan_build_workspace_bytes(int64_t n_hits, int64_t n_segments, int32_t chunk_segments)
+{
+    if (n_hits <= 0 || n_segments <= 0 || chunk_segments <= 0) return 0;
+    return carve(nullptr, n_hits, n_segments, chunk_segments).bytes + 256;
+}
+
+int gnn_plan_build_sizes(const int32_t *src, const int32_t *dst, const int64_t *hit_ptr, int64_t n_hits,
+                         int64_t n_segments, int64_t n_graphs, int32_t tile_hits, int32_t iter_records,
+                         int32_t chunk_segments, int32_t edge_records, void *workspace, size_t workspace_bytes,
+                         gnn_plan_sizes_t *sizes_out, void *stream)
+{
+    const int64_t n = n_hits, E = n_segments, G = n_graphs;
+    if (!src || !dst || !hit_ptr || !workspace || !sizes_out || n <= 0 || E <= 0 || G <= 0 || tile_hits < SLICE ||
+        tile_hits > kMaxSlicesPerTile * SLICE || chunk_segments <= 0 || iter_records < 0 || edge_records < 0)
+        return fail(GNN_ERR_BADARG, "gnn_plan_build_sizes: bad argument");
+    if (n >= (1ll << 30) || E >= (1ll << 30) || G >= (1ll << 24))
+        return fail(GNN_ERR_UNSUPPORTED, "gnn_plan_build_sizes: batch too large for 32-bit plan indices");
+    if (workspace_bytes < gnn_plan_build_workspace_bytes(n, E, chunk_segments))
+        return fail(GNN_ERR_WORKSPACE, "gnn_plan_build_sizes: workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    char *wb = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    const Ws w = carve(wb, n, E, chunk_segments);
+    const Bounds b = bounds_of(n, E, chunk_segments);
+    // header, sweep flags, degrees and both level buffers start at zero (adjacent in the workspace)
+    HIP_OK(hipMemsetAsync(w.hdr, 0, (size_t)(reinterpret_cast<char *>(w.gid) - reinterpret_cast<char *>(w.hdr)), s), "memset");
+    HIP_OK(hipMemsetAsync(w.degn, 0, (size_t)(b.np_max + 1) * sizeof(I2), s), "memset");
+    GNN_LAUNCH("pb_degrees", pb_degrees, gs(E), TB, s, src, dst, E, w.deg_in, w.deg_out, w.hdr);
+    GNN_LAUNCH("pb_gid", pb_gid, gs(n), TB, s, hit_ptr, G, n, w.gid);
+    int *level = w.lvA;
+    if (E <= kSmallSweepSegments)
+        GNN_LAUNCH("pb_levels_small", pb_levels_small, 1, 1024, s, src, dst, (int)E, level);
+    else
+        for (int t = 1; t <= kMaxLevelIters; ++t)
+            GNN_LAUNCH("pb_level_sweep", pb_level_sweep, gs(E), TB, s, src, dst, E, level, w.chg, t);
+    GNN_LAUNCH("pb_fill_i32", pb_fill_i32, gs(n), TB, s, w.down, n, 0x7FFFFFFF);
+    GNN_LAUNCH("pb_down", pb_down, gs(E), TB, s, src, dst, E, level, w.deg_in, w.down);
+    GNN_LAUNCH("pb_key1", pb_key1, gs(n), TB, s, n, w.deg_in, w.deg_out, w.gid, level, w.down, w.k64a, w.iota, w.hdr);
+    size_t tb = w.temp_bytes;
+    HIP_OK(rocprim::radix_sort_pairs(w.temp, tb, (const unsigned long long *)w.k64a, w.k64b, (const int *)w.iota, w.base,
+                                     (size_t)n, 0u, 39u + bit_width((uint64_t)G), s, false), "hit sort 1");
+    GNN_LAUNCH("pb_unit_flags", pb_unit_flags, gs(n + 1), TB, s, n, w.k64b, w.uflag);
+    tb = w.temp_bytes;
+    HIP_OK(rocprim::exclusive_scan(w.temp, tb, (const int *)w.uflag, w.uscan, 0, (size_t)n + 1, rocprim::plus<int>(), s, false),
+           "unit scan");
+    GNN_LAUNCH("pb_compact", pb_compact, gs(n + 1), TB, s, n, w.uflag, w.uscan, w.ustart, w.hdr, (int)H_NUNITS);
+    GNN_LAUNCH("pb_cut_tiles", pb_cut_tiles, 1, 1024, s, w.ustart, (int)n, (int)tile_hits, w.tile_bounds, w.hdr,
+               (int)b.nt_max);
+    GNN_LAUNCH("pb_key2", pb_key2, gs(n), TB, s, n, w.base, w.deg_in, w.deg_out, w.tile_bounds, w.hdr, w.tpos, w.k64a);
+    tb = w.temp_bytes;
+    HIP_OK(rocprim::radix_sort_pairs(w.temp, tb, (const unsigned long long *)w.k64a, w.k64b, (const int *)w.base, w.oor,
+                                     (size_t)n, 0u, 32u + bit_width((uint64_t)b.nt_max), s, false), "hit sort 2");
+    GNN_LAUNCH("pb_tile_offsets", pb_tile_offsets, 1, 1024, s, w.tile_bounds, w.tpad_off, w.sbase, w.hdr, b.np_max);
+    GNN_LAUNCH("pb_new_ids", pb_new_ids, gs(n + 1), TB, s, n, w.oor, w.tpos, w.tile_bounds, w.tpad_off, w.deg_in, w.deg_out,
+               w.inv, w.degn, w.hdr);
+    GNN_LAUNCH("pb_renumber", pb_renumber, gs(E), TB, s, src, dst, E, w.inv, (int)n, w.src_new, w.dst_new, w.hdr);
+    const unsigned idbits = bit_width((uint64_t)b.np_max);
+    tb = w.temp_bytes;
+    HIP_OK(rocprim::radix_sort_pairs(w.temp, tb, (const int *)w.dst_new, w.kscr, (const int *)w.src_new, w.sv_in, (size_t)E, 0u,
+                                     idbits, s, false), "segment sort (in)");
+    tb = w.temp_bytes;
+    HIP_OK(rocprim::radix_sort_pairs(w.temp, tb, (const int *)w.src_new, w.kscr, (const int *)w.dst_new, w.sv_out, (size_t)E, 0u,
+                                     idbits, s, false), "segment sort (out)");
+    tb = w.temp_bytes;
+    HIP_OK(rocprim::exclusive_scan(w.temp, tb, (const I2 *)w.degn, w.ptr, I2{0, 0}, (size_t)b.np_max + 1, PlusI2(), s, false),
+           "degree scan");
+    GNN_LAUNCH("pb_slices", pb_slices, gs(b.ns_max + 1), TB, s, b.ns_max, w.degn, w.sl4, w.hdr);
+    tb = w.temp_bytes;
+    HIP_OK(rocprim::exclusive_scan(w.temp, tb, (const I4 *)w.sl4, w.off4, I4{0, 0, 0, 0}, (size_t)b.ns_max + 1, PlusI4(), s, false),
+           "slice scan");
+    GNN_LAUNCH("pb_tile_windows", pb_tile_windows, 2048, TB, s, w.tpad_off, w.sbase, w.degn, w.ptr, w.sv_in, w.sv_out,
+               (int)iter_records, w.t_desc, w.hdr);
+    // edge chunks
+    GNN_LAUNCH("pb_valid_idx", pb_valid_idx, gs(E), TB, s, src, E, w.kscr);
+    tb = w.temp_bytes;
+    HIP_OK(rocprim::inclusive_scan(w.temp, tb, (const int *)w.kscr, w.rb, (size_t)E, rocprim::maximum<int>(), s, false),
+           "valid-index scan");
+    GNN_LAUNCH("pb_run_flags", pb_run_flags, gs(E + 1), TB, s, src, E, w.rb, w.gid, level, w.mscan);
+    tb = w.temp_bytes;
+    HIP_OK(rocprim::exclusive_scan(w.temp, tb, (const int *)w.mscan, w.c_scan, 0, (size_t)E + 1, rocprim::plus<int>(), s, false),
+           "run scan");
+    GNN_LAUNCH("pb_compact", pb_compact, gs(E + 1), TB, s, E, w.mscan, w.c_scan, w.rb, w.hdr, (int)H_NRUNS);
+    GNN_LAUNCH("pb_mark_flags", pb_mark_flags, gs(E + 1), TB, s, w.rb, E, (int)chunk_segments, w.mscan, w.hdr);
+    tb = w.temp_bytes;
+    HIP_OK(rocprim::exclusive_scan(w.temp, tb, (const int *)w.mscan, w.c_scan, 0, (size_t)E + 1, rocprim::plus<int>(), s, false),
+           "mark scan");
+    GNN_LAUNCH("pb_marks", pb_marks, gs(E + 1), TB, s, w.rb, E, w.mscan, w.c_scan, w.marks, b.m_max, w.hdr);
+    GNN_LAUNCH("pb_chunk_bounds", pb_chunk_bounds, 1, 1024, s, w.marks, (int)chunk_segments, w.parts, w.pscan, w.cb, b.c_max,
+               w.hdr);
+    GNN_LAUNCH("pb_chunk_windows", pb_chunk_windows, 2048, TB, s, w.cb, src, w.src_new, w.dst_new, (int)edge_records, w.c_desc,
+               w.hdr);
+    GNN_LAUNCH("pb_sizes", pb_sizes, 1, 64, s, w.hdr, w.off4, sizes_out, b.np_max, b.ns_max);
+    return 0;
+}
+
+int gnn_plan_build_fill(const float *X, int32_t F, const int32_t *src, const int32_t *dst, int64_t n_hits,
+                        int64_t n_segments, int32_t chunk_segments, const gnn_plan_sizes_t *sz, void *workspace,
+                        size_t workspace_bytes, const gnn_plan_out_t *out, void *stream)
+{
+    const int64_t n = n_hits, E = n_segments;
+    if (!X || !src || !dst || !sz || !workspace || !out || n <= 0 || E <= 0 || F <= 0 || F > 16)
+        return fail(GNN_ERR_BADARG, "gnn_plan_build_fill: bad argument");
+    if (sz->status) return fail(GNN_ERR_UNSUPPORTED, "gnn_plan_build_fill: stage 1 reported status %lld", (long long)sz->status);
+    if (workspace_bytes < gnn_plan_build_workspace_bytes(n, E, chunk_segments))
+        return fail(GNN_ERR_WORKSPACE, "gnn_plan_build_fill: workspace too small");
+    if (!out->X || !out->x_absmax || !out->src || !out->dst || !out->sd16 || !out->in_off || !out->in_nbr || !out->out_off ||
+        !out->out_nbr || !out->in_off16 || !out->in_nbr16 || !out->out_off16 || !out->out_nbr16 || !out->tiles ||
+        !out->chunks || !out->sched_a || !out->sched_b || !out->perm)
+        return fail(GNN_ERR_BADARG, "gnn_plan_build_fill: output array missing");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    char *wb = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    const Ws w = carve(wb, n, E, chunk_segments);
+    const int64_t n_pad = sz->n_pad, ns = sz->n_slices;
+    const int nt = (int)sz->n_tiles, nc = (int)sz->n_chunks;
+    HIP_OK(hipMemsetAsync(out->X, 0, (size_t)(n_pad + 1 + 64) * F * sizeof(float), s), "memset X");
+    HIP_OK(hipMemsetAsync(out->x_absmax, 0, (size_t)F * sizeof(float), s), "memset absmax");
+    HIP_OK(hipMemsetAsync(out->perm, 0xFF, (size_t)n_pad * sizeof(int), s), "memset perm");
+    HIP_OK(hipMemsetAsync(out->sched_a, 0xFF, (size_t)sz->n_sched * sizeof(int), s), "memset sched");
+    HIP_OK(hipMemsetAsync(out->sched_b, 0xFF, (size_t)sz->n_sched * sizeof(int), s), "memset sched");
+    HIP_OK(hipMemsetAsync(out->in_nbr + sz->in_total, 0, 4 * SLICE * sizeof(int), s), "memset tail");
+    HIP_OK(hipMemsetAsync(out->out_nbr + sz->out_total, 0, 4 * SLICE * sizeof(int), s), "memset tail");
+    HIP_OK(hipMemsetAsync(out->in_nbr16 + sz->in16_words, 0, 64 * sizeof(int), s), "memset tail");
+    HIP_OK(hipMemsetAsync(out->out_nbr16 + sz->out16_words, 0, 64 * sizeof(int), s), "memset tail");
+    GNN_LAUNCH("pb_fill_hits", (pb_fill_hits<16>), gs(n), TB, s, n, (int)F, X, w.oor, w.inv, out->X, out->perm,
+               reinterpret_cast<unsigned *>(out->x_absmax));
+    GNN_LAUNCH("pb_fill_offsets", pb_fill_offsets, gs(ns + 1), TB, s, ns, w.off4, out->in_off, out->out_off, out->in_off16,
+               out->out_off16);
+    GNN_LAUNCH("pb_fill_lists", (pb_fill_lists<true>), gs(n_pad), TB, s, n_pad, w.degn, w.ptr, w.sl4, w.off4, w.sv_in, w.t_desc,
+               w.tpad_off, nt, out->in_nbr, out->in_nbr16);
+    GNN_LAUNCH("pb_fill_lists", (pb_fill_lists<false>), gs(n_pad), TB, s, n_pad, w.degn, w.ptr, w.sl4, w.off4, w.sv_out,
+               w.t_desc, w.tpad_off, nt, out->out_nbr, out->out_nbr16);
+    if (nt > 0) {
+        GNN_LAUNCH("pb_copy_i32", pb_copy_i32, gs((int64_t)nt * 8), TB, s, w.t_desc, out->tiles, (int64_t)nt * 8);
+        GNN_LAUNCH("pb_schedule", pb_schedule, (unsigned)(nt < 4096 ? nt : 4096), 64, s, nt, w.t_desc, w.sl4, out->sched_a,
+                   out->sched_b);
+    }
+    if (nc > 0)
+        GNN_LAUNCH("pb_fill_chunks", pb_fill_chunks, (unsigned)(nc < 4096 ? nc : 4096), TB, s, nc, w.c_desc, src, w.src_new,
+                   w.dst_new, out->chunks, out->src, out->dst, out->sd16);
+    if (out->src_abs) GNN_LAUNCH("pb_copy_i32", pb_copy_i32, gs(E), TB, s, w.src_new, out->src_abs, E);
+    if (out->dst_abs) GNN_LAUNCH("pb_copy_i32", pb_copy_i32, gs(E), TB, s, w.dst_new, out->dst_abs, E);
+    if (out->level) GNN_LAUNCH("pb_copy_i32", pb_copy_i32, gs(n), TB, s, w.lvA, out->level, n);
+    return 0;
+}
+
+}  // extern "C"

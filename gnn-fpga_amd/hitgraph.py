@@ -120,19 +120,31 @@ class HitGraphBatch:
 
     def build_plan(self, hidden_dim, limits=None):
         """Tiles + windows + SELL-16 execution plan of the fused kernels, built once for the
-        kernel shape (input_dim = n_features, hidden_dim): on the GPU with torch ops when the batch
-        lives there (plan_device.py, a fraction of a second for 25.6 M segments), else on the host
-        with numpy (plan.py); both build the same plan, array for array."""
+        kernel shape (input_dim = n_features, hidden_dim): by HIP kernels when the batch lives on the
+        GPU (plan_hip.py / csrc/plan_build.hip; GNN_PLAN_BUILDER=torch selects the torch-op builder
+        plan_device.py, which also takes the batches outside the kernels' bounds), else on the host
+        with numpy (plan.py, the specification); all three build the same plan, array for array."""
         if self.plan is None or self.plan.hidden_dim != hidden_dim:
             from . import _lib
             lim = _lib.plan_limits(self.n_features, hidden_dim)
             lim.update(limits or {})       # tests / experiments: e.g. iter_records=0 -> global mode
-            if self.X.is_cuda and not os.environ.get("GNN_HOST_PLAN"):
+            builder = os.environ.get("GNN_PLAN_BUILDER", "hip" if self.X.is_cuda else "host")
+            if os.environ.get("GNN_HOST_PLAN") or not self.X.is_cuda:
+                builder = "host"
+            plan = None
+            if builder == "hip":          # HIP kernels (csrc/plan_build.hip): milliseconds
+                from .plan_hip import HipSellPlan, PlanBuilderUnsupported
+                try:
+                    plan = HipSellPlan(self, lim)
+                except PlanBuilderUnsupported:
+                    builder = "torch"     # outside the kernels' static bounds, or empty
+            if plan is None and builder == "torch":
                 from .plan_device import DeviceSellPlan
-                self.plan = DeviceSellPlan(self, lim)
-            else:
+                plan = DeviceSellPlan(self, lim)
+            if plan is None:
                 from .plan import SellPlan
-                self.plan = SellPlan(self, lim)
+                plan = SellPlan(self, lim)
+            self.plan = plan
             self.plan.hidden_dim = hidden_dim
             self.plan.to(self.X.device)
         return self.plan

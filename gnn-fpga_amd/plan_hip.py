@@ -1,0 +1,84 @@
+"""The execution plan of plan.py built by HIP kernels (csrc/plan_build.hip) where the batch lives.
+
+Same plan as `plan.SellPlan` (numpy, the specification) and `plan_device.DeviceSellPlan` (torch
+ops), array for array; what changes is the cost: a few dozen kernel launches and ONE host read-back
+(the array sizes) instead of ~300 torch ops with a dozen synchronisations - milliseconds instead of
+0.2 s for the 25.6 M-segment benchmark batch, so that a stream of never-repeated batches (inference
+on real events) no longer pays hundreds of forwards per plan.
+
+Batches outside the builder's static bounds (`sizes.status != 0`: a hit with >= 65536 segments,
+more than n/16 + 1024 tiles, ...) and empty batches raise `PlanBuilderUnsupported`; the caller
+(`HitGraphBatch.build_plan`) then uses the torch builder.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .plan import SLICE, SellPlan
+
+
+class PlanBuilderUnsupported(RuntimeError):
+    pass
+
+
+class HipSellPlan(SellPlan):
+    def __init__(self, batch, limits, debug=False):   # noqa: C901
+        dev = batch.X.device
+        n, E, G = batch.n_hits, batch.n_segments, batch.n_graphs
+        if n <= 0 or E <= 0 or G <= 0:
+            raise PlanBuilderUnsupported("empty batch")
+        tile_hits = int(limits["tile_hits"])
+        want = 512 if int(limits["iter_records"]) > 0 else 256          # plan.py: small batches
+        if n < want * tile_hits:
+            tile_hits = max(64, ((n + want - 1) // want + SLICE - 1) // SLICE * SLICE)
+        CH = int(limits["chunk_segments"])
+        if E < 512 * CH:
+            CH = min(CH, max(1024, (E + 511) // 512))
+        F = batch.n_features
+        if F > 16 or n >= 2 ** 30 or E >= 2 ** 30 or G >= 2 ** 24:
+            raise PlanBuilderUnsupported("batch outside the builder's index ranges")
+        src = batch.src.to(dev).to(torch.int32).contiguous()
+        dst = batch.dst.to(dev).to(torch.int32).contiguous()
+        X = batch.X.to(dev).to(torch.float32).contiguous()
+        hit_ptr = torch.from_numpy(np.ascontiguousarray(batch.hit_ptr, dtype=np.int64)).to(dev)
+        ws = torch.empty(_lib.plan_build_workspace_bytes(n, E, CH), dtype=torch.uint8, device=dev)
+        sz = _lib.plan_build_sizes(src, dst, hit_ptr, n, E, G, tile_hits, int(limits["iter_records"]), CH,
+                                   int(limits["edge_records"]), ws)
+        if sz.status:
+            raise PlanBuilderUnsupported("plan builder status %d" % sz.status)
+        if max(sz.in_total, sz.out_total) + 64 >= 2 ** 31:
+            raise ValueError("SELL list exceeds int32 index range")
+        i32 = lambda k: torch.empty(int(k), dtype=torch.int32, device=dev)     # noqa: E731
+        a = {
+            "X": torch.empty((sz.n_pad + 1 + 64, F), dtype=torch.float32, device=dev),
+            "x_absmax": torch.empty(F, dtype=torch.float32, device=dev),
+            "src": i32(E), "dst": i32(E), "sd16": i32(E),
+            "in_off": i32(sz.n_slices + 1), "in_nbr": i32(sz.in_total + 4 * SLICE),
+            "out_off": i32(sz.n_slices + 1), "out_nbr": i32(sz.out_total + 4 * SLICE),
+            "in_off16": i32(sz.n_slices + 1), "in_nbr16": i32(sz.in16_words + 64),
+            "out_off16": i32(sz.n_slices + 1), "out_nbr16": i32(sz.out16_words + 64),
+            "tiles": i32(8 * sz.n_tiles), "chunks": i32(8 * sz.n_chunks),
+            "sched_a": i32(sz.n_sched), "sched_b": i32(sz.n_sched), "perm": i32(sz.n_pad),
+        }
+        if debug:
+            a["src_abs"], a["dst_abs"], a["level"] = i32(E), i32(E), i32(n)
+        _lib.plan_build_fill(X, src, dst, n, E, CH, sz, ws, a)
+        for k in self._TENSORS:
+            setattr(self, k, a[k])
+        self.n_hits, self.n_pad, self.n_segments = n, int(sz.n_pad), E
+        self.n_features = F
+        self.n_slices, self.n_tiles, self.n_chunks = int(sz.n_slices), int(sz.n_tiles), int(sz.n_chunks)
+        self.iter_lds_records, self.edge_lds_rows = int(sz.iter_lds_records), int(sz.edge_lds_rows)
+        self.n_lds_tiles = int(sz.n_lds_tiles)
+        self.iter_lds_in, self.iter_lds_out = int(sz.iter_lds_in), int(sz.iter_lds_out)
+        self.tile_hits_max, self.max_list_steps = int(sz.tile_hits_max), int(sz.max_list_steps)
+        nv = max(1, int(sz.n_valid))
+        self.padding = (int(sz.in_total) + int(sz.out_total)) / (2 * nv) - 1.0
+        self.lds_tile_fraction = float(np.float64(sz.n_lds_tiles) / np.float64(sz.n_tiles)) if sz.n_tiles else 1.0
+        self.lds_chunk_fraction = float(np.float64(sz.n_lds_chunks) / np.float64(sz.n_chunks)) if sz.n_chunks else 1.0
+        self._dbg = (a.get("src_abs"), a.get("dst_abs"), a.get("level"))
+
+    # host copies for tests (debug=True)
+    src_abs = property(lambda self: self._dbg[0].cpu().numpy().astype(np.int64))
+    dst_abs = property(lambda self: self._dbg[1].cpu().numpy().astype(np.int64))
+    level = property(lambda self: self._dbg[2].cpu().numpy().astype(np.int32))

@@ -229,6 +229,52 @@ int gnn_plan_shape_supported(int32_t F, int32_t D);
  * for the iteration kernel, rows of D floats for the edge kernel). */
 int gnn_plan_limits(int32_t F, int32_t D, int32_t *out4);
 
+/* ---- the plan, built on the GPU (csrc/plan_build.hip) -------------------------------------------
+ * Index-form counterpart of the reference's per-batch host work (graph_from_sparse densifies,
+ * merge_graphs zero-pads: gnn/graph.py:28-35, gnn/trainSegmentClassifier.py:66-111): the same
+ * plan gnn-fpga_amd/plan.py specifies in numpy, array for array, in two calls around ONE host
+ * read-back of the sizes:
+ *   gnn_plan_build_sizes  levels, tiles, renumbering, sorted neighbour lists, windows, chunks ->
+ *                         *sizes_out (DEVICE memory, written asynchronously on `stream`)
+ *   gnn_plan_build_fill   fills the arrays the caller allocated from those sizes (a HOST copy of
+ *                         the sizes is passed back in)
+ * src / dst [n_segments] int32 (-1 = padded), hit_ptr [n_graphs+1] int64 on the DEVICE (graph
+ * boundaries, non-decreasing); tile_hits / iter_records / chunk_segments / edge_records as
+ * gnn_plan_limits gives them (after the caller's small-batch adjustments, plan.py).  sizes.status
+ * != 0: this batch is outside the builder's static bounds (degree >= 65536, > n/16 + 1024 tiles,
+ * ...) - build the plan with plan.py / plan_device.py instead.  n_hits, n_segments > 0. */
+typedef struct gnn_plan_sizes {
+    int64_t n_pad, n_tiles, n_slices, n_chunks;
+    int64_t in_total, out_total;        /* entries of in_nbr / out_nbr before their 64 zero entries */
+    int64_t in16_words, out16_words;    /* words of in_nbr16 / out_nbr16 before their 64 zero words */
+    int64_t n_sched;                    /* entries of sched_a, sched_b                              */
+    int64_t iter_lds_records, edge_lds_rows, n_lds_tiles, n_lds_chunks, iter_lds_in, iter_lds_out;
+    int64_t tile_hits_max, max_list_steps, n_valid, max_level, status;
+} gnn_plan_sizes_t;
+
+typedef struct gnn_plan_out {           /* device arrays gnn_plan_build_fill writes (sizes: gnn_plan_t) */
+    float *X;                           /* [(n_pad + 1 + 64) * F]                                     */
+    float *x_absmax;                    /* [F] per-feature max |X| (gnn_exp_product_bound)            */
+    int32_t *src, *dst, *sd16;          /* [n_segments]                                               */
+    int32_t *in_off, *in_nbr;           /* [n_slices + 1], [in_total + 64]                            */
+    int32_t *out_off, *out_nbr;         /* [n_slices + 1], [out_total + 64]                           */
+    int32_t *in_off16, *in_nbr16;       /* [n_slices + 1], [in16_words + 64]                          */
+    int32_t *out_off16, *out_nbr16;     /* [n_slices + 1], [out16_words + 64]                         */
+    int32_t *tiles, *chunks;            /* [8 n_tiles], [8 n_chunks]                                  */
+    int32_t *sched_a, *sched_b;         /* [n_sched]                                                  */
+    int32_t *perm;                      /* [n_pad] new id -> caller's hit id, -1 = padding            */
+    int32_t *src_abs, *dst_abs, *level; /* optional (NULL): renumbered endpoints [n_segments], levels [n_hits] */
+} gnn_plan_out_t;
+
+size_t gnn_plan_build_workspace_bytes(int64_t n_hits, int64_t n_segments, int32_t chunk_segments);
+int gnn_plan_build_sizes(const int32_t *src, const int32_t *dst, const int64_t *hit_ptr, int64_t n_hits,
+                         int64_t n_segments, int64_t n_graphs, int32_t tile_hits, int32_t iter_records,
+                         int32_t chunk_segments, int32_t edge_records, void *workspace,
+                         size_t workspace_bytes, gnn_plan_sizes_t *sizes_out, void *stream);
+int gnn_plan_build_fill(const float *X, int32_t F, const int32_t *src, const int32_t *dst, int64_t n_hits,
+                        int64_t n_segments, int32_t chunk_segments, const gnn_plan_sizes_t *sizes,
+                        void *workspace, size_t workspace_bytes, const gnn_plan_out_t *out, void *stream);
+
 /* bound_out (device, 1 float) = the left side of the GNN_FLAG_EXP_PRODUCT condition;
  * x_absmax (device, [F]) = per-feature max |X|.  Asynchronous on `stream`. */
 int gnn_exp_product_bound(const gnn_params_t *p, const float *x_absmax, float *bound_out,

@@ -667,7 +667,12 @@ def test_plan_built_on_the_gpu_equals_the_host_plan(hip, lim_over):
     dev = DeviceSellPlan(b.cuda(), lim)
     assert dev.X.is_cuda
     _same_plan(host, dev)
-    assert isinstance(b.cuda().build_plan(8), DeviceSellPlan)
+    import os
+    os.environ["GNN_PLAN_BUILDER"] = "torch"
+    try:
+        assert isinstance(b.cuda().build_plan(8), DeviceSellPlan)
+    finally:
+        del os.environ["GNN_PLAN_BUILDER"]
 
 
 def test_csr_built_on_the_gpu_equals_the_host_csr(hip):

@@ -1,0 +1,117 @@
+"""The HIP plan builder (csrc/plan_build.hip, gnn_plan_build_sizes / gnn_plan_build_fill) against the
+numpy specification plan.SellPlan: EVERY array and scalar equal (integer work: bit-exact), on layered
+detector batches, ragged / tiny graphs, padded segments, forced global-gather mode, wide hidden
+layers, one graph whose levels exceed a tile, muon-size graphs, graphs with cycles / self loops
+(the 64-sweep cap of the level relaxation), shuffled segment order, and BASELINE's c3 graph."""
+import numpy as np
+import pytest
+import torch
+
+from gnn_fpga_amd import HitGraphBatch, synth
+from test_plan import _same_plan
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_graph(n, e, F, seed):
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(-1, 1, (n, F)).astype(np.float32)
+    return synth.HitGraph(X, rng.integers(0, n, e).astype(np.int32), rng.integers(0, n, e).astype(np.int32),
+                          np.zeros(e, np.float32))
+
+
+CASES = ["layered", "ragged", "padded", "global", "wide", "one_graph_big_levels", "muon", "cyclic",
+         "shuffled", "c3", "many_c3", "leading_pads", "tiny_tiles"]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_hip_builder_builds_the_same_plan(hip, case):
+    from gnn_fpga_amd.plan import SellPlan
+    from gnn_fpga_amd.plan_hip import HipSellPlan
+    F, D, lim_over = 3, 8, {}
+    pads = None
+    if case == "layered":
+        graphs = [synth.layered_graph(700, 4000, 3, seed=s) for s in range(5)]
+    elif case == "ragged":
+        graphs = [synth.layered_graph(n, e, 3, n_layers=L, seed=s)
+                  for s, (n, e, L) in enumerate([(40, 90, 10), (3, 2, 2), (300, 2500, 10), (17, 16, 3), (2, 1, 2)])]
+    elif case == "padded":
+        graphs = [synth.layered_graph(200, 900, 3, seed=s) for s in range(3)]
+        pads = slice(0, None, 7)
+    elif case == "leading_pads":
+        graphs = [synth.layered_graph(300, 2000, 3, seed=s) for s in range(2)]
+        pads = slice(0, 37)
+    elif case == "global":
+        graphs = [synth.layered_graph(700, 4000, 3, seed=s) for s in range(3)]
+        lim_over = {"iter_records": 0, "edge_records": 0}
+    elif case == "wide":
+        F, D = 3, 64
+        graphs = [synth.layered_graph(500, 3000, 3, seed=s) for s in range(4)]
+    elif case == "one_graph_big_levels":
+        graphs = [synth.layered_graph(20000, 60000, 3, n_layers=4, seed=3)]
+    elif case == "muon":
+        F = 11
+        graphs = [synth.muon_graph(s) for s in range(700)]
+    elif case == "cyclic":
+        graphs = [_random_graph(400, 3000, 3, 1), _random_graph(37, 90, 3, 2),
+                  synth.layered_graph(600, 5000, 3, seed=3), _random_graph(5, 40, 3, 4)]
+    elif case == "shuffled":
+        g = synth.layered_graph(3000, 30000, 3, seed=5)
+        o = np.random.default_rng(0).permutation(30000)
+        graphs = [synth.HitGraph(g.X, g.src[o], g.dst[o], g.y[o]), synth.layered_graph(2000, 15000, 3, seed=6)]
+    elif case == "c3":
+        graphs = [synth.layered_graph(10000, 100000, 3, seed=0)]
+    elif case == "many_c3":
+        graphs = [synth.layered_graph(10000, 100000, 3, seed=s) for s in range(12)]
+    else:   # tiny_tiles: force the smallest tiles (many tiles, many units per workgroup chunk)
+        graphs = [synth.layered_graph(900, 5000, 3, n_layers=30, seed=s) for s in range(6)]
+        lim_over = {"tile_hits": 64}
+    b = HitGraphBatch.from_graphs(graphs)
+    if pads is not None:     # zero-padded segments (src = dst = -1)
+        src, dst = b.src.numpy().copy(), b.dst.numpy().copy()
+        src[pads] = -1
+        dst[pads] = -1
+        b = HitGraphBatch(b.X.numpy(), src, dst, hit_ptr=b.hit_ptr, seg_ptr=b.seg_ptr)
+    lim = hip.plan_limits(F, D)
+    lim.update(lim_over)
+    host = SellPlan(b, lim)
+    dev = HipSellPlan(b.cuda(), lim, debug=True)
+    assert dev.X.is_cuda
+    _same_plan(host, dev)
+
+
+def test_hip_builder_is_the_default_and_declines_what_it_cannot_hold(hip, monkeypatch):
+    from gnn_fpga_amd.plan_device import DeviceSellPlan
+    from gnn_fpga_amd.plan_hip import HipSellPlan, PlanBuilderUnsupported
+    g = [synth.layered_graph(800, 5000, 3, seed=s) for s in range(3)]
+    assert isinstance(HitGraphBatch.from_graphs(g).cuda().build_plan(8), HipSellPlan)
+    monkeypatch.setenv("GNN_PLAN_BUILDER", "torch")
+    assert isinstance(HitGraphBatch.from_graphs(g).cuda().build_plan(8), DeviceSellPlan)
+    monkeypatch.delenv("GNN_PLAN_BUILDER")
+    empty = HitGraphBatch.from_graphs([synth.layered_graph(50, 0, 3, seed=1)]).cuda()
+    with pytest.raises(PlanBuilderUnsupported):
+        HipSellPlan(empty, hip.plan_limits(3, 8))
+    assert isinstance(empty.build_plan(8), DeviceSellPlan)          # falls back by itself
+    # a hub with >= 65536 segments is outside the 16-bit degree keys of the hit sorts
+    n, e = 70000, 70000
+    X = np.zeros((n, 3), np.float32)
+    hub = synth.HitGraph(X, np.arange(1, e + 1, dtype=np.int32) % n, np.zeros(e, np.int32), np.zeros(e, np.float32))
+    with pytest.raises(PlanBuilderUnsupported):
+        HipSellPlan(HitGraphBatch.from_graphs([hub]).cuda(), hip.plan_limits(3, 8))
+
+
+def test_forward_on_a_hip_built_plan_matches_the_oracle(hip):
+    from gnn_fpga_amd.model import SegmentClassifier
+    from gnn_fpga_amd.plan_hip import HipSellPlan
+    from oracle import index_c
+    torch.manual_seed(0)
+    graphs = [synth.layered_graph(3000, 30000, 3, seed=s) for s in range(6)]
+    m = SegmentClassifier(input_dim=3, hidden_dim=8, n_iters=3).cuda().eval()
+    m.use_events = False
+    b = HitGraphBatch.from_graphs(graphs).cuda()
+    with torch.no_grad():
+        e = m(b)
+    assert isinstance(b.plan, HipSellPlan)
+    params = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    for g, eg in zip(graphs, b.split_scores(e.cpu().numpy())):
+        assert np.abs(eg - index_c.segment_classifier(g.X, g.src, g.dst, params, 3)).max() < 1e-5

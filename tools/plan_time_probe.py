@@ -1,17 +1,32 @@
-"""Execution-plan build time on the GPU for the benchmark batch (second build: kernels loaded)."""
+"""Plan build times on the GPU: HIP builder (csrc/plan_build.hip) vs the torch-op builder."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from gnn_fpga_amd import HitGraphBatch, synth, _lib
+from gnn_fpga_amd.plan_hip import HipSellPlan
 from gnn_fpga_amd.plan_device import DeviceSellPlan
 
-G = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-b = HitGraphBatch.from_graphs([synth.layered_graph(10000, 100000, 3, seed=s) for s in range(G)]).cuda()
-lim = _lib.plan_limits(3, 8)
-for i in range(3):
-    torch.cuda.synchronize(); t = time.perf_counter()
-    p = DeviceSellPlan(b, lim)
-    torch.cuda.synchronize(); print("build %d: %.3f s (%d segments, %d tiles)" % (i, time.perf_counter() - t, b.n_segments, p.n_tiles))
-torch.cuda.synchronize(); t = time.perf_counter()
-b._ensure_csr()
-torch.cuda.synchronize(); print("two CSRs: %.3f s" % (time.perf_counter() - t))
+def probe(name, graphs, F, D, reps=5):
+    lim = _lib.plan_limits(F, D)
+    b = HitGraphBatch.from_graphs(graphs).cuda()
+    out = []
+    for cls in (HipSellPlan, DeviceSellPlan):
+        cls(b, lim); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            cls(b, lim)
+        torch.cuda.synchronize()
+        out.append((time.perf_counter() - t0) / reps * 1e3)
+    with _lib.profile(512) as prof:
+        HipSellPlan(b, lim)
+    per = {}
+    for k, v in prof.records: per[k] = per.get(k, 0.0) + v
+    top = sorted(per.items(), key=lambda kv: -kv[1])[:8]
+    print("%-28s hits %8d segs %9d   HIP %8.3f ms   torch %8.1f ms   kernels (own, ms): %s"
+          % (name, b.n_hits, b.n_segments, out[0], out[1], ", ".join("%s %.3f" % kv for kv in top)))
+
+probe("c3 single graph", [synth.layered_graph(10000, 100000, 3, seed=0)], 3, 8, 20)
+probe("c4 512 muon graphs", [synth.muon_graph(s) for s in range(512)], 11, 8, 20)
+probe("c3 x 32", [synth.layered_graph(10000, 100000, 3, seed=s) for s in range(32)], 3, 8, 5)
+probe("c5 x 8", [synth.layered_graph(50000, 500000, 3, seed=s) for s in range(8)], 3, 64, 5)
+probe("c3 x 256", [synth.layered_graph(10000, 100000, 3, seed=s) for s in range(256)], 3, 8, 3)
