@@ -64,10 +64,10 @@ def algorithmic(n, e, F, D, T, w=4):
     f_in = 2 * n * F * D
     it_b, it_f = b_edge + b_node, f_edge + f_agg + f_node
     return {"bytes": {"k_input": b_in, "k_input4": b_in, "k_edge": b_edge, "k_node": b_node, "k_iter": it_b,
-                      "k_iter2": it_b, "k_pack": 0, "k_pack16": 0,
+                      "k_iter_w": it_b, "k_iter2": it_b, "k_pack": 0, "k_pack16": 0,
                       "forward": b_in + (T + 1) * b_edge + T * b_node},
             "flops": {"k_input": f_in, "k_input4": f_in, "k_edge": f_edge, "k_node": f_agg + f_node,
-                      "k_iter": it_f, "k_iter2": it_f, "k_pack": 0, "k_pack16": 0,
+                      "k_iter": it_f, "k_iter_w": it_f, "k_iter2": it_f, "k_pack": 0, "k_pack16": 0,
                       "forward": f_in + (T + 1) * f_edge + T * (f_agg + f_node)}}
 
 

@@ -285,7 +285,10 @@ struct Cfg {
     // k_iter window: records of 2D floats ([P|R] or [Q|S]); k_edge window: rows of D floats
     static constexpr int it_rec = (D <= 16) ? (lds_bytes - table_bytes - 2048) / (8 * D) : 0;
     static constexpr int ed_rec = (D <= 16) ? (lds_bytes - 2048) / (4 * D) : 0;
-    static constexpr int tile_hits = 1280;      // > one 1000-hit detector level incl. fluctuations
+    // D <= 16: > one 1000-hit detector level incl. fluctuations (LDS windows).  Wide shapes have no
+    // LDS windows; 256-hit tiles = one slice per wave of k_iter_w's 16, and many workgroups per CU
+    // for the fp32 k_iter (4 waves each)
+    static constexpr int tile_hits = (D <= 16) ? 1280 : 256;
     static constexpr int chunk_segments = 16384;   // > one level pair of a 100k-segment graph
     // Cross-slice prefetch keeps ~25 asm-loaded registers in flight while a slice is processed.
     // That is only legal if the register allocator never spills: a spill of an in-flight
@@ -522,6 +525,15 @@ __device__ __forceinline__ unsigned short bf16_rne(float f)
     return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
 }
 
+// two floats -> two bf16 in one dword, round to nearest even: v_cvt_pk_bf16_f32 (one instruction;
+// the integer form above is 4 per element and is kept for the host-order packing kernels)
+__device__ __forceinline__ unsigned pack_bf16(float a, float b)
+{
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2v __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f2v{a, b}, b2v));
+}
+
 template <int F, int D>
 struct BL {                     // bf16 table layout, in 4-byte words
     static_assert(D % 32 == 0 && F <= 8, "matrix-core path: D = 32 or 64, X in one k-step");
@@ -555,10 +567,15 @@ __device__ __forceinline__ float record_weight(const gnn_params_t &p, bool last,
         m = 4;
         d = o - 4 * D;
     } else {
-        const int row = o / (2 * D), pos = o % (2 * D), c = pos / (2 * d4), w = pos % (2 * d4);
-        m = 2 * row + (w >= d4);
-        d = c * d4 + w % d4;
+        // bf16 record rows for k_iter_w, where a hit is 16 lanes and lane p owns dims DL p .. (DL =
+        // D / 16): [P(DL) R(DL)] per lane, so ONE load per lane fetches its piece of both halves and
+        // the 16 lanes read a neighbour's row as whole, contiguous lines
+        constexpr int DL = D / 16;
+        const int row = o / (2 * D), pos = o % (2 * D), blk = pos / (2 * DL), w = pos % (2 * DL);
+        m = 2 * row + (w >= DL);
+        d = blk * DL + w % DL;
     }
+    (void)d4;
     if (bias) return m == 0 ? kTwoLog2e * p.b1[d] : m == 4 ? p.b3[d] : 0.0f;
     switch (m) {
     case 0: return kTwoLog2e * p.W1[d * 2 * C + k];
@@ -576,11 +593,12 @@ __global__ __launch_bounds__(256) void k_pack16(gnn_params_t p, unsigned *__rest
 {
     using B = BL<F, D>;
     if (blockIdx.x == 0 && threadIdx.x < 2 * D) {       // bf16 NULL records (cf. write_null_rows)
-        constexpr int d4 = D / 4;
-        const int t = threadIdx.x, c = t / (2 * d4), w = t % (2 * d4);
-        float pv = (w < d4) ? kTwoLog2e * p.b1[c * d4 + w] : 0.0f;
-        if (xp && w < d4) pv = __builtin_amdgcn_exp2f(pv);
-        const float qv = (xp && w < d4) ? 1.0f : 0.0f;
+        constexpr int DL = D / 16;                      // row position: [P(DL) R(DL)] per lane of k_iter_w
+        const int t = threadIdx.x, blk = t / (2 * DL), w = t % (2 * DL);
+        const bool is_p = w < DL;
+        float pv = is_p ? kTwoLog2e * p.b1[blk * DL + w] : 0.0f;
+        if (xp && is_p) pv = __builtin_amdgcn_exp2f(pv);
+        const float qv = (xp && is_p) ? 1.0f : 0.0f;
         unsigned short *a = reinterpret_cast<unsigned short *>(PRa), *b = reinterpret_cast<unsigned short *>(PRb);
         unsigned short *cq = reinterpret_cast<unsigned short *>(QSa), *dq = reinterpret_cast<unsigned short *>(QSb);
         a[n_pad * 2 * D + t] = b[n_pad * 2 * D + t] = bf16_rne(pv);
@@ -621,10 +639,10 @@ __global__ __launch_bounds__(256) void k_pack16(gnn_params_t p, unsigned *__rest
 template <int NTILE>
 __device__ __forceinline__ bf16x8_t act_frag(const float (*v)[4], int st)
 {
-    bf16x8_t b;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) b[j] = (short)bf16_rne(v[2 * st + j / 4][j % 4]);
-    return b;
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    const u4v w = {pack_bf16(v[2 * st][0], v[2 * st][1]), pack_bf16(v[2 * st][2], v[2 * st][3]),
+                   pack_bf16(v[2 * st + 1][0], v[2 * st + 1][1]), pack_bf16(v[2 * st + 1][2], v[2 * st + 1][3])};
+    return __builtin_bit_cast(bf16x8_t, w);
 }
 
 template <int F, int D, bool LAST, bool XP>
@@ -632,7 +650,13 @@ __device__ __forceinline__ void mfma_records(const bf16x8_t *Tm, const float *bm
                                              const float (*v)[4], bf16x8_t xb, int lane, int64_t n0,
                                              float *__restrict__ PRn, float *__restrict__ QSn,
                                              float *__restrict__ U, float *__restrict__ Pc,
-                                             float *__restrict__ Qc);
+                                             float *__restrict__ Qc, int T0 = 0, int TS = 1);
+
+template <int F, int D, bool LAST, bool XP>
+__device__ __forceinline__ void mfma_tail_scratch(const unsigned *tb, const float *tr, int lane, int64_t n0,
+                                                  float *__restrict__ PRn, float *__restrict__ QSn,
+                                                  float *__restrict__ U, float *__restrict__ Pc,
+                                                  float *__restrict__ Qc, int T0 = 0, int TS = 1);
 
 // Hit update + records of one slice on the matrix cores.  `tb`: LDS [T4 | Tm | b4 | bm] (BL);
 // `tr`: this wave's transpose scratch [16][D + 4]; acc / xv in the sweep's lane layout
@@ -663,6 +687,24 @@ __device__ __forceinline__ void mfma_tail(const unsigned *tb, float *tr, const f
 #pragma unroll
             for (int k = 0; k < F; ++k) tr[hit * B::tr_stride + D + k] = xv[k];
     }
+    mfma_tail_scratch<F, D, LAST, XP>(tb, tr, lane, n0, PRn, QSn, U, Pc, Qc);
+}
+
+// the same from a scratch the caller has filled: tr[hit][0 .. D) = tanh(acc), tr[hit][D .. D + F) = X;
+// record tiles T0, T0 + TS, ... only (several waves may share one slice's records)
+template <int F, int D, bool LAST, bool XP>
+__device__ __forceinline__ void mfma_tail_scratch(const unsigned *tb, const float *tr, int lane, int64_t n0,
+                                                  float *__restrict__ PRn, float *__restrict__ QSn,
+                                                  float *__restrict__ U, float *__restrict__ Pc,
+                                                  float *__restrict__ Qc, int T0, int TS)
+{
+    using B = BL<F, D>;
+    constexpr int NT1 = B::NT1, KS1 = B::KS1;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const bf16x8_t *T4 = reinterpret_cast<const bf16x8_t *>(tb);
+    const bf16x8_t *Tm = T4 + NT1 * KS1 * 64;
+    const float *b4 = reinterpret_cast<const float *>(tb + NT1 * KS1 * 256 + B::template tm_words<LAST>());
+    const float *bm = b4 + D;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // own wave's LDS writes have landed
     const int hit = lane & 15, g = lane >> 4;
     float v[NT1][4];
@@ -689,7 +731,7 @@ __device__ __forceinline__ void mfma_tail(const unsigned *tb, float *tr, const f
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(T4[(T * KS1 + st) * 64 + lane], qb[st], c, 0, 0, 0);
         v[T][0] = tanh_f(c.x); v[T][1] = tanh_f(c.y); v[T][2] = tanh_f(c.z); v[T][3] = tanh_f(c.w);
     }
-    mfma_records<F, D, LAST, XP>(Tm, bm, v, xb, lane, n0, PRn, QSn, U, Pc, Qc);
+    mfma_records<F, D, LAST, XP>(Tm, bm, v, xb, lane, n0, PRn, QSn, U, Pc, Qc, T0, TS);
 }
 
 // records = Wm [hl | x] + bias, tile by tile, stored as 16-byte pieces of the record rows.
@@ -700,7 +742,7 @@ __device__ __forceinline__ void mfma_records(const bf16x8_t *Tm, const float *bm
                                              const float (*v)[4], bf16x8_t xb, int lane, int64_t n0,
                                              float *__restrict__ PRn, float *__restrict__ QSn,
                                              float *__restrict__ U, float *__restrict__ Pc,
-                                             float *__restrict__ Qc)
+                                             float *__restrict__ Qc, int T0, int TS)
 {
     using B = BL<F, D>;
     constexpr int d4 = D / 4, NT1 = B::NT1, KS1 = B::KS1, KS2 = B::KS2;
@@ -711,8 +753,11 @@ __device__ __forceinline__ void mfma_records(const bf16x8_t *Tm, const float *bm
 #pragma unroll
     for (int st = 0; st < KS1; ++st) hb[st] = act_frag<NT1>(v, st);
     const int64_t n = n0 + hit;
+    (void)d4;
 #pragma unroll
-    for (int T = 0; T < NT2; ++T) {
+    for (int Tu = 0; Tu < NT2; ++Tu) {
+        if (TS != 1 && (Tu % 4) != T0) continue;                   // (TS is 1 or 4; wave-uniform)
+        const int T = Tu;
         f4v c = *reinterpret_cast<const f4v *>(bm + 16 * T + 4 * g);
 #pragma unroll
         for (int st = 0; st < KS2; ++st)
@@ -721,6 +766,7 @@ __device__ __forceinline__ void mfma_records(const bf16x8_t *Tm, const float *bm
         const int o = 16 * T + 4 * g;                              // first of this lane's 4 outputs
         float *dst;
         bool expo;                                                 // a P / Q position: 2^x in XP mode
+        bool expo_half = false;                                    // D = 32: [P P R R] inside one store
         if constexpr (LAST) {
             dst = (o < D ? Pc + n * D + o : Qc + n * D + (o - D));
             expo = true;
@@ -729,19 +775,19 @@ __device__ __forceinline__ void mfma_records(const bf16x8_t *Tm, const float *bm
             expo = false;
         } else {
             dst = (o < 2 * D ? PRn + n * 2 * D + o : QSn + n * 2 * D + (o - 2 * D));
-            expo = (o % (2 * d4)) < d4;
+            constexpr int DL = D / 16;                             // rows: [P(DL) R(DL)] per 2 DL positions
+            expo = (o % (2 * DL)) < DL;
+            expo_half = DL == 2;
         }
         if (XP && expo) {
             c.x = __builtin_amdgcn_exp2f(c.x); c.y = __builtin_amdgcn_exp2f(c.y);
-            c.z = __builtin_amdgcn_exp2f(c.z); c.w = __builtin_amdgcn_exp2f(c.w);
+            if (!expo_half) { c.z = __builtin_amdgcn_exp2f(c.z); c.w = __builtin_amdgcn_exp2f(c.w); }
         }
         if (!LAST && o < 4 * D) {
             // gather records travel as bf16 (row = 2D halfwords, same position order): half the
             // bytes per list step, half the registers per record group
             unsigned *row = reinterpret_cast<unsigned *>(o < 2 * D ? PRn : QSn) + n * D + (o % (2 * D)) / 2;
-            *reinterpret_cast<uint2 *>(row) =
-                make_uint2((unsigned)bf16_rne(c.x) | ((unsigned)bf16_rne(c.y) << 16),
-                           (unsigned)bf16_rne(c.z) | ((unsigned)bf16_rne(c.w) << 16));
+            *reinterpret_cast<uint2 *>(row) = make_uint2(pack_bf16(c.x, c.y), pack_bf16(c.z, c.w));
         } else {
             *reinterpret_cast<f4v *>(dst) = c;
         }
@@ -1506,6 +1552,213 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_iter(
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_iter_w: the iteration kernel for WIDE hidden layers (D = 32 / 64) on bf16 records
+// (GNN_FLAG_BF16_MLP; BASELINE configs[4], gnn/MPNN_Seg_ACTS_mu200.ipynb: D = 64, T = 6)
+// ---------------------------------------------------------------------------------------------
+// What the counters said about the 4-lanes-per-hit form at D = 64 (profiles/r02_c5_a): 420
+// registers per lane = ONE wave per SIMD, 320 workgroups for 256 CUs, 38 % L2 hit rate on the record
+// gathers (1.8 of the 2 GB gathered per launch came over the fabric), i.e. latency-bound at 4 TB/s.
+// Here a hit is 16 lanes (lane p owns dims 4p .. 4p+3): a neighbour's 256-byte bf16 record row
+// [P(D) | R(D)] is read as two full 128-byte lines by the 16 lanes (8 bytes each), a record group
+// of 4 list steps costs 16 registers instead of 64, the whole sweep fits 128 registers, and a
+// 1024-thread workgroup (4 waves per SIMD) shares ONE copy of the 70 KB bf16 weight fragments.
+// The W2 dot product is finished by the 4x4 transpose-add inside each quad plus two row rotations
+// across the 4 quads of a hit.  Workgroups are persistent: the tables are staged once, then each
+// XCD walks its own contiguous range of 256-hit tiles (its 32 CUs work on ~1.6 detector levels at a
+// time, whose records fit the XCD's L2), wave w of a workgroup taking slice (w + k) & 15 of the
+// k-th tile it visits - no barrier after the staging.  The hit update runs on the matrix cores
+// from the wave's own LDS scratch (mfma_tail_scratch), 16 hits at a time.
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float v)     // row_ror:n etc.: all 16 lanes of a row are valid sources
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// DL = D / 16 dims per lane; a lane's piece of a record row is [P(DL) R(DL)] bf16: 16 bytes at
+// D = 64, 8 bytes at D = 32 - one load
+template <int DL> struct PieceW;
+template <> struct PieceW<4> {
+    uint4 w;
+    __device__ __forceinline__ void load(const unsigned *a) { w = *reinterpret_cast<const uint4 *>(a); }
+    __device__ __forceinline__ void first(float *f) const { f[0] = bf_lo(w.x); f[1] = bf_hi(w.x); f[2] = bf_lo(w.y); f[3] = bf_hi(w.y); }
+    __device__ __forceinline__ void second(float *f) const { f[0] = bf_lo(w.z); f[1] = bf_hi(w.z); f[2] = bf_lo(w.w); f[3] = bf_hi(w.w); }
+};
+template <> struct PieceW<2> {
+    uint2 w;
+    __device__ __forceinline__ void load(const unsigned *a) { w = *reinterpret_cast<const uint2 *>(a); }
+    __device__ __forceinline__ void first(float *f) const { f[0] = bf_lo(w.x); f[1] = bf_hi(w.x); }
+    __device__ __forceinline__ void second(float *f) const { f[0] = bf_lo(w.y); f[1] = bf_hi(w.y); }
+};
+
+template <int D>
+struct RecW {                   // one step group (4 list steps): this lane's piece of each of the 4 records
+    static constexpr int DL = D / 16;
+    PieceW<DL> r[4];
+    // 32-bit byte offsets off the wave-uniform table base (one v_lshl_or / v_mad per address instead
+    // of a 64-bit multiply-add; the host checks that the table is below 4 GB)
+    __device__ __forceinline__ void read(int cur, const unsigned *__restrict__ REC, unsigned lane_off)
+    {
+        const int nb[4] = {quad_bcast_i<0>(cur), quad_bcast_i<1>(cur), quad_bcast_i<2>(cur), quad_bcast_i<3>(cur)};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            r[j].load(reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(REC) +
+                                                         ((unsigned)nb[j] * (unsigned)(4 * D) + lane_off)));
+    }
+};
+
+// score the 4 segments of a group for the 4 hits of this wave pass and add their weighted R / S
+template <int D, bool XP>
+__device__ __forceinline__ void score_w(const RecW<D> &g, const float *own, const float *w2, float b2, int p,
+                                        float *acc)
+{
+    constexpr int DL = D / 16;
+    float part[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float P[DL];
+        g.r[j].first(P);
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < DL; ++i) {
+            const float r = XP ? __builtin_amdgcn_rcpf(fmaf(P[i], own[i], 1.0f)) : r_f(P[i] + own[i]);
+            s = fmaf(w2[i], r, s);
+        }
+        part[j] = s;
+    }
+    // 4x4 transpose-add inside the quad (as score4), then the other three quads of this hit
+    const int q = p & 3;
+    const bool odd = q & 1, hi = q & 2;
+    const float s0 = odd ? part[0] : part[1], s1 = odd ? part[2] : part[3];
+    const float k0 = odd ? part[1] : part[0], k1 = odd ? part[3] : part[2];
+    const float t0 = k0 + dpp<0xB1>(s0), t1 = k1 + dpp<0xB1>(s1);
+    const float give = hi ? t0 : t1, keep = hi ? t1 : t0;
+    float mine = keep + dpp<0x4E>(give);               // segment q: sum over this quad's 4 DL dims
+    mine += dpp_row<0x124>(mine);                      // row_ror:4
+    mine += dpp_row<0x128>(mine);                      // row_ror:8  -> all D dims
+    const float e = r_f(mine + b2);
+    const float e4[4] = {quad_bcast_f<0>(e), quad_bcast_f<1>(e), quad_bcast_f<2>(e), quad_bcast_f<3>(e)};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float R[DL];
+        g.r[j].second(R);
+#pragma unroll
+        for (int i = 0; i < DL; ++i) acc[i] = fmaf(e4[j], R[i], acc[i]);
+    }
+}
+
+// walk one hit's list (all 16 lanes of the hit together); `lst` = nbr + the slice's list base
+// (wave-uniform), `i16` the hit's index in the slice; two record groups in flight
+template <int D, bool XP>
+__device__ __forceinline__ void sweep_w(const int32_t *__restrict__ lst, int i16, int len, int null_idx,
+                                        const unsigned *__restrict__ REC, int p, const float *own, const float *w2,
+                                        float b2, float *acc)
+{
+    if (len <= 0) return;
+    constexpr int DL = D / 16;
+    const int ng = (len + 3) >> 2;
+    const unsigned lane_off = (unsigned)(4 * DL * p);
+    const unsigned st_off = (unsigned)((SLICE * (p & 3) + i16) * 4);      // byte offset of step (p & 3)
+    auto index_of = [&](int c) {               // lane p reads step 4c + (p & 3); quads broadcast it
+        const int cur = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(lst) +
+                                                             ((unsigned)(c * 4 * SLICE * 4) + st_off));
+        return 4 * c + (p & 3) < len ? cur : null_idx;   // (up to 3 steps past the end: plan.py pads the arrays)
+    };
+    RecW<D> a, b;
+    int ia = index_of(0), ib = ng > 1 ? index_of(1) : 0;
+    a.read(ia, REC, lane_off);
+    for (int c = 0; c < ng; c += 2) {
+        if (c + 1 < ng) b.read(ib, REC, lane_off);
+        if (c + 2 < ng) ia = index_of(c + 2);
+        score_w<D, XP>(a, own, w2, b2, p, acc);
+        if (c + 1 < ng) {
+            if (c + 2 < ng) a.read(ia, REC, lane_off);
+            if (c + 3 < ng) ib = index_of(c + 3);
+            score_w<D, XP>(b, own, w2, b2, p, acc);
+        }
+    }
+}
+
+template <int F, int D, bool LAST, bool XP>
+__global__ __launch_bounds__(1024) void k_iter_w(
+    const float *__restrict__ X, const float *__restrict__ table, const unsigned *__restrict__ t16,
+    const int32_t *__restrict__ tiles, const int32_t *__restrict__ in_off, const int32_t *__restrict__ in_nbr,
+    const int32_t *__restrict__ out_off, const int32_t *__restrict__ out_nbr, const unsigned *__restrict__ PR,
+    const unsigned *__restrict__ QS, float *__restrict__ U, float *__restrict__ PRn, float *__restrict__ QSn,
+    float *__restrict__ Pc, float *__restrict__ Qc, int64_t n_pad, int tiles_per_xcd, int n_tiles)
+{
+    using L = TL<F, D>;
+    using B = BL<F, D>;
+    static_assert(D % 32 == 0, "16 lanes x 4 dims per hit, matrix-core tail");
+    (void)tiles; (void)tiles_per_xcd; (void)n_tiles;   // (the walk is over slices; tiles only order them)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned *tb = reinterpret_cast<unsigned *>(smem);
+    {
+        constexpr int n1 = B::NT1 * B::KS1 * 256, nm = B::template tm_words<LAST>();
+        for (int i = threadIdx.x; i < n1; i += 1024) tb[i] = t16[B::o_t4 + i];
+        for (int i = threadIdx.x; i < nm; i += 1024) tb[n1 + i] = t16[(LAST ? B::o_tml : B::o_tmn) + i];
+        for (int i = threadIdx.x; i < D; i += 1024) tb[n1 + nm + i] = t16[B::o_b4 + i];
+        for (int i = threadIdx.x; i < (LAST ? 2 : 5) * D; i += 1024)
+            tb[n1 + nm + D + i] = t16[(LAST ? B::o_bml : B::o_bmn) + i];
+    }
+    __syncthreads();                                   // the only barrier: waves are independent below
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int hs = lane >> 4, p = lane & 15;
+    // Teams: 4 waves share a slice (wave m of team t sweeps hits 4m .. 4m+3), so only 4 slices per
+    // CU = 2048 hits per XCD are in progress at a time and the records they gather (one level's
+    // [P|R] and [Q|S] tables, 2.6 MB at 5000-hit levels) stay in the XCD's 4 MB L2 - with a whole
+    // slice per wave the 8192 hits in progress per XCD span 1.6 levels and 52 % of the gathers
+    // missed L2 (profiles/r02_c5_b).  The team's scratch is double-buffered: one barrier per round.
+    const int team = wv >> 2, mem = wv & 3;
+    float *scratch = smem + B::template lds_words<LAST>();
+    constexpr int DL = D / 16;                         // dims per lane
+    float w2[DL];
+#pragma unroll
+    for (int i = 0; i < DL; ++i) w2[i] = table[(p >> 2) * L::stride + L::o_w2 + DL * (p & 3) + i];
+    const float b2 = table[L::o_b2];
+    // XCD x (blockIdx & 7) walks its own contiguous eighth of the slices (whole graphs stay in one
+    // L2); its workgroups take consecutive groups of 4 slices round-robin, so the slices in progress
+    // on an XCD are one contiguous run of 4 x (workgroups per XCD) slices
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int n_slices = (int)(n_pad / SLICE);
+    const int span = (((n_slices + 7) >> 3) + 3) & ~3;
+    const int s_end = (xcd + 1) * span < n_slices ? (xcd + 1) * span : n_slices;
+    int buf = 0;
+    {
+        for (int s0 = xcd * span + 4 * local; s0 < s_end; s0 += 4 * per_xcd, buf ^= 1) {   // workgroup-uniform
+            const int sl = s0 + team;
+            float *tr = scratch + (buf * 4 + team) * 16 * B::tr_stride;
+            if (sl < s_end) {
+                const int ib = __builtin_amdgcn_readfirstlane(in_off[sl]);
+                const int il = (__builtin_amdgcn_readfirstlane(in_off[sl + 1]) - ib) >> 4;
+                const int ob = __builtin_amdgcn_readfirstlane(out_off[sl]);
+                const int ol = (__builtin_amdgcn_readfirstlane(out_off[sl + 1]) - ob) >> 4;
+                const int i16 = 4 * mem + hs;
+                const int64_t n = (int64_t)sl * SLICE + i16;
+                float acc[DL], ownQ[DL], ownP[DL];
+                load_vec<DL>(U + n * D + DL * p, acc);
+                PieceW<DL> qw, pw;
+                qw.load(QS + n * D + DL * p);
+                pw.load(PR + n * D + DL * p);
+                qw.first(ownQ);
+                pw.first(ownP);
+                // segments ending here: P[start] with own Q, adds e R[start]; then starting here
+                sweep_w<D, XP>(in_nbr + ib, i16, il, (int)n_pad, PR, p, ownQ, w2, b2, acc);
+                sweep_w<D, XP>(out_nbr + ob, i16, ol, (int)n_pad, QS, p, ownP, w2, b2, acc);
+#pragma unroll
+                for (int i = 0; i < DL; ++i) acc[i] = tanh_f(acc[i]);
+                store_vec<DL>(tr + i16 * B::tr_stride + DL * p, acc);
+                if (p < F) tr[i16 * B::tr_stride + D + p] = X[n * F + p];
+            }
+            __syncthreads();                           // the team's 16 hits are in the scratch
+            // hit update H' = tanh(W4 tanh(acc) + b4) (every wave of the team, 8 MFMAs) and this
+            // wave's quarter of the record tiles of the next pass (model.py:94-98,125)
+            if (sl < s_end)
+                mfma_tail_scratch<F, D, LAST, XP>(tb, tr, lane, (int64_t)sl * SLICE, PRn, QSn, U, Pc, Qc, mem, 4);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // exact-fp32 matrix-core products of k_iter2 (D = 8): v_mfma_f32_16x16x4_f32 is a k-ordered fmaf
 // chain, so moving the per-hit MLPs there changes no tolerance - and frees the vector pipe.
 // ---------------------------------------------------------------------------------------------
@@ -2235,6 +2488,52 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_edge(
     }
 }
 
+// final edge pass for wide hidden layers (no LDS windows): 16 lanes per segment, lane p owns dims
+// DL p .. of the start hit's P row and the end hit's Q row - a row is read as whole 128-byte lines
+// by the 16 lanes (one lane per segment made every load instruction touch 64 different rows:
+// 3.8 TB/s of gathered bytes, 66 % of the wave cycles waiting on issue, profiles/r02_c5_a).  XCD x
+// walks its own contiguous eighth of the segments (graphs stay in one L2), two passes in flight.
+template <int F, int D, bool XP>
+__global__ __launch_bounds__(256) void k_edge_w(const int32_t *__restrict__ src, const int32_t *__restrict__ dst,
+                                                const float *__restrict__ Pc, const float *__restrict__ Qc,
+                                                const float *__restrict__ table, float *__restrict__ e,
+                                                int64_t n_segments)
+{
+    constexpr int DL = D / 16;
+    const float *__restrict__ W2 = table + TL<F, D>::o_flat;
+    const int lane = threadIdx.x & 63, hs = lane >> 4, p = lane & 15;
+    float w2[DL];
+#pragma unroll
+    for (int i = 0; i < DL; ++i) w2[i] = W2[DL * p + i];
+    const float b2 = W2[D];
+    const int64_t per = (n_segments + 7) / 8;
+    const int64_t lo = (int64_t)(blockIdx.x & 7) * per;
+    const int64_t hi = lo + per < n_segments ? lo + per : n_segments;
+    const int64_t wave = (int64_t)(blockIdx.x >> 3) * 4 + (threadIdx.x >> 6), nwaves = (int64_t)(gridDim.x >> 3) * 4;
+    auto rows = [&](int64_t j, float *P, float *Q) {
+        const int s = j < hi ? src[j] : 0, d = j < hi ? dst[j] : 0;
+        load_vec<DL>(Pc + (int64_t)s * D + DL * p, P);
+        load_vec<DL>(Qc + (int64_t)d * D + DL * p, Q);
+    };
+    auto score = [&](int64_t j, const float *P, const float *Q) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < DL; ++i)
+            acc = fmaf(w2[i], XP ? __builtin_amdgcn_rcpf(fmaf(P[i], Q[i], 1.0f)) : r_f(P[i] + Q[i]), acc);
+        acc = quad_sum(acc);
+        acc += dpp_row<0x124>(acc);
+        acc += dpp_row<0x128>(acc);
+        if (p == 0 && j < hi) e[j] = r_f(acc + b2);
+    };
+    for (int64_t b0 = lo + 8 * wave; b0 < hi; b0 += 8 * nwaves) {
+        float P0[DL], Q0[DL], P1[DL], Q1[DL];
+        rows(b0 + hs, P0, Q0);
+        rows(b0 + 4 + hs, P1, Q1);
+        score(b0 + hs, P0, Q0);
+        score(b0 + 4 + hs, P1, Q1);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -2279,7 +2578,9 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
     const int64_t Np = pl->n_pad, E = pl->n_segments;
     Ws w = carve(ws, Np, L::total, D, t16_words<F, D>());
     constexpr bool can_bf = t16_words<F, D>() > 0;
-    const bool bf = can_bf && (p->flags & GNN_FLAG_BF16_MLP) && n_iters > 0;
+    // (k_iter_w addresses record rows and list steps with 32-bit byte offsets)
+    const bool bf = can_bf && (p->flags & GNN_FLAG_BF16_MLP) && n_iters > 0 &&
+                    (uint64_t)(Np + 2) * D * 4 < (1ull << 32);
     if constexpr (can_bf)
         if (bf && Np > 0)
             GNN_LAUNCH("k_pack16", (k_pack16<F, D>), 64, 256, s, *p, w.t16, w.PRa, w.PRb, w.QSa, w.QSb, Np,
@@ -2385,24 +2686,27 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
             }
             bool launched = false;
             if constexpr (can_bf) {
-                if (bf) {           // matrix-core hit update (bf16 operands, fp32 accumulate)
+                if (bf) {           // wide hidden layers on bf16 records: k_iter_w (16 lanes per hit)
                     using B = BL<F, D>;
-                    const size_t trw = (size_t)(G::NT / 64) * 16 * B::tr_stride;
                     static DevOnce bf_attr;
                     if (bf_attr.need()) {
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter<F, D, true, XP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter<F, D, false, XP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter_w<F, D, true, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter_w<F, D, false, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
                     }
+                    const int ncu = device_cus();
+                    const unsigned wgs = (unsigned)(((nt < ncu ? nt : ncu) + 7) / 8 * 8);   // persistent, 8 | grid
+                    const size_t trw = (size_t)2 * 4 * 16 * B::tr_stride;      // double-buffered scratch of the 4 teams
+                    const unsigned *PRh = reinterpret_cast<const unsigned *>(PR), *QSh = reinterpret_cast<const unsigned *>(QS);
                     if (t + 1 == n_iters)
-                        GNN_LAUNCH_SH("k_iter", (k_iter<F, D, true, XP, true>), 8 * tpx, G::NT,
-                                      (B::template lds_words<true>() + trw) * 4, s, pl->X, w.table, pl->tiles,
-                                      pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PR, QS, w.U, PRn, QSn,
-                                      w.Pc, w.Qc, Np, tpx, nt, ablate, w.t16);
+                        GNN_LAUNCH_SH("k_iter_w", (k_iter_w<F, D, true, XP>), wgs, 1024,
+                                      (B::template lds_words<true>() + trw) * 4, s, pl->X, w.table, w.t16, pl->tiles,
+                                      pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PRh, QSh, w.U, PRn, QSn,
+                                      w.Pc, w.Qc, Np, tpx, nt);
                     else
-                        GNN_LAUNCH_SH("k_iter", (k_iter<F, D, false, XP, true>), 8 * tpx, G::NT,
-                                      (B::template lds_words<false>() + trw) * 4, s, pl->X, w.table, pl->tiles,
-                                      pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PR, QS, w.U, PRn, QSn,
-                                      w.Pc, w.Qc, Np, tpx, nt, ablate, w.t16);
+                        GNN_LAUNCH_SH("k_iter_w", (k_iter_w<F, D, false, XP>), wgs, 1024,
+                                      (B::template lds_words<false>() + trw) * 4, s, pl->X, w.table, w.t16, pl->tiles,
+                                      pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PRh, QSh, w.U, PRn, QSn,
+                                      w.Pc, w.Qc, Np, tpx, nt);
                     launched = true;
                 }
             }
@@ -2426,8 +2730,19 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
         static DevOnce edge_attr;
         if (edge_attr.need())
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_edge<F, D, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
-        GNN_LAUNCH_SH("k_edge", (k_edge<F, D, XP>), 8 * cpx, G::NT, ed_lds, s, pl->chunks, pl->src, pl->dst, pl->sd16, w.Pc,
-                   w.Qc, w.table, e_out, Np, cpx, nc);
+        if constexpr (G::ed_rec == 0 && D % 16 == 0) {
+            // wide rows, no LDS windows: every chunk is in global mode (absolute ids; padded
+            // segments point at the NULL rows), so the chunk descriptors are not needed
+            const int64_t waves = (E + 7) / 8;                            // 8 segments per wave trip
+            int64_t wg = (waves + 3) / 4;
+            const int64_t cap = (int64_t)device_cus() * 8;                // 8 workgroups of 256 per CU
+            wg = wg < cap ? wg : cap;
+            GNN_LAUNCH("k_edge", (k_edge_w<F, D, XP>), (unsigned)((wg + 7) / 8 * 8), 256, s, pl->src, pl->dst, w.Pc, w.Qc,
+                       w.table, e_out, E);
+        } else {
+            GNN_LAUNCH_SH("k_edge", (k_edge<F, D, XP>), 8 * cpx, G::NT, ed_lds, s, pl->chunks, pl->src, pl->dst, pl->sd16, w.Pc,
+                       w.Qc, w.table, e_out, Np, cpx, nc);
+        }
     }
     return 0;
 }
