@@ -93,6 +93,10 @@ SIGNATURES = {
     "gnn_segclf_backward": (ctypes.c_int, [ctypes.POINTER(GnnGraph), ctypes.POINTER(GnnParams),
                                            _i32, _f, _f, _f, ctypes.POINTER(GnnGrads), _f, _sz, _f]),
     "gnn_bce_loss": (ctypes.c_int, [_f, _f, _i64, ctypes.c_float, _f, _f, _f, _f]),
+    "gnn_edge_bwd": (ctypes.c_int, [_f, _i32, ctypes.POINTER(GnnGraph), ctypes.POINTER(GnnParams), _f, _f, _f,
+                                    ctypes.POINTER(GnnGrads), _f, _sz, _f]),
+    "gnn_node_bwd": (ctypes.c_int, [_f, _i32, _f, _f, ctypes.POINTER(GnnGraph), ctypes.POINTER(GnnParams), _f, _f,
+                                    _f, ctypes.POINTER(GnnGrads), _f, _sz, _f]),
     "gnn_plan_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
     "gnn_segclf_forward_plan": (ctypes.c_int, [ctypes.POINTER(GnnPlan), ctypes.POINTER(GnnParams),
                                                _i32, _f, _f, _sz, _f]),
@@ -399,6 +403,54 @@ def segclf_backward(batch, weights, F, D, n_iters, e_all, H_all, grad_out):
                                           _dev(grad_out, torch.float32, "grad_out"),
                                           ctypes.byref(gs), ws.data_ptr(), ws.numel(), st))
     return grads
+
+
+def _grad_views(weights, dev):
+    """One zero-filled flat buffer, ten views shaped like the weights (state_dict order)."""
+    flat = torch.zeros(sum(w.numel() for w in weights), dtype=torch.float32, device=dev)
+    grads, o = [], 0
+    for w in weights:
+        grads.append(flat[o:o + w.numel()].view_as(w))
+        o += w.numel()
+    gs = GnnGrads()
+    for name, t in zip(("Win", "bin", "W1", "b1", "W2", "b2", "W3", "b3", "W4", "b4"), grads):
+        setattr(gs, name, t.data_ptr())
+    return grads, gs
+
+
+def edge_bwd(H, batch, weights, F, D, e, grad_e):
+    """Backward of EdgeNetwork.forward: (grad_H [n_hits, ldh], [gW1, gb1, gW2, gb2]).
+    `weights`: the ten effective tensors (only the edge network's four are read)."""
+    dev = H.device
+    grads, gs = _grad_views(weights, dev)
+    gH = torch.zeros_like(H)
+    ws = torch.empty(int(load().gnn_backward_workspace_bytes(batch.n_hits, batch.n_segments, F, D)),
+                     dtype=torch.uint8, device=dev)
+    g = cached_graph_struct(batch)
+    p = params_struct(weights, F, D)
+    with _on(H, g, p) as st:
+        _check(load().gnn_edge_bwd(_dev(H, torch.float32, "H"), H.shape[1], ctypes.byref(g), ctypes.byref(p),
+                                   _dev(e, torch.float32, "e"), _dev(grad_e, torch.float32, "grad_e"),
+                                   _dev(gH, torch.float32, "grad_H"), ctypes.byref(gs), ws.data_ptr(), ws.numel(), st))
+    return gH, grads[2:6]
+
+
+def node_bwd(H, e, Hn, batch, weights, F, D, grad_Hn):
+    """Backward of NodeNetwork.forward: (grad_H [n_hits, ldh], grad_e [n_segments], [gW3, gb3, gW4, gb4])."""
+    dev = H.device
+    grads, gs = _grad_views(weights, dev)
+    gH = torch.empty_like(H)
+    ge = torch.empty(batch.n_segments, dtype=torch.float32, device=dev)
+    ws = torch.empty(int(load().gnn_backward_workspace_bytes(batch.n_hits, batch.n_segments, F, D)),
+                     dtype=torch.uint8, device=dev)
+    g = cached_graph_struct(batch)
+    p = params_struct(weights, F, D)
+    with _on(H, g, p) as st:
+        _check(load().gnn_node_bwd(_dev(H, torch.float32, "H"), H.shape[1], _dev(e, torch.float32, "e"),
+                                   _dev(Hn, torch.float32, "Hnext"), ctypes.byref(g), ctypes.byref(p),
+                                   _dev(grad_Hn, torch.float32, "grad_Hnext"), _dev(gH, torch.float32, "grad_H"),
+                                   _dev(ge, torch.float32, "grad_e"), ctypes.byref(gs), ws.data_ptr(), ws.numel(), st))
+    return gH, ge, grads[6:10]
 
 
 @functools.lru_cache(maxsize=None)

@@ -57,3 +57,59 @@ def segclf_apply(model, batch):
     if batch.dense_shape:
         e = e.view(batch.dense_shape[0], batch.dense_shape[2])
     return e
+
+
+# ---- the sub-modules on their own (reference gnn/model.py:69-81, 113-125 are ordinary autograd
+# modules; the notebooks call them directly: gnn/MPNN_Seg_ACTS_maskedlinear.ipynb cells 42, 46) ------
+def _pad_rows(H2, ldh):
+    """[n, C] -> [n, ldh] float32 rows (zero-padded, 16-byte aligned: what the kernels read)."""
+    Hp = torch.zeros((H2.shape[0], ldh), dtype=torch.float32, device=H2.device)
+    Hp[:, :H2.shape[1]] = H2
+    return Hp
+
+
+def _dummy_weights(F, D, dev, edge=None, node=None):
+    """The C structs take all ten tensors; a sub-module owns four of them."""
+    C = F + D
+    z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)    # noqa: E731
+    e = edge if edge is not None else [z(D, 2 * C), z(D), z(1, D), z(1)]
+    n = node if node is not None else [z(D, 3 * C), z(D), z(D, D), z(D)]
+    return [z(D, F), z(D)] + list(e) + list(n)
+
+
+class _EdgeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, batch, F, D, H2, W1, b1, W2, b2):
+        w = [t.detach().to(torch.float32).contiguous() for t in (W1, b1, W2, b2)]
+        Hp = _pad_rows(H2.detach().to(torch.float32), _lib.h_stride(F, D))
+        e = _lib.edge_fwd(Hp, batch.src, batch.dst, *w, F, D)
+        ctx.batch, ctx.F, ctx.D, ctx.C = batch, F, D, H2.shape[1]
+        ctx.save_for_backward(Hp, e, *w)
+        return e.clone()
+
+    @staticmethod
+    def backward(ctx, ge):
+        Hp, e, *w = ctx.saved_tensors
+        gH, gw = _lib.edge_bwd(Hp, ctx.batch, _dummy_weights(ctx.F, ctx.D, Hp.device, edge=w), ctx.F, ctx.D, e,
+                               ge.to(torch.float32).contiguous())
+        return (None, None, None, gH[:, :ctx.C].contiguous()) + tuple(gw)
+
+
+class _NodeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, batch, F, D, H2, e, W3, b3, W4, b4):
+        w = [t.detach().to(torch.float32).contiguous() for t in (W3, b3, W4, b4)]
+        Hp = _pad_rows(H2.detach().to(torch.float32), _lib.h_stride(F, D))
+        ev = e.detach().to(torch.float32).contiguous().reshape(-1)
+        Hn = _lib.node_fwd(Hp, ev, batch, *w, F, D)
+        ctx.batch, ctx.F, ctx.D, ctx.C = batch, F, D, H2.shape[1]
+        ctx.save_for_backward(Hp, ev, Hn, *w)
+        return Hn[:, :D].clone()
+
+    @staticmethod
+    def backward(ctx, gHn):
+        Hp, ev, Hn, *w = ctx.saved_tensors
+        g = _pad_rows(gHn.to(torch.float32), Hp.shape[1])
+        gH, ge, gw = _lib.node_bwd(Hp, ev, Hn, ctx.batch, _dummy_weights(ctx.F, ctx.D, Hp.device, node=w), ctx.F,
+                                   ctx.D, g)
+        return (None, None, None, gH[:, :ctx.C].contiguous(), ge) + tuple(gw)

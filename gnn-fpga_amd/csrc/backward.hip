@@ -455,6 +455,33 @@ __global__ __launch_bounds__(kBlock) void k_input_bwd(const float *__restrict__ 
     accum_outer<D, F>(g, x, active, gWin, F, 0, gbin, lds);
 }
 
+// gradient w.r.t. the scores a node pass consumed: ge[j] = <gmi[d], H[s]> + <gmo[s], H[d]>, zero for
+// padded segments (the whole-model backward folds this into k_edge_bwd; the per-module entry point
+// gnn_node_bwd hands it to the caller)
+template <int F, int D>
+__global__ __launch_bounds__(kBlock) void k_seg_grad(const int32_t *__restrict__ src, const int32_t *__restrict__ dst,
+                                                     const float *__restrict__ H, const float *__restrict__ gmio,
+                                                     float *__restrict__ ge, int64_t n_segments)
+{
+    constexpr int C = F + D, LDH = Shape<F, D>::LDH;
+    for (int64_t j = xcd_block() * kBlock + threadIdx.x; j < n_segments; j += (int64_t)gridDim.x * kBlock) {
+        const int s = src[j], d = dst[j];
+        float g = 0.0f;
+        if (s >= 0) {
+            float hs[LDH], hd[LDH], gmi_d[LDH], gmo_s[LDH];
+            load_row4<LDH / 4>(H + (int64_t)s * LDH, hs);
+            load_row4<LDH / 4>(H + (int64_t)d * LDH, hd);
+            load_row4<LDH / 4>(gmio + (int64_t)d * 2 * LDH, gmi_d);
+            load_row4<LDH / 4>(gmio + (int64_t)s * 2 * LDH + LDH, gmo_s);
+#pragma unroll
+            for (int c = 0; c < C; ++c) g = fmaf(gmi_d[c], hs[c], g);
+#pragma unroll
+            for (int c = 0; c < C; ++c) g = fmaf(gmo_s[c], hd[c], g);
+        }
+        ge[j] = g;
+    }
+}
+
 // layout of one gradient replica (floats): the ten tensors in state_dict order
 template <int F, int D>
 struct GradLayout {
@@ -569,6 +596,63 @@ int backward_t(const gnn_graph_t *g, const gnn_params_t *p, int T, const float *
     if (N > 0)
         GNN_LAUNCH("k_input_bwd", (k_input_bwd<F, D>), grid_for(N), kBlock, s, g->X, H_all, LDH, gH,
                    rp + GL::oWin, rp + GL::obin, RS, N);
+    GNN_LAUNCH("k_grad_fold", (k_grad_fold<F, D>), (GL::total + kBlock - 1) / kBlock, kBlock, s, rp, *gr);
+    return 0;
+}
+
+// ---- per-module backward (the reference's sub-modules are ordinary autograd modules:
+// model.edge_network(H, Ri, Ro) / model.node_network(H, e, Ri, Ro), gnn/model.py:69-81,113-125, called
+// directly in gnn/MPNN_Seg_ACTS_maskedlinear.ipynb cells 42, 46) --------------------------------
+// EdgeNetwork: e = sigmoid(W2 tanh(W1 [H_s | H_d] + b1) + b2).  Given ge = dL/de: adds dL/dH into gH
+// (rows of LDH floats, caller-zeroed) and the gradients of W1, b1, W2, b2 into gr.
+template <int F, int D>
+int edge_bwd_t(const float *H, const gnn_graph_t *g, const gnn_params_t *p, const float *e, const float *ge,
+               float *gH, const gnn_grads_t *gr, char *ws, hipStream_t s)
+{
+    constexpr int C = Shape<F, D>::C, LDH = Shape<F, D>::LDH;
+    const int64_t N = g->n_hits, E = g->n_segments;
+    BwdWs w = carve_bwd(ws, N, E, LDH, C, D);
+    using GL = GradLayout<F, D>;
+    float *const rp = w.rep;
+    constexpr int RS = GL::stride;
+    hipError_t err = hipMemsetAsync(rp, 0, (size_t)kReplicas * RS * sizeof(float), s);
+    if (err != hipSuccess) return fail(-(int)err, "memset of the gradient replicas failed");
+    if (N > 0) GNN_LAUNCH("kb_pq", (kb_pq<F, D>), grid_for(N), kBlock, s, H, LDH, p->W1, p->b1, w.PQ, N);
+    if (E > 0) {
+        const unsigned ge_grid = grid_for(E) < (unsigned)kSegGrid ? grid_for(E) : (unsigned)kSegGrid;
+        GNN_LAUNCH("k_edge_bwd", (k_edge_bwd<F, D>), ge_grid, kBlock, s, g->src, g->dst, w.PQ, p->b1, p->W2, e, ge, H,
+                   w.gmio, w.gu, rp + GL::oW2, rp + GL::ob2, rp + GL::ob1, RS, E);
+    }
+    if (N > 0)
+        GNN_LAUNCH("k_pq_bwd", (k_pq_bwd<F, D>), grid_for(N), kBlock, s, H, LDH, w.PQ, w.gu, g->in_ptr, g->in_eid,
+                   g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, p->W1, p->W2, gH, rp + GL::oW1, rp + GL::ob1, RS, N);
+    GNN_LAUNCH("k_grad_fold", (k_grad_fold<F, D>), (GL::total + kBlock - 1) / kBlock, kBlock, s, rp, *gr);
+    return 0;
+}
+
+// NodeNetwork: H' = tanh(W4 tanh(W3 [mi | mo | H] + b3) + b4).  Given gHn = dL/dH' (rows of LDH floats,
+// first D used) and the forward's H, e, H': writes dL/dH into gH (rows of LDH), dL/de into ge, adds the
+// gradients of W3, b3, W4, b4 into gr.
+template <int F, int D>
+int node_bwd_t(const float *H, const float *e, const float *Hn, const gnn_graph_t *g, const gnn_params_t *p,
+               const float *gHn, float *gH, float *ge, const gnn_grads_t *gr, char *ws, hipStream_t s)
+{
+    constexpr int C = Shape<F, D>::C, LDH = Shape<F, D>::LDH;
+    const int64_t N = g->n_hits, E = g->n_segments;
+    BwdWs w = carve_bwd(ws, N, E, LDH, C, D);
+    using GL = GradLayout<F, D>;
+    float *const rp = w.rep;
+    constexpr int RS = GL::stride;
+    hipError_t err = hipMemsetAsync(rp, 0, (size_t)kReplicas * RS * sizeof(float), s);
+    if (err != hipSuccess) return fail(-(int)err, "memset of the gradient replicas failed");
+    if (N > 0) {
+        GNN_LAUNCH("k_node_bwd", (k_node_bwd<F, D>), grid_for(N), kBlock, s, H, Hn, LDH, e, g->in_ptr, g->in_eid,
+                   g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, p->W3, p->b3, p->W4, gHn, gH, w.gmio,
+                   rp + GL::oW3, rp + GL::ob3, rp + GL::oW4, rp + GL::ob4, RS, N);
+        GNN_LAUNCH("k_agg_bwd_n", (k_agg_bwd_n<F, D>), grid_for(N), kBlock, s, e, w.gmio, g->in_ptr, g->in_eid,
+                   g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, gH, LDH, N);
+    }
+    if (E > 0) GNN_LAUNCH("k_seg_grad", (k_seg_grad<F, D>), grid_for(E), kBlock, s, g->src, g->dst, H, w.gmio, ge, E);
     GNN_LAUNCH("k_grad_fold", (k_grad_fold<F, D>), (GL::total + kBlock - 1) / kBlock, kBlock, s, rp, *gr);
     return 0;
 }
@@ -1077,6 +1161,32 @@ int backward(const gnn_graph_t *g, const gnn_params_t *p, int T, const float *e_
                     backward_workspace_bytes(g->n_hits, g->n_segments, p->F, p->D));
     char *base = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
 #define X_(F_, D_) if (p->F == F_ && p->D == D_) return backward_t<F_, D_>(g, p, T, e_all, H_all, grad_out, gr, base, s);
+    BWD_FOR_EACH_SHAPE(X_)
+#undef X_
+    return fail(GNN_ERR_UNSUPPORTED, "no backward kernel for input_dim=%d hidden_dim=%d", p->F, p->D);
+}
+
+int edge_bwd(const float *H, const gnn_graph_t *g, const gnn_params_t *p, const float *e, const float *ge, float *gH,
+             const gnn_grads_t *gr, void *ws, size_t ws_bytes, hipStream_t s)
+{
+    if (ws_bytes < backward_workspace_bytes(g->n_hits, g->n_segments, p->F, p->D))
+        return fail(GNN_ERR_WORKSPACE, "backward workspace too small: need %zu bytes",
+                    backward_workspace_bytes(g->n_hits, g->n_segments, p->F, p->D));
+    char *base = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
+#define X_(F_, D_) if (p->F == F_ && p->D == D_) return edge_bwd_t<F_, D_>(H, g, p, e, ge, gH, gr, base, s);
+    BWD_FOR_EACH_SHAPE(X_)
+#undef X_
+    return fail(GNN_ERR_UNSUPPORTED, "no backward kernel for input_dim=%d hidden_dim=%d", p->F, p->D);
+}
+
+int node_bwd(const float *H, const float *e, const float *Hn, const gnn_graph_t *g, const gnn_params_t *p,
+             const float *gHn, float *gH, float *ge, const gnn_grads_t *gr, void *ws, size_t ws_bytes, hipStream_t s)
+{
+    if (ws_bytes < backward_workspace_bytes(g->n_hits, g->n_segments, p->F, p->D))
+        return fail(GNN_ERR_WORKSPACE, "backward workspace too small: need %zu bytes",
+                    backward_workspace_bytes(g->n_hits, g->n_segments, p->F, p->D));
+    char *base = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
+#define X_(F_, D_) if (p->F == F_ && p->D == D_) return node_bwd_t<F_, D_>(H, e, Hn, g, p, gHn, gH, ge, gr, base, s);
     BWD_FOR_EACH_SHAPE(X_)
 #undef X_
     return fail(GNN_ERR_UNSUPPORTED, "no backward kernel for input_dim=%d hidden_dim=%d", p->F, p->D);

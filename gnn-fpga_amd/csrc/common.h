@@ -165,4 +165,9 @@ int backward(const gnn_graph_t *g, const gnn_params_t *p, int T, const float *e_
              const float *H_all, const float *grad_out, const gnn_grads_t *gr, void *ws,
              size_t ws_bytes, hipStream_t s);
 
+int edge_bwd(const float *H, const gnn_graph_t *g, const gnn_params_t *p, const float *e, const float *ge, float *gH,
+             const gnn_grads_t *gr, void *ws, size_t ws_bytes, hipStream_t s);
+int node_bwd(const float *H, const float *e, const float *Hn, const gnn_graph_t *g, const gnn_params_t *p,
+             const float *gHn, float *gH, float *ge, const gnn_grads_t *gr, void *ws, size_t ws_bytes, hipStream_t s);
+
 }  // namespace gnn

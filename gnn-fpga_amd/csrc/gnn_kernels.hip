@@ -860,6 +860,36 @@ int gnn_segclf_backward(const gnn_graph_t *g, const gnn_params_t *p, int32_t n_i
                     static_cast<hipStream_t>(stream));
 }
 
+static bool grads_complete(const gnn_grads_t *gr)
+{
+    return gr && gr->Win && gr->bin && gr->W1 && gr->b1 && gr->W2 && gr->b2 && gr->W3 && gr->b3 && gr->W4 && gr->b4;
+}
+
+int gnn_edge_bwd(const float *H, int32_t ldh, const gnn_graph_t *g, const gnn_params_t *p, const float *e,
+                 const float *grad_e, float *grad_H, const gnn_grads_t *gr, void *workspace,
+                 size_t workspace_bytes, void *stream)
+{
+    if (!g || !p || !workspace || g->n_hits < 0 || g->n_segments < 0 || !grads_complete(gr))
+        return fail(GNN_ERR_BADARG, "gnn_edge_bwd: bad argument");
+    if (ldh != gnn_h_stride(p->F, p->D)) return fail(GNN_ERR_BADARG, "gnn_edge_bwd: ldh must be gnn_h_stride(F, D)");
+    if ((g->n_hits > 0 && (!H || !grad_H)) || (g->n_segments > 0 && (!e || !grad_e)))
+        return fail(GNN_ERR_BADARG, "gnn_edge_bwd: tensor missing");
+    return edge_bwd(H, g, p, e, grad_e, grad_H, gr, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int gnn_node_bwd(const float *H, int32_t ldh, const float *e, const float *Hnext, const gnn_graph_t *g,
+                 const gnn_params_t *p, const float *grad_Hnext, float *grad_H, float *grad_e,
+                 const gnn_grads_t *gr, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!g || !p || !workspace || g->n_hits < 0 || g->n_segments < 0 || !grads_complete(gr))
+        return fail(GNN_ERR_BADARG, "gnn_node_bwd: bad argument");
+    if (ldh != gnn_h_stride(p->F, p->D)) return fail(GNN_ERR_BADARG, "gnn_node_bwd: ldh must be gnn_h_stride(F, D)");
+    if ((g->n_hits > 0 && (!H || !Hnext || !grad_Hnext || !grad_H)) || (g->n_segments > 0 && (!e || !grad_e)))
+        return fail(GNN_ERR_BADARG, "gnn_node_bwd: tensor missing");
+    return node_bwd(H, e, Hnext, g, p, grad_Hnext, grad_H, grad_e, gr, workspace, workspace_bytes,
+                    static_cast<hipStream_t>(stream));
+}
+
 int gnn_segclf_forward_train_events(const gnn_graph_t *g, const gnn_params_t *p, const int32_t *hit_ptr,
                                     const int32_t *seg_ptr, int64_t n_graphs, int32_t max_hits,
                                     int32_t max_segments, int32_t n_iters, float *e_all, float *H_all,

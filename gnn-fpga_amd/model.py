@@ -89,11 +89,19 @@ class EdgeNetwork(nn.Module):
                 _f32c(n[2].effective_weight()), _f32c(n[2].bias)]
 
     def forward(self, X, Ri, Ro=None):
-        """X = hit features H [B,N,C]; (Ri, Ro) dense, or Ri a HitGraphBatch.  -> e [B,E]."""
+        """X = hit features H [B,N,C]; (Ri, Ro) dense, or Ri a HitGraphBatch.  -> e [B,E].
+        Differentiable in X and the four weights like the reference's module (HIP backward:
+        gnn_edge_bwd)."""
         batch = _as_batch(X, Ri, Ro)
-        H = _f32c(X).reshape(-1, X.shape[-1])
         D = self._D
-        e = _lib.edge_fwd(H, batch.src, batch.dst, *self.weights(), self._C - D, D)
+        n = self.network
+        if torch.is_grad_enabled() and (X.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from .autograd import _EdgeFn
+            e = _EdgeFn.apply(batch, self._C - D, D, X.reshape(-1, X.shape[-1]), n[0].effective_weight(),
+                              n[0].bias, n[2].effective_weight(), n[2].bias)
+        else:
+            H = _f32c(X).reshape(-1, X.shape[-1])
+            e = _lib.edge_fwd(H, batch.src, batch.dst, *self.weights(), self._C - D, D)
         return e.view(batch.dense_shape[0], batch.dense_shape[2]) if batch.dense_shape else e
 
 
@@ -120,9 +128,17 @@ class NodeNetwork(nn.Module):
                 _f32c(n[2].effective_weight()), _f32c(n[2].bias)]
 
     def forward(self, X, e, Ri, Ro=None):
-        """X = H [B,N,C], e [B,E] -> H' [B,N,D] (without the skip concat, like the reference)."""
+        """X = H [B,N,C], e [B,E] -> H' [B,N,D] (without the skip concat, like the reference).
+        Differentiable in X, e and the four weights (HIP backward: gnn_node_bwd)."""
         batch = _as_batch(X, Ri, Ro)
         C, D = self._C, self._D
+        n = self.network
+        if torch.is_grad_enabled() and (X.requires_grad or e.requires_grad or
+                                        any(p.requires_grad for p in self.parameters())):
+            from .autograd import _NodeFn
+            Hn = _NodeFn.apply(batch, C - D, D, X.reshape(-1, C), e.reshape(-1), n[0].effective_weight(),
+                               n[0].bias, n[2].effective_weight(), n[2].bias)
+            return Hn.reshape(*X.shape[:-1], D)
         ldh = _lib.h_stride(C - D, D)
         H2 = _f32c(X).reshape(-1, C)
         Hp = torch.zeros((H2.shape[0], ldh), dtype=torch.float32, device=H2.device)

@@ -229,6 +229,23 @@ int gnn_plan_shape_supported(int32_t F, int32_t D);
  * for the iteration kernel, rows of D floats for the edge kernel). */
 int gnn_plan_limits(int32_t F, int32_t D, int32_t *out4);
 
+/* ---- per-module backward ------------------------------------------------------------------------
+ * The reference's sub-modules are ordinary autograd modules (model.edge_network(H, Ri, Ro),
+ * model.node_network(H, e, Ri, Ro): gnn/model.py:69-81, 113-125; called on their own in
+ * gnn/MPNN_Seg_ACTS_maskedlinear.ipynb cells 42, 46).  These two entry points are their backward:
+ * H rows of ldh = gnn_h_stride(F, D) floats, gradient tensors as in gnn_segclf_backward (all ten
+ * pointers valid, the backward ADDS into them; an edge backward touches W1, b1, W2, b2 only, a node
+ * backward W3, b3, W4, b4 only).  Workspace: gnn_backward_workspace_bytes.
+ *   gnn_edge_bwd: grad_e [n_segments] -> grad_H [n_hits, ldh] (caller-zeroed, ADDED into)
+ *   gnn_node_bwd: Hnext = the forward's output [n_hits, ldh], grad_Hnext [n_hits, ldh] (first D
+ *                 columns used) -> grad_H [n_hits, ldh] (written), grad_e [n_segments] (written) */
+int gnn_edge_bwd(const float *H, int32_t ldh, const gnn_graph_t *g, const gnn_params_t *p, const float *e,
+                 const float *grad_e, float *grad_H, const gnn_grads_t *grads, void *workspace,
+                 size_t workspace_bytes, void *stream);
+int gnn_node_bwd(const float *H, int32_t ldh, const float *e, const float *Hnext, const gnn_graph_t *g,
+                 const gnn_params_t *p, const float *grad_Hnext, float *grad_H, float *grad_e,
+                 const gnn_grads_t *grads, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- the plan, built on the GPU (csrc/plan_build.hip) -------------------------------------------
  * Index-form counterpart of the reference's per-batch host work (graph_from_sparse densifies,
  * merge_graphs zero-pads: gnn/graph.py:28-35, gnn/trainSegmentClassifier.py:66-111): the same

@@ -147,6 +147,60 @@ def test_submodules_like_the_notebooks(hip):
         assert np.abs(out[0].cpu().numpy() - fx.scores).max() < TOL
 
 
+@pytest.mark.parametrize("F,D", [(3, 8), (11, 8), (2, 32)])
+def test_submodules_are_differentiable_like_the_reference(hip, F, D):
+    """model.edge_network(H, Ri, Ro) / model.node_network(H, e, Ri, Ro) are ordinary autograd modules
+    in the reference (gnn/model.py:69-81,113-125): gradients w.r.t. the hit features, the scores and
+    the masked weights through the HIP backward (gnn_edge_bwd / gnn_node_bwd) against autograd through
+    the dense oracle, on a padded batch of two graphs."""
+    from gnn_fpga_amd.model import SegmentClassifier
+    from oracle import dense_torch
+    torch.manual_seed(F * 10 + D)
+    C = F + D
+    graphs = [synth.layered_graph(60, 200, F, seed=1), synth.layered_graph(45, 120, F, seed=2)]
+    Nmax, Emax = 60, 200
+    dense = [synth.to_dense(g, Nmax, Emax) for g in graphs]
+    Ri, Ro = (torch.from_numpy(np.stack([d[i] for d in dense])) for i in (1, 2))
+    me = [(torch.rand(D, 2 * C) < 0.8).float(), torch.ones(1, D)]
+    mn = [(torch.rand(D, 3 * C) < 0.8).float(), (torch.rand(D, D) < 0.9).float()]
+    m = SegmentClassifier(input_dim=F, hidden_dim=D, n_iters=1, masks_e=me, masks_n=mn).cuda().train()
+    params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    masks = {"edge_network.network.0.weight": me[0], "edge_network.network.2.weight": me[1],
+             "node_network.network.0.weight": mn[0], "node_network.network.2.weight": mn[1]}
+    H0 = torch.randn(2, Nmax, C) * 0.5
+    we, wh = torch.randn(2, Emax), torch.randn(2, Nmax, D)
+    # reference formulation on the CPU
+    Hc = H0.clone().requires_grad_(True)
+    e_c = dense_torch.edge_network(Hc, Ri, Ro, params, masks)
+    Hn_c = dense_torch.node_network(Hc, e_c, Ri, Ro, params, masks)
+    ((e_c * we).sum() + (Hn_c * wh).sum()).backward()
+    # HIP modules
+    Hg = H0.cuda().requires_grad_(True)
+    e_g = m.edge_network(Hg, Ri.cuda(), Ro.cuda())
+    assert e_g.requires_grad and e_g.shape == (2, Emax)
+    Hn_g = m.node_network(Hg, e_g, Ri.cuda(), Ro.cuda())
+    assert Hn_g.requires_grad and Hn_g.shape == (2, Nmax, D)
+    assert np.abs(e_g.detach().cpu().numpy() - e_c.detach().numpy()).max() < TOL
+    assert np.abs(Hn_g.detach().cpu().numpy() - Hn_c.detach().numpy()).max() < TOL_H
+    ((e_g * we.cuda()).sum() + (Hn_g * wh.cuda()).sum()).backward()
+
+    def close(a, r, what):
+        err = np.abs(a - r).max()
+        assert err < 1e-6 + 1e-4 * np.abs(r).max(), (what, err)
+
+    close(Hg.grad.cpu().numpy(), Hc.grad.numpy(), "dL/dH")
+    for k, p_ in m.named_parameters():
+        if k.startswith("input_network"):
+            assert p_.grad is None
+            continue
+        close(p_.grad.cpu().numpy(), params[k].grad.numpy(), k)
+        if k in masks:
+            assert np.all(p_.grad.cpu().numpy()[masks[k].numpy() == 0] == 0)
+    # and nothing is detached silently in inference either: no grad -> plain tensors
+    with torch.no_grad():
+        assert not m.edge_network(Hg, Ri.cuda(), Ro.cuda()).requires_grad
+
+
 def test_full_size_properties(hip):
     """Config-3 size (10k hits / 100k segments) x 8 graphs: size-independent properties -
     block-diagonal independence (each graph's scores equal its stand-alone run bit for bit),
