@@ -93,6 +93,7 @@ SIGNATURES = {
     "gnn_segclf_backward": (ctypes.c_int, [ctypes.POINTER(GnnGraph), ctypes.POINTER(GnnParams),
                                            _i32, _f, _f, _f, ctypes.POINTER(GnnGrads), _f, _sz, _f]),
     "gnn_bce_loss": (ctypes.c_int, [_f, _f, _i64, ctypes.c_float, _f, _f, _f, _f]),
+    "gnn_dense_to_index": (ctypes.c_int, [_f, _f, _i64, _i64, _i64, _f, _f, _f, _f]),
     "gnn_edge_bwd": (ctypes.c_int, [_f, _i32, ctypes.POINTER(GnnGraph), ctypes.POINTER(GnnParams), _f, _f, _f,
                                     ctypes.POINTER(GnnGrads), _f, _sz, _f]),
     "gnn_node_bwd": (ctypes.c_int, [_f, _i32, _f, _f, ctypes.POINTER(GnnGraph), ctypes.POINTER(GnnParams), _f, _f,
@@ -403,6 +404,19 @@ def segclf_backward(batch, weights, F, D, n_iters, e_all, H_all, grad_out):
                                           _dev(grad_out, torch.float32, "grad_out"),
                                           ctypes.byref(gs), ws.data_ptr(), ws.numel(), st))
     return grads
+
+
+def dense_to_index(Ri, Ro):
+    """Dense [B, N, E] float32 incidence matrices on the device -> (src, dst int32 [B*E], flags int32 [1]);
+    asynchronous - the caller decides whether to read the flags back."""
+    B, N, E = Ri.shape
+    src = torch.empty(B * E, dtype=torch.int32, device=Ri.device)
+    dst = torch.empty(B * E, dtype=torch.int32, device=Ri.device)
+    flags = torch.empty(1, dtype=torch.int32, device=Ri.device)
+    with _on(Ri) as st:
+        _check(load().gnn_dense_to_index(_dev(Ri, torch.float32, "Ri"), _dev(Ro, torch.float32, "Ro"), B, N, E,
+                                         src.data_ptr(), dst.data_ptr(), flags.data_ptr(), st))
+    return src, dst, flags
 
 
 def _grad_views(weights, dev):

@@ -860,6 +860,54 @@ int gnn_segclf_backward(const gnn_graph_t *g, const gnn_params_t *p, int32_t n_i
                     static_cast<hipStream_t>(stream));
 }
 
+// dense one-hot incidence matrices -> index form, where the matrices live (the reference's input
+// contract: [B, N, E] float32 with one 1 per real column, all-zero padded columns;
+// gnn/graph.py:28-35, gnn/trainSegmentClassifier.py:66-95).  One lane per (batch, column): the N
+// rows of a column are read with the column index fastest across lanes (coalesced).  O(B N E)
+// reads - the price of the dense contract, paid once per batch on the device instead of a PCIe
+// round trip.  flags[0] |= 1: a column with more than one non-zero, |= 2: a column set in only one
+// of Ri / Ro.
+__global__ __launch_bounds__(256) void k_dense_to_index(const float *__restrict__ Ri, const float *__restrict__ Ro,
+                                                        int64_t B, int64_t N, int64_t E, int32_t *__restrict__ src,
+                                                        int32_t *__restrict__ dst, int32_t *flags)
+{
+    int bad = 0;
+    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < B * E; c += (int64_t)gridDim.x * 256) {
+        const int64_t b = c / E, j = c % E;
+        const float *ri = Ri + b * N * E + j, *ro = Ro + b * N * E + j;
+        int ci = 0, co = 0;
+        int64_t di = -1, so = -1;
+        for (int64_t n = 0; n < N; ++n) {
+            if (ri[n * E] != 0.0f) { if (!ci) di = n; ++ci; }
+            if (ro[n * E] != 0.0f) { if (!co) so = n; ++co; }
+        }
+        if (ci > 1 || co > 1) bad |= 1;
+        if ((ci == 0) != (co == 0)) bad |= 2;
+        const bool real = ci == 1 && co == 1;
+        src[c] = real ? (int32_t)(b * N + so) : -1;
+        dst[c] = real ? (int32_t)(b * N + di) : -1;
+    }
+    if (bad) atomicOr(flags, bad);
+}
+
+int gnn_dense_to_index(const float *Ri, const float *Ro, int64_t B, int64_t N, int64_t E, int32_t *src, int32_t *dst,
+                       int32_t *flags, void *stream)
+{
+    if (B < 0 || N < 0 || E < 0 || !flags || (B * E > 0 && (!Ri || !Ro || !src || !dst)))
+        return fail(GNN_ERR_BADARG, "gnn_dense_to_index: bad argument");
+    if (B * N >= (1ll << 31) || B * E >= (1ll << 31))
+        return fail(GNN_ERR_UNSUPPORTED, "gnn_dense_to_index: batch too large for 32-bit ids");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t err = hipMemsetAsync(flags, 0, sizeof(int32_t), s);
+    if (err != hipSuccess) return fail(-(int)err, "memset of the flag failed");
+    if (B * E > 0) {
+        const int64_t g = (B * E + 255) / 256;
+        GNN_LAUNCH("k_dense_to_index", k_dense_to_index, (unsigned)(g < 65536 ? g : 65536), 256, s, Ri, Ro, B, N, E, src,
+                   dst, flags);
+    }
+    return 0;
+}
+
 static bool grads_complete(const gnn_grads_t *gr)
 {
     return gr && gr->Win && gr->bin && gr->W1 && gr->b1 && gr->W2 && gr->b2 && gr->W3 && gr->b3 && gr->W4 && gr->b4;

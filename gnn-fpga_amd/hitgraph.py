@@ -317,6 +317,8 @@ class HitGraphBatch:
         E = Rit.shape[2]
         if tuple(Rit.shape) != (B, N, E) or tuple(Rot.shape) != (B, N, E):
             raise ValueError("expected X [B,N,F], Ri [B,N,E], Ro [B,N,E]")
+        if Rit.is_cuda and Rot.is_cuda and Xt.is_cuda:
+            return cls._from_dense_device(Xt, Rit, Rot, y)
         Xn = Xt.cpu().numpy()
         off = (np.arange(B, dtype=np.int64) * N)[:, None]
 
@@ -336,6 +338,45 @@ class HitGraphBatch:
         return cls(Xn.reshape(B * N, -1), src, dst, y=yy,
                    hit_ptr=np.arange(B + 1) * N, seg_ptr=np.arange(B + 1) * E,
                    dense_shape=(B, N, E))
+
+    validate_dense = True      # read the conversion kernel's error flag back (4 bytes, one sync per batch)
+
+    @classmethod
+    def _from_dense_device(cls, Xt, Rit, Rot, y=None):
+        """from_dense for matrices that already live on the GPU (what an unchanged estimator.py loop
+        hands over after `np_to_torch(...).cuda()`): one HIP kernel (`gnn_dense_to_index`), nothing
+        crosses PCIe except - with `validate_dense` - the 4-byte error flag."""
+        from . import _lib
+        B, N, F = Xt.shape
+        E = Rit.shape[2]
+        f32 = lambda t: t.to(torch.float32).contiguous()          # noqa: E731
+        src, dst, flags = _lib.dense_to_index(f32(Rit), f32(Rot))
+        if cls.validate_dense:
+            fl = int(flags.item())
+            if fl & 1:
+                raise ValueError("incidence matrix column with more than one hit")
+            if fl & 2:
+                raise ValueError("a segment column must be set in both Ri and Ro or in neither")
+        self = cls.__new__(cls)
+        self.n_hits, self.n_features, self.n_segments = B * N, F, B * E
+        self.hit_ptr = np.arange(B + 1, dtype=np.int64) * N
+        self.seg_ptr = np.arange(B + 1, dtype=np.int64) * E
+        self.n_graphs = B
+        self.dense_shape = (B, N, E)
+        self.X = f32(Xt).reshape(B * N, F)
+        self.src, self.dst = src, dst
+        self._csr = None
+        self._src_host = self._dst_host = None
+        self.y = None if y is None else (y.detach() if torch.is_tensor(y) else torch.from_numpy(np.asarray(y))
+                                         ).to(torch.float32).reshape(-1).to(Xt.device)
+        self.plan = None
+        # block-diagonal by construction: no host check of the endpoints
+        lay = _EventLayout()
+        lay.hit_ptr = torch.from_numpy(self.hit_ptr.astype(_I32)).to(Xt.device)
+        lay.seg_ptr = torch.from_numpy(self.seg_ptr.astype(_I32)).to(Xt.device)
+        lay.max_hits, lay.max_segments = N, E
+        self._event = (lay,)
+        return self
 
     # -- device movement -----------------------------------------------------------------
     def to(self, device):

@@ -229,6 +229,14 @@ int gnn_plan_shape_supported(int32_t F, int32_t D);
  * for the iteration kernel, rows of D floats for the edge kernel). */
 int gnn_plan_limits(int32_t F, int32_t D, int32_t *out4);
 
+/* The reference's dense input contract -> index form, on the device: Ri, Ro [B, N, E] float32 with one
+ * non-zero per real column and all-zero padded columns (gnn/graph.py:28-35,
+ * gnn/trainSegmentClassifier.py:66-95) -> src, dst [B*E] int32 global hit ids b*N + n, -1 for a padded
+ * column.  flags [1] (device): bit 0 = a column with more than one non-zero, bit 1 = a column set in
+ * only one of Ri / Ro (such columns come out as -1).  Asynchronous on `stream`. */
+int gnn_dense_to_index(const float *Ri, const float *Ro, int64_t B, int64_t N, int64_t E, int32_t *src,
+                       int32_t *dst, int32_t *flags, void *stream);
+
 /* ---- per-module backward ------------------------------------------------------------------------
  * The reference's sub-modules are ordinary autograd modules (model.edge_network(H, Ri, Ro),
  * model.node_network(H, e, Ri, Ro): gnn/model.py:69-81, 113-125; called on their own in

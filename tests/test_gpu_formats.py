@@ -70,3 +70,40 @@ def test_batch_generator_batches_score_like_the_reference(hip, name):
     counts = np.diff(batch.seg_ptr)
     want = np.concatenate([ref[i, :c] for i, c in enumerate(counts)])
     assert np.abs(out.cpu().numpy() - want).max() < TOL
+
+
+def test_dense_inputs_are_converted_on_the_device(hip):
+    """The reference's dense [B,N,E] contract on CUDA tensors: one HIP kernel (gnn_dense_to_index)
+    gives the index form the host adapter gives, refuses what it refuses, and - with validation off -
+    synchronises nothing."""
+    from gnn_fpga_amd import synth
+    graphs = [synth.muon_graph(s) for s in (3, 4, 5, 6)]
+    Nmax = max(g.X.shape[0] for g in graphs)
+    Emax = max(g.src.shape[0] for g in graphs)
+    dense = [synth.to_dense(g, Nmax, Emax) for g in graphs]
+    X, Ri, Ro = (torch.from_numpy(np.stack([d[i] for d in dense])) for i in range(3))
+    host = HitGraphBatch.from_dense(X, Ri, Ro)
+    dev = HitGraphBatch.from_dense(X.cuda(), Ri.cuda(), Ro.cuda())
+    assert dev.src.is_cuda and dev.dense_shape == host.dense_shape == (4, Nmax, Emax)
+    for k in ("X", "src", "dst"):
+        assert torch.equal(getattr(host, k), getattr(dev, k).cpu()), k
+    assert np.array_equal(host.hit_ptr, dev.hit_ptr) and np.array_equal(host.seg_ptr, dev.seg_ptr)
+    for name in HitGraphBatch._CSR_NAMES:                       # CSRs built on the device from it
+        assert torch.equal(getattr(host, name), getattr(dev, name).cpu()), name
+    lay = dev.event_layout()
+    assert lay.max_hits == Nmax and lay.max_segments == Emax
+    bad = Ri.clone()
+    bad[0, 1, 0] = 1.0
+    bad[0, 2, 0] = 1.0                                            # two end hits in one column
+    with pytest.raises(ValueError):
+        HitGraphBatch.from_dense(X.cuda(), bad.cuda(), Ro.cuda())
+    half = Ro.clone()
+    half[1, :, 0] = 0.0                                           # a column set in Ri only
+    with pytest.raises(ValueError):
+        HitGraphBatch.from_dense(X.cuda(), Ri.cuda(), half.cuda())
+    HitGraphBatch.validate_dense = False
+    try:
+        b = HitGraphBatch.from_dense(X.cuda(), Ri.cuda(), half.cuda())   # asynchronous: column comes out padded
+        assert int(b.src[Emax].item()) == -1 and int(b.dst[Emax].item()) == -1
+    finally:
+        HitGraphBatch.validate_dense = True
