@@ -13,7 +13,7 @@ import torch  # imported first: its bundled libamdhip64.so.7 is the one HIP runt
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgnn_hip.so")
 
-GNN_ABI_VERSION = 1
+GNN_ABI_VERSION = 2
 GNN_ERR_UNSUPPORTED = -10001
 GNN_ERR_BADARG = -10002
 GNN_ERR_WORKSPACE = -10003
@@ -83,7 +83,7 @@ SIGNATURES = {
     "gnn_segclf_forward_train_events": (ctypes.c_int, [ctypes.POINTER(GnnGraph), ctypes.POINTER(GnnParams),
                                                        _f, _f, _i64, _i32, _i32, _i32, _f, _f, _f]),
     "gnn_events_backward_supported": (ctypes.c_int, [_i32, _i32, _i64, _i64]),
-    "gnn_backward_events_workspace_bytes": (_sz, [_i32, _i32]),
+    "gnn_backward_events_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "gnn_segclf_backward_events": (ctypes.c_int, [ctypes.POINTER(GnnGraph), ctypes.POINTER(GnnParams),
                                                   _f, _f, _i64, _i32, _i32, _i32, _f, _f, _f,
                                                   ctypes.POINTER(GnnGrads), _f, _sz, _f]),
@@ -484,7 +484,8 @@ def segclf_backward_events(batch, layout, weights, F, D, n_iters, e_all, H_all, 
     gs = GnnGrads()
     for name, t in zip(("Win", "bin", "W1", "b1", "W2", "b2", "W3", "b3", "W4", "b4"), grads):
         setattr(gs, name, t.data_ptr())
-    ws = torch.empty(int(load().gnn_backward_events_workspace_bytes(F, D)), dtype=torch.uint8, device=dev)
+    ws = torch.empty(int(load().gnn_backward_events_workspace_bytes(batch.n_graphs, F, D)), dtype=torch.uint8,
+                     device=dev)
     g = cached_graph_struct(batch)
     p = params_struct(weights, F, D)
     with _on(batch.X, g, p) as st:

@@ -20,10 +20,11 @@
 //   input         k_input_bwd per hit: g = gH0[:D] (1-H0^2);  gWin, gbin
 //
 // Weight gradients are sums of per-item outer products: a workgroup parks its 256 items' factors
-// in LDS, each thread then owns output elements and sums over the 256 items (fixed order), and
-// one atomicAdd per element per workgroup goes to the (zero-initialised) gradient tensor
-// (accum_outer; the per-segment kernel keeps private sums instead, see kSegGrid).
-// Only the order of those cross-workgroup atomics is run-dependent (last-bit differences).
+// in LDS, each thread then owns output elements and sums over the 256 items (fixed order) and adds
+// the result to ITS WORKGROUP'S OWN ROW of a partial-sum table (row = blockIdx.x; one writer per
+// element, so the adds of successive launches land in launch order).  k_grad_fold1 / 2 then sum the
+// rows in row order, 256 rows per chunk, chunks in order: every float addition of a backward happens
+// in a fixed order, and two runs give bit-identical gradients (deterministic by default).
 #include "common.h"
 
 namespace {
@@ -59,20 +60,20 @@ __device__ __forceinline__ void store_row4(float *__restrict__ row, const float 
 // factor c of all 256 items, rows padded by 4 floats - so that the thread that owns an output
 // element walks two rows with 16-byte reads (4 items per read, bank-conflict free across the
 // wavefront: neighbouring threads own neighbouring k, i.e. rows 4 banks apart), in item order.
-// One atomicAdd per element per workgroup goes to the (zero-initialised) gradient tensor.
+// One add per element per workgroup goes to the workgroup's own row of the partial table.
 // Wide right factors: the staging area is capped at kOuterCap rows (133 KB), the columns of R are
 // taken in chunks that fit beside L.
 constexpr int kOuterCap = 128, kOuterStride = kBlock + 4;
 
-// Gradient atomics go to one of 8 REPLICAS of the gradient vector, picked by the XCD the
-// workgroup runs on (workgroups are dealt round-robin): a replica's lines then stay in one L2
-// instead of bouncing between the 8 of them (k_pq_bwd: 135 -> ~100 us at 320 k hits).
-// k_grad_fold adds the replicas into the caller's tensors once per backward.
-constexpr int kReplicas = 8;
+// A workgroup's partial gradient sums live in row blockIdx.x of the partial table (GradLayout::stride
+// floats per row): no other workgroup touches the row, so there is nothing to bounce between the
+// 8 L2s and nothing whose order could vary; the fold kernels add the rows up in a fixed order.
+constexpr int kFoldChunk = 256;           // rows summed sequentially by one thread of k_grad_fold1
 __device__ __forceinline__ float *my_replica(float *g, int rep_stride)
 {
-    return g + (size_t)(blockIdx.x & (kReplicas - 1)) * rep_stride;
+    return g + (size_t)blockIdx.x * rep_stride;
 }
+inline int64_t fold_chunks(int64_t rows) { return (rows + kFoldChunk - 1) / kFoldChunk; }
 template <int NL, int NR>
 constexpr int outer_lds_floats() { return kOuterStride * ((NL + NR + 1) < kOuterCap ? (NL + NR + 1) : kOuterCap); }
 
@@ -103,7 +104,8 @@ __device__ __forceinline__ void accum_outer(const float *L, const float *R, bool
             acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc);
             acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
         }
-        atomicAdd(k < CH ? &g[i * ldg + col0 + C0 + k] : &gb[i], acc);
+        float *dst = k < CH ? &g[i * ldg + col0 + C0 + k] : &gb[i];      // own row: the only writer
+        *dst += acc;
     }
     __syncthreads();
     if constexpr (C0 + CH < NR) accum_outer<NL, NR, C0 + CH>(L, R, active, g, ldg, col0, gb, lds);
@@ -139,8 +141,6 @@ __global__ __launch_bounds__(kBlock) void kb_pq(const float *__restrict__ H, int
 // segments' contributions, the workgroup adds them up once at the end (wavefront butterfly, one
 // LDS slot per wavefront) and issues ONE atomic per gradient element - a few hundred per launch
 // instead of one per 256 segments (12 500 at 3.2 M segments: they serialised and were the launch).
-constexpr int kSegGrid = 1024;
-
 // per segment; padded segments (src = -1) score sigmoid(W2 tanh(b1) + b2): their gz flows into
 // b1 only (summed here, the hits' share of gb1 comes from k_pq_bwd)
 // ge: gradient w.r.t. this pass's scores - the loss gradient for the last pass (ge != null), else
@@ -223,14 +223,14 @@ __global__ __launch_bounds__(kBlock) void k_edge_bwd(
             float x = 0.0f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) x += lds[w * N + threadIdx.x];
-            atomicAdd((int)threadIdx.x < D ? gW2 + threadIdx.x : gb2, x);
+            *((int)threadIdx.x < D ? gW2 + threadIdx.x : gb2) += x;          // own row, one writer per element
         } else if ((int)threadIdx.x < 2 * D + 1) {
             const int i = threadIdx.x - D - 1;
             float x = 0.0f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) x += lds[w * N + D + 1];
             const float a = tanh_f(b1[i]);
-            if (x != 0.0f) atomicAdd(gb1 + i, x * W2[i] * (1.0f - a * a));
+            if (x != 0.0f) gb1[i] += x * W2[i] * (1.0f - a * a);
         }
     }
 }
@@ -492,15 +492,31 @@ struct GradLayout {
     static constexpr int stride = (total + 63) & ~63;      // replicas on separate 256-byte lines
 };
 
+// rows of the partial table -> the caller's gradient tensors, in a fixed order: thread (element i,
+// chunk c) of k_grad_fold1 adds rows 256 c .. 256 c + 255 sequentially into tmp[c][i]; k_grad_fold2
+// adds the chunks of an element sequentially into the tensor.
 template <int F, int D>
-__global__ __launch_bounds__(kBlock) void k_grad_fold(const float *__restrict__ rep, gnn_grads_t gr)
+__global__ __launch_bounds__(kBlock) void k_grad_fold1(const float *__restrict__ rep, int64_t n_rows,
+                                                       float *__restrict__ tmp)
+{
+    using G = GradLayout<F, D>;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= G::total) return;
+    const int64_t r0 = (int64_t)blockIdx.y * kFoldChunk;
+    const int64_t r1 = r0 + kFoldChunk < n_rows ? r0 + kFoldChunk : n_rows;
+    float sum = 0.0f;
+    for (int64_t r = r0; r < r1; ++r) sum += rep[r * G::stride + i];
+    tmp[(int64_t)blockIdx.y * G::stride + i] = sum;
+}
+
+template <int F, int D>
+__global__ __launch_bounds__(kBlock) void k_grad_fold2(const float *__restrict__ tmp, int64_t n_chunks, gnn_grads_t gr)
 {
     using G = GradLayout<F, D>;
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= G::total) return;
     float sum = 0.0f;
-#pragma unroll
-    for (int x = 0; x < kReplicas; ++x) sum += rep[x * G::stride + i];
+    for (int64_t c = 0; c < n_chunks; ++c) sum += tmp[c * G::stride + i];
     float *dst = i < G::obin ? gr.Win + (i - G::oWin)
                : i < G::oW1 ? gr.bin + (i - G::obin)
                : i < G::ob1 ? gr.W1 + (i - G::oW1)
@@ -514,9 +530,33 @@ __global__ __launch_bounds__(kBlock) void k_grad_fold(const float *__restrict__ 
     *dst += sum;
 }
 
+template <int F, int D>
+int grad_fold(const float *rep, int64_t n_rows, float *tmp, const gnn_grads_t *gr, hipStream_t s)
+{
+    using GL = GradLayout<F, D>;
+    const int64_t nc = fold_chunks(n_rows);
+    if (nc > 65535) return fail(GNN_ERR_UNSUPPORTED, "too many partial-gradient rows (%lld)", (long long)n_rows);
+    const unsigned gx = (GL::total + kBlock - 1) / kBlock;
+    GNN_LAUNCH("k_grad_fold", (k_grad_fold1<F, D>), dim3(gx, (unsigned)(nc < 1 ? 1 : nc)), kBlock, s, rep, n_rows, tmp);
+    GNN_LAUNCH("k_grad_fold", (k_grad_fold2<F, D>), gx, kBlock, s, tmp, nc, *gr);
+    return 0;
+}
+
+// rows of the partial table a backward over N hits / E segments needs: one per workgroup of its
+// widest launch (hit kernels: grid_for(N); k_edge_bwd: at most kSegGrid)
+constexpr int kSegGrid = 1024;
+inline int64_t bwd_rows(int64_t N, int64_t E)
+{
+    int64_t r = grid_for(N);
+    const int64_t ge = grid_for(E) < (unsigned)kSegGrid ? grid_for(E) : kSegGrid;
+    r = r > ge ? r : ge;
+    return r < 8 ? 8 : r;
+}
+
 struct BwdWs {
-    float *PQ, *gu, *gHa, *gHb, *gmio, *rep;
+    float *PQ, *gu, *gHa, *gHb, *gmio, *rep, *tmp;
     char *rep_end;
+    int64_t rows;
     size_t bytes;
 };
 
@@ -537,8 +577,11 @@ BwdWs carve_bwd(char *b, int64_t N, int64_t E, int ldh, int C, int D)
     // memset clears both
     w.gHa = take((size_t)N * ldh);
     const int tot = D * (C - D) + D + D * 2 * C + D + D + 1 + D * 3 * C + D + D * D + D;
-    w.rep = take((size_t)kReplicas * ((tot + 63) & ~63));
+    const size_t stride = (size_t)((tot + 63) & ~63);
+    w.rows = bwd_rows(N, E);
+    w.rep = take((size_t)w.rows * stride);
     w.rep_end = b + off;
+    w.tmp = take((size_t)fold_chunks(w.rows) * stride);
     w.bytes = off;
     return w;
 }
@@ -559,8 +602,8 @@ int backward_t(const gnn_graph_t *g, const gnn_params_t *p, int T, const float *
     }
     float *const rp = w.rep;
     constexpr int RS = GL::stride;
-    if (w.rep_end - reinterpret_cast<char *>(rp) < (ptrdiff_t)(kReplicas * RS * sizeof(float)))
-        return fail(GNN_ERR_WORKSPACE, "gradient replica area does not match GradLayout");
+    if (w.rep_end - reinterpret_cast<char *>(rp) < (ptrdiff_t)((size_t)w.rows * RS * sizeof(float)))
+        return fail(GNN_ERR_WORKSPACE, "partial-gradient table does not match GradLayout");
     const float *ge = grad_out;
     for (int t = T; t >= 0; --t) {
         const float *Ht = H_all + (size_t)t * N * LDH;
@@ -596,8 +639,7 @@ int backward_t(const gnn_graph_t *g, const gnn_params_t *p, int T, const float *
     if (N > 0)
         GNN_LAUNCH("k_input_bwd", (k_input_bwd<F, D>), grid_for(N), kBlock, s, g->X, H_all, LDH, gH,
                    rp + GL::oWin, rp + GL::obin, RS, N);
-    GNN_LAUNCH("k_grad_fold", (k_grad_fold<F, D>), (GL::total + kBlock - 1) / kBlock, kBlock, s, rp, *gr);
-    return 0;
+    return grad_fold<F, D>(rp, w.rows, w.tmp, gr, s);
 }
 
 // ---- per-module backward (the reference's sub-modules are ordinary autograd modules:
@@ -615,8 +657,8 @@ int edge_bwd_t(const float *H, const gnn_graph_t *g, const gnn_params_t *p, cons
     using GL = GradLayout<F, D>;
     float *const rp = w.rep;
     constexpr int RS = GL::stride;
-    hipError_t err = hipMemsetAsync(rp, 0, (size_t)kReplicas * RS * sizeof(float), s);
-    if (err != hipSuccess) return fail(-(int)err, "memset of the gradient replicas failed");
+    hipError_t err = hipMemsetAsync(rp, 0, (size_t)w.rows * RS * sizeof(float), s);
+    if (err != hipSuccess) return fail(-(int)err, "memset of the partial-gradient table failed");
     if (N > 0) GNN_LAUNCH("kb_pq", (kb_pq<F, D>), grid_for(N), kBlock, s, H, LDH, p->W1, p->b1, w.PQ, N);
     if (E > 0) {
         const unsigned ge_grid = grid_for(E) < (unsigned)kSegGrid ? grid_for(E) : (unsigned)kSegGrid;
@@ -626,8 +668,7 @@ int edge_bwd_t(const float *H, const gnn_graph_t *g, const gnn_params_t *p, cons
     if (N > 0)
         GNN_LAUNCH("k_pq_bwd", (k_pq_bwd<F, D>), grid_for(N), kBlock, s, H, LDH, w.PQ, w.gu, g->in_ptr, g->in_eid,
                    g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, p->W1, p->W2, gH, rp + GL::oW1, rp + GL::ob1, RS, N);
-    GNN_LAUNCH("k_grad_fold", (k_grad_fold<F, D>), (GL::total + kBlock - 1) / kBlock, kBlock, s, rp, *gr);
-    return 0;
+    return grad_fold<F, D>(rp, w.rows, w.tmp, gr, s);
 }
 
 // NodeNetwork: H' = tanh(W4 tanh(W3 [mi | mo | H] + b3) + b4).  Given gHn = dL/dH' (rows of LDH floats,
@@ -643,8 +684,8 @@ int node_bwd_t(const float *H, const float *e, const float *Hn, const gnn_graph_
     using GL = GradLayout<F, D>;
     float *const rp = w.rep;
     constexpr int RS = GL::stride;
-    hipError_t err = hipMemsetAsync(rp, 0, (size_t)kReplicas * RS * sizeof(float), s);
-    if (err != hipSuccess) return fail(-(int)err, "memset of the gradient replicas failed");
+    hipError_t err = hipMemsetAsync(rp, 0, (size_t)w.rows * RS * sizeof(float), s);
+    if (err != hipSuccess) return fail(-(int)err, "memset of the partial-gradient table failed");
     if (N > 0) {
         GNN_LAUNCH("k_node_bwd", (k_node_bwd<F, D>), grid_for(N), kBlock, s, H, Hn, LDH, e, g->in_ptr, g->in_eid,
                    g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, p->W3, p->b3, p->W4, gHn, gH, w.gmio,
@@ -653,8 +694,7 @@ int node_bwd_t(const float *H, const float *e, const float *Hn, const gnn_graph_
                    g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, gH, LDH, N);
     }
     if (E > 0) GNN_LAUNCH("k_seg_grad", (k_seg_grad<F, D>), grid_for(E), kBlock, s, g->src, g->dst, H, w.gmio, ge, E);
-    GNN_LAUNCH("k_grad_fold", (k_grad_fold<F, D>), (GL::total + kBlock - 1) / kBlock, kBlock, s, rp, *gr);
-    return 0;
+    return grad_fold<F, D>(rp, w.rows, w.tmp, gr, s);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1038,9 +1078,12 @@ int backward_events_t(const gnn_graph_t *g, const gnn_params_t *p, const int32_t
                       const gnn_grads_t *gr, char *ws, hipStream_t s)
 {
     using GL = GradLayout<F, D>;
+    // one row of partial sums per graph (= workgroup), folded in graph order
+    const int64_t rows = n_graphs > 0 ? n_graphs : 1;
     float *rp = reinterpret_cast<float *>(ws);
-    hipError_t err = hipMemsetAsync(rp, 0, (size_t)kReplicas * GL::stride * sizeof(float), s);
-    if (err != hipSuccess) return fail(-(int)err, "memset of the gradient replicas failed");
+    float *tmp = rp + (size_t)rows * GL::stride;
+    hipError_t err = hipMemsetAsync(rp, 0, (size_t)rows * GL::stride * sizeof(float), s);
+    if (err != hipSuccess) return fail(-(int)err, "memset of the partial-gradient table failed");
     if (n_graphs > 0) {
         static DevOnce attr_done;
         if (attr_done.need())
@@ -1051,8 +1094,7 @@ int backward_events_t(const gnn_graph_t *g, const gnn_params_t *p, const int32_t
         GNN_LAUNCH_SH("k_event_bwd", (k_event_bwd<F, D>), (unsigned)n_graphs, kBlock, lds, s, *g, *p, hit_ptr,
                       seg_ptr, T, e_all, H_all, grad_out, rp, cap_h, cap_s);
     }
-    GNN_LAUNCH("k_grad_fold", (k_grad_fold<F, D>), (GL::total + kBlock - 1) / kBlock, kBlock, s, rp, *gr);
-    return 0;
+    return grad_fold<F, D>(rp, rows, tmp, gr, s);
 }
 
 // shapes of the one-launch backward: the register-held gradient elements must stay few
@@ -1121,11 +1163,12 @@ int backward_events_supported(int F, int D, int64_t max_hits, int64_t max_segmen
     return 0;
 }
 
-size_t backward_events_workspace_bytes(int F, int D)
+size_t backward_events_workspace_bytes(int64_t n_graphs, int F, int D)
 {
     const int C = F + D;
     const int tot = D * F + D + D * 2 * C + D + D + 1 + D * 3 * C + D + D * D + D;
-    return (size_t)kReplicas * ((tot + 63) & ~63) * sizeof(float) + 256;
+    const int64_t rows = n_graphs > 0 ? n_graphs : 1;
+    return (size_t)(rows + fold_chunks(rows)) * ((tot + 63) & ~63) * sizeof(float) + 256;
 }
 
 int backward_events(const gnn_graph_t *g, const gnn_params_t *p, const int32_t *hit_ptr,
@@ -1133,9 +1176,9 @@ int backward_events(const gnn_graph_t *g, const gnn_params_t *p, const int32_t *
                     const float *e_all, const float *H_all, const float *grad_out,
                     const gnn_grads_t *gr, void *ws, size_t ws_bytes, hipStream_t s)
 {
-    if (ws_bytes < backward_events_workspace_bytes(p->F, p->D))
+    if (ws_bytes < backward_events_workspace_bytes(n_graphs, p->F, p->D))
         return fail(GNN_ERR_WORKSPACE, "event backward workspace too small: need %zu bytes",
-                    backward_events_workspace_bytes(p->F, p->D));
+                    backward_events_workspace_bytes(n_graphs, p->F, p->D));
     if (!backward_events_supported(p->F, p->D, cap_h, cap_s))
         return fail(GNN_ERR_UNSUPPORTED, "events of up to %d hits / %d segments do not fit the one-launch "
                     "backward at input_dim=%d hidden_dim=%d", cap_h, cap_s, p->F, p->D);

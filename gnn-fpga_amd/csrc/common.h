@@ -156,7 +156,7 @@ int bce_loss(const float *e, const float *y, int64_t n, float scale, float *loss
              float *partial, hipStream_t s);
 size_t backward_workspace_bytes(int64_t n_hits, int64_t n_segments, int F, int D);
 int backward_events_supported(int F, int D, int64_t max_hits, int64_t max_segments);
-size_t backward_events_workspace_bytes(int F, int D);
+size_t backward_events_workspace_bytes(int64_t n_graphs, int F, int D);
 int backward_events(const gnn_graph_t *g, const gnn_params_t *p, const int32_t *hit_ptr,
                     const int32_t *seg_ptr, int64_t n_graphs, int cap_h, int cap_s, int T,
                     const float *e_all, const float *H_all, const float *grad_out,

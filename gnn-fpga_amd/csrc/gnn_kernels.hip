@@ -964,7 +964,10 @@ int gnn_events_backward_supported(int32_t F, int32_t D, int64_t max_hits, int64_
     return backward_events_supported(F, D, max_hits, max_segments);
 }
 
-size_t gnn_backward_events_workspace_bytes(int32_t F, int32_t D) { return backward_events_workspace_bytes(F, D); }
+size_t gnn_backward_events_workspace_bytes(int64_t n_graphs, int32_t F, int32_t D)
+{
+    return backward_events_workspace_bytes(n_graphs, F, D);
+}
 
 int gnn_segclf_backward_events(const gnn_graph_t *g, const gnn_params_t *p, const int32_t *hit_ptr,
                                const int32_t *seg_ptr, int64_t n_graphs, int32_t max_hits,

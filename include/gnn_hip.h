@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNN_ABI_VERSION 1
+#define GNN_ABI_VERSION 2
 
 #define GNN_ERR_UNSUPPORTED (-10001) /* (F, D) has no kernel instantiation            */
 #define GNN_ERR_BADARG      (-10002) /* null pointer, negative size, bad stride ...   */
@@ -208,7 +208,7 @@ int gnn_segclf_backward(const gnn_graph_t *g, const gnn_params_t *p, int32_t n_i
  * gnn_backward_events_workspace_bytes.  gnn_events_backward_supported: 1 if graphs of that size
  * fit one workgroup for this (input_dim, hidden_dim). */
 int gnn_events_backward_supported(int32_t F, int32_t D, int64_t max_hits, int64_t max_segments);
-size_t gnn_backward_events_workspace_bytes(int32_t F, int32_t D);
+size_t gnn_backward_events_workspace_bytes(int64_t n_graphs, int32_t F, int32_t D);
 int gnn_segclf_backward_events(const gnn_graph_t *g, const gnn_params_t *p, const int32_t *hit_ptr,
                                const int32_t *seg_ptr, int64_t n_graphs, int32_t max_hits,
                                int32_t max_segments, int32_t n_iters, const float *e_all,

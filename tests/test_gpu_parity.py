@@ -666,6 +666,36 @@ def test_training_gradients_are_additive_over_graphs(hip, F, D):
         assert np.abs(a - r).max() < 1e-6 + 1e-4 * np.abs(r).max(), k
 
 
+@pytest.mark.parametrize("kind", ["detector graphs (per-pass kernels)", "muon events (one-launch kernels)"])
+def test_training_gradients_are_bit_reproducible(hip, kind):
+    """deterministic by default.  Every weight-gradient sum runs in a fixed order (one row
+    of partial sums per workgroup, rows folded in row order), so two backward passes over the same
+    batch give bit-identical gradients - with cross-workgroup float atomics they differed in the last
+    bits from run to run."""
+    from gnn_fpga_amd.loss import BCELoss
+    from gnn_fpga_amd.model import SegmentClassifier
+    torch.manual_seed(1)
+    if kind.startswith("detector"):
+        graphs = [synth.layered_graph(10000, 100000, 3, seed=80 + s) for s in range(6)]
+        F = 3
+    else:
+        graphs = [synth.muon_graph(s) for s in range(512)]
+        F = 11
+    b = HitGraphBatch.from_graphs(graphs).cuda()
+    y = b.y.cuda()
+    m = SegmentClassifier(input_dim=F, hidden_dim=8, n_iters=3).cuda().train()
+    runs = []
+    for _ in range(3):
+        m.zero_grad()
+        loss = BCELoss()(m(b), y)
+        loss.backward()
+        runs.append([loss.detach().clone()] + [p.grad.detach().clone() for p in m.parameters()])
+    for other in runs[1:]:
+        for a, c in zip(runs[0], other):
+            assert torch.equal(a, c)
+    assert all(float(g.abs().max()) > 0 for g in runs[0][1:])
+
+
 TOL_BF16 = 5e-3     # bf16 operands in the hit update (GNN_FLAG_BF16_MLP): stated separately from the
                     # fp32 path's 1e-5 (SURVEY 8(d): "1e-5 does not apply to bf16"); measured max 6e-4, mean 8e-5
 
