@@ -1606,24 +1606,35 @@ struct RecW {                   // one step group (4 list steps): this lane's pi
     }
 };
 
-// score the 4 segments of a group for the 4 hits of this wave pass and add their weighted R / S
+// score the 4 segments of a group for the 4 hits of this wave pass and add their weighted R / S;
+// dimension pairs run on packed fp32 (v_pk_fma_f32 / v_pk_mul_f32: two lanes of math per issue slot)
 template <int D, bool XP>
 __device__ __forceinline__ void score_w(const RecW<D> &g, const float *own, const float *w2, float b2, int p,
                                         float *acc)
 {
     constexpr int DL = D / 16;
+    static_assert(DL % 2 == 0, "dimension pairs");
+    const f2_t one2 = {1.0f, 1.0f};
     float part[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         float P[DL];
         g.r[j].first(P);
-        float s = 0.0f;
+        f2_t s2 = {0.0f, 0.0f};
 #pragma unroll
-        for (int i = 0; i < DL; ++i) {
-            const float r = XP ? __builtin_amdgcn_rcpf(fmaf(P[i], own[i], 1.0f)) : r_f(P[i] + own[i]);
-            s = fmaf(w2[i], r, s);
+        for (int i = 0; i < DL; i += 2) {
+            const f2_t pj = {P[i], P[i + 1]}, o2 = {own[i], own[i + 1]};
+            f2_t a;
+            if constexpr (XP) {
+                a = pj * o2 + one2;
+            } else {
+                const f2_t z = pj + o2;
+                a = f2_t{__builtin_amdgcn_exp2f(z.x), __builtin_amdgcn_exp2f(z.y)} + one2;
+            }
+            const f2_t r = {__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)};
+            s2 = f2_t{w2[i], w2[i + 1]} * r + s2;
         }
-        part[j] = s;
+        part[j] = s2.x + s2.y;
     }
     // 4x4 transpose-add inside the quad (as score4), then the other three quads of this hit
     const int q = p & 3;
@@ -1641,8 +1652,13 @@ __device__ __forceinline__ void score_w(const RecW<D> &g, const float *own, cons
     for (int j = 0; j < 4; ++j) {
         float R[DL];
         g.r[j].second(R);
+        const f2_t e2 = {e4[j], e4[j]};
 #pragma unroll
-        for (int i = 0; i < DL; ++i) acc[i] = fmaf(e4[j], R[i], acc[i]);
+        for (int i = 0; i < DL; i += 2) {
+            const f2_t a2 = f2_t{R[i], R[i + 1]} * e2 + f2_t{acc[i], acc[i + 1]};
+            acc[i] = a2.x;
+            acc[i + 1] = a2.y;
+        }
     }
 }
 
