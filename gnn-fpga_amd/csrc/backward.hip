@@ -455,6 +455,247 @@ __global__ __launch_bounds__(kBlock) void k_input_bwd(const float *__restrict__ 
     accum_outer<D, F>(g, x, active, gWin, F, 0, gbin, lds);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pull-form backward of one message-passing iteration (node pass + the edge pass that fed it),
+// hidden_dim <= 16.  The four kernels above move C-wide rows (H, gmi, gmo) and visit every segment
+// six times per iteration with twelve row gathers.  The same algebra that makes the forward cheap
+// (sell_pipeline.hip) applies to the gradients:
+//     mi = sum_in e H[s]  enters only as W3a mi = sum_in e R[s],  R = W3a H  (D wide)
+//     <gmi[d], H[s]> = gp[d] . R[s],   <gmo[s], H[d]> = gp[s] . S[d],   S = W3b H
+//     sum_out e gmi[d] = W3a^T Gout,  Gout[s] = sum_out e gp[d];   sum_in e gmo[s] = W3b^T Gin
+//     gW3a = sum_s Gout[s] H[s]^T,  gW3b = sum_d Gin[d] H[d]^T     (no aggregated M needed)
+// so per hit two records A = [P | R | gp], B = [Q | S | gp] (3D floats) carry everything a neighbour
+// must supply, a hit PULLS along its two CSR lists (fixed order, no atomics), and a segment's score
+// gradient is rebuilt at both of its ends:
+//   kb_prs    per hit:  P, R, Q, S from H                                   (fills A, B)
+//   k_hit_bwd per hit:  acc = U + sum_in e R[s] + sum_out e S[d] (the forward's sum), q, gp;
+//                       gp into A and B;  gH_prev = W3c^T gp;  gW3c, gb3, gW4, gb4
+//   k_seg_bwd per hit:  out list: ge, gu, gz from (Q, S, gp)[d] -> gP, Gout;  in list: from
+//                       (P, R, gp)[s] -> gQ, Gin (+ gW2, gb2 once per segment);
+//                       gH_prev += W1a^T gP + W1b^T gQ + W3a^T Gout + W3b^T Gin;  gW1, gb1, gW3a, gW3b
+// Two kernels and four row gathers per segment and iteration instead of four and twelve.
+template <int F, int D>
+__global__ __launch_bounds__(kBlock) void kb_prs(const float *__restrict__ H, int ldh, const float *__restrict__ W1,
+                                                 const float *__restrict__ b1, const float *__restrict__ W3,
+                                                 float *__restrict__ A, float *__restrict__ B, int64_t n_hits)
+{
+    constexpr int C = F + D;
+    const int64_t n = xcd_block() * kBlock + threadIdx.x;
+    if (n >= n_hits) return;
+    float h[C];
+#pragma unroll
+    for (int k = 0; k < C; ++k) h[k] = H[n * ldh + k];
+    float a[2 * D], b[2 * D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        float pp = b1[i], qq = 0.0f, rr = 0.0f, ss = 0.0f;
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            pp = fmaf(W1[i * 2 * C + k], h[k], pp);
+            qq = fmaf(W1[i * 2 * C + C + k], h[k], qq);
+            rr = fmaf(W3[i * 3 * C + k], h[k], rr);
+            ss = fmaf(W3[i * 3 * C + C + k], h[k], ss);
+        }
+        a[i] = pp; a[D + i] = rr; b[i] = qq; b[D + i] = ss;
+    }
+    store_row4<2 * D / 4>(A + n * 3 * D, a);
+    store_row4<2 * D / 4>(B + n * 3 * D, b);
+}
+
+template <int F, int D>
+__global__ __launch_bounds__(kBlock) void k_hit_bwd(
+    const float *__restrict__ H, const float *__restrict__ Hn, int ldh, const float *__restrict__ e,
+    const int32_t *__restrict__ in_ptr, const int32_t *__restrict__ in_eid, const int32_t *__restrict__ in_nbr,
+    const int32_t *__restrict__ out_ptr, const int32_t *__restrict__ out_eid, const int32_t *__restrict__ out_nbr,
+    const float *__restrict__ W3, const float *__restrict__ b3, const float *__restrict__ W4,
+    const float *__restrict__ gHn, float *__restrict__ gH, float *A, float *B, float *__restrict__ gW3,
+    float *__restrict__ gb3, float *__restrict__ gW4, float *__restrict__ gb4, int rep_stride, int64_t n_hits)
+{
+    gW3 = my_replica(gW3, rep_stride);
+    gb3 = my_replica(gb3, rep_stride);
+    gW4 = my_replica(gW4, rep_stride);
+    gb4 = my_replica(gb4, rep_stride);
+    constexpr int C = Shape<F, D>::C, LDH = Shape<F, D>::LDH;
+    __shared__ __attribute__((aligned(16))) float lds[outer_lds_floats<D, C>()];
+    const int64_t n = xcd_block() * kBlock + threadIdx.x;
+    const bool active = n < n_hits;
+    float h[C], q[D], gr[D], gp[D];
+#pragma unroll
+    for (int k = 0; k < C; ++k) h[k] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < D; ++i) q[i] = gr[i] = gp[i] = 0.0f;
+    if (active) {
+        float hp[LDH];
+        load_row4<LDH / 4>(H + n * ldh, hp);
+#pragma unroll
+        for (int k = 0; k < C; ++k) h[k] = hp[k];
+        float acc[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            float u = b3[i];
+#pragma unroll
+            for (int k = 0; k < C; ++k) u = fmaf(W3[i * 3 * C + 2 * C + k], h[k], u);
+            acc[i] = u;
+        }
+        auto add = [&](float w, const float *r) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) acc[i] = fmaf(w, r[i], acc[i]);
+        };
+        csr_walk<D / 4, 4>(in_ptr[n], in_ptr[n + 1],
+                           [&](int k) { return A + (int64_t)in_nbr[k] * 3 * D + D; },            // R[s]
+                           [&](int k) { return e[in_eid[k]]; }, add);
+        csr_walk<D / 4, 4>(out_ptr[n], out_ptr[n + 1],
+                           [&](int k) { return B + (int64_t)out_nbr[k] * 3 * D + D; },           // S[d]
+                           [&](int k) { return e[out_eid[k]]; }, add);
+#pragma unroll
+        for (int i = 0; i < D; ++i) q[i] = tanh_f(acc[i]);
+        float hn[D], gn[D];
+        load_row4<D / 4>(Hn + n * ldh, hn);
+        load_row4<D / 4>(gHn + n * ldh, gn);
+#pragma unroll
+        for (int i = 0; i < D; ++i) gr[i] = gn[i] * (1.0f - hn[i] * hn[i]);
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            float s = 0.0f;
+#pragma unroll
+            for (int i = 0; i < D; ++i) s = fmaf(W4[i * D + k], gr[i], s);
+            gp[k] = s * (1.0f - q[k] * q[k]);
+        }
+        float gh[LDH];
+#pragma unroll
+        for (int k = 0; k < LDH; ++k) gh[k] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            float s = 0.0f;
+#pragma unroll
+            for (int i = 0; i < D; ++i) s = fmaf(W3[i * 3 * C + 2 * C + k], gp[i], s);
+            gh[k] = s;
+        }
+        store_row4<LDH / 4>(gH + n * ldh, gh);                     // gHself initialises gH_prev
+    }
+    // every lane has finished READING neighbours' R / S before anyone writes its gp next to them?
+    // R / S and gp are different words of a record: no ordering is needed.
+    if (active) {
+        store_row4<D / 4>(A + n * 3 * D + 2 * D, gp);
+        store_row4<D / 4>(B + n * 3 * D + 2 * D, gp);
+    }
+    accum_outer<D, C>(gp, h, active, gW3, 3 * C, 2 * C, gb3, lds);
+    accum_outer<D, D>(gr, q, active, gW4, D, 0, gb4, lds);
+}
+
+template <int F, int D>
+__global__ __launch_bounds__(kBlock) void k_seg_bwd(
+    const float *__restrict__ H, int ldh, const float *__restrict__ A, const float *__restrict__ B,
+    const float *__restrict__ e, const int32_t *__restrict__ in_ptr, const int32_t *__restrict__ in_eid,
+    const int32_t *__restrict__ in_nbr, const int32_t *__restrict__ out_ptr, const int32_t *__restrict__ out_eid,
+    const int32_t *__restrict__ out_nbr, const float *__restrict__ W1, const float *__restrict__ W2,
+    const float *__restrict__ W3, float *__restrict__ gH, float *__restrict__ gW1, float *__restrict__ gb1,
+    float *__restrict__ gW2, float *__restrict__ gb2, float *__restrict__ gW3, int rep_stride, int64_t n_hits)
+{
+    gW1 = my_replica(gW1, rep_stride);
+    gb1 = my_replica(gb1, rep_stride);
+    gW2 = my_replica(gW2, rep_stride);
+    gb2 = my_replica(gb2, rep_stride);
+    gW3 = my_replica(gW3, rep_stride);
+    constexpr int C = Shape<F, D>::C, LDH = Shape<F, D>::LDH;
+    __shared__ __attribute__((aligned(16))) float lds[outer_lds_floats<D, C>()];
+    const int64_t n = xcd_block() * kBlock + threadIdx.x;
+    const bool active = n < n_hits;
+    float gP[D], gQ[D], Gout[D], Gin[D], h[C], sw2[D + 1];
+#pragma unroll
+    for (int i = 0; i < D; ++i) gP[i] = gQ[i] = Gout[i] = Gin[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i <= D; ++i) sw2[i] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < C; ++k) h[k] = 0.0f;
+    if (active) {
+        float a[3 * D], b[3 * D], w2[D];                 // own [P | R | gp], [Q | S | gp]
+        load_row4<3 * D / 4>(A + n * 3 * D, a);
+        load_row4<3 * D / 4>(B + n * 3 * D, b);
+#pragma unroll
+        for (int i = 0; i < D; ++i) w2[i] = W2[i];
+        constexpr int U = D <= 8 ? 4 : 2;
+        // segments starting here (n -> d): the end hit supplies [Q | S | gp]
+        csr_walk<3 * D / 4, U>(out_ptr[n], out_ptr[n + 1],
+                               [&](int k) { return B + (int64_t)out_nbr[k] * 3 * D; },
+                               [&](int k) { return e[out_eid[k]]; },
+                               [&](float ev, const float *r) {
+                                   float ge = 0.0f;
+#pragma unroll
+                                   for (int i = 0; i < D; ++i) ge = fmaf(r[2 * D + i], a[D + i], ge);     // gp[d] . R[n]
+#pragma unroll
+                                   for (int i = 0; i < D; ++i) ge = fmaf(a[2 * D + i], r[D + i], ge);     // gp[n] . S[d]
+                                   const float gu = ge * ev * (1.0f - ev);
+#pragma unroll
+                                   for (int i = 0; i < D; ++i) {
+                                       const float t = tanh_f(a[i] + r[i]);
+                                       gP[i] = fmaf(gu * w2[i], 1.0f - t * t, gP[i]);
+                                       Gout[i] = fmaf(ev, r[2 * D + i], Gout[i]);
+                                   }
+                               });
+        // segments ending here (s -> n): the start hit supplies [P | R | gp]; W2 / b2 sums are taken here
+        csr_walk<3 * D / 4, U>(in_ptr[n], in_ptr[n + 1],
+                               [&](int k) { return A + (int64_t)in_nbr[k] * 3 * D; },
+                               [&](int k) { return e[in_eid[k]]; },
+                               [&](float ev, const float *r) {
+                                   float ge = 0.0f;
+#pragma unroll
+                                   for (int i = 0; i < D; ++i) ge = fmaf(b[2 * D + i], r[D + i], ge);     // gp[n] . R[s]
+#pragma unroll
+                                   for (int i = 0; i < D; ++i) ge = fmaf(r[2 * D + i], b[D + i], ge);     // gp[s] . S[n]
+                                   const float gu = ge * ev * (1.0f - ev);
+#pragma unroll
+                                   for (int i = 0; i < D; ++i) {
+                                       const float t = tanh_f(r[i] + b[i]);
+                                       gQ[i] = fmaf(gu * w2[i], 1.0f - t * t, gQ[i]);
+                                       Gin[i] = fmaf(ev, r[2 * D + i], Gin[i]);
+                                       sw2[i] = fmaf(gu, t, sw2[i]);
+                                   }
+                                   sw2[D] += gu;
+                               });
+        float hr[LDH], gh[LDH];
+        load_row4<LDH / 4>(H + n * ldh, hr);
+        load_row4<LDH / 4>(gH + n * ldh, gh);
+#pragma unroll
+        for (int k = 0; k < C; ++k) h[k] = hr[k];
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            float s = 0.0f;
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                s = fmaf(W1[i * 2 * C + k], gP[i], s);
+                s = fmaf(W1[i * 2 * C + C + k], gQ[i], s);
+                s = fmaf(W3[i * 3 * C + k], Gout[i], s);
+                s = fmaf(W3[i * 3 * C + C + k], Gin[i], s);
+            }
+            gh[k] += s;
+        }
+        store_row4<LDH / 4>(gH + n * ldh, gh);
+    }
+    accum_outer<D, C>(gP, h, active, gW1, 2 * C, 0, gb1, lds);
+    accum_outer<D, C>(gQ, h, active, gW1, 2 * C, C, nullptr, lds);
+    accum_outer<D, C>(Gout, h, active, gW3, 3 * C, 0, nullptr, lds);
+    accum_outer<D, C>(Gin, h, active, gW3, 3 * C, C, nullptr, lds);
+    {   // gW2[D] | gb2: wave sums, then one writer per element of this workgroup's row
+        constexpr int NW = kBlock / 64, NS = D + 1;
+        float *red = lds;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            float x = sw2[i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+            if ((threadIdx.x & 63) == 0) red[(threadIdx.x >> 6) * NS + i] = x;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x <= D) {
+            float x = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) x += red[w * NS + threadIdx.x];
+            *((int)threadIdx.x < D ? gW2 + threadIdx.x : gb2) += x;
+        }
+    }
+}
+
 // gradient w.r.t. the scores a node pass consumed: ge[j] = <gmi[d], H[s]> + <gmo[s], H[d]>, zero for
 // padded segments (the whole-model backward folds this into k_edge_bwd; the per-module entry point
 // gnn_node_bwd hands it to the caller)
@@ -554,7 +795,7 @@ inline int64_t bwd_rows(int64_t N, int64_t E)
 }
 
 struct BwdWs {
-    float *PQ, *gu, *gHa, *gHb, *gmio, *rep, *tmp;
+    float *PQ, *gu, *gHa, *gHb, *gmio, *rep, *tmp, *A, *B;
     char *rep_end;
     int64_t rows;
     size_t bytes;
@@ -582,6 +823,8 @@ BwdWs carve_bwd(char *b, int64_t N, int64_t E, int ldh, int C, int D)
     w.rep = take((size_t)w.rows * stride);
     w.rep_end = b + off;
     w.tmp = take((size_t)fold_chunks(w.rows) * stride);
+    w.A = take((size_t)N * 3 * D);           // [P | R | gp], [Q | S | gp] of the pull-form kernels
+    w.B = take((size_t)N * 3 * D);
     w.bytes = off;
     return w;
 }
@@ -621,7 +864,27 @@ int backward_t(const gnn_graph_t *g, const gnn_params_t *p, int T, const float *
                        g->in_ptr, g->in_eid, g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, p->W1, p->W2,
                        gH, rp + GL::oW1, rp + GL::ob1, RS, N);
         if (t == 0) break;
-        // node pass t-1 backward: H_{t-1}, e_{t-1} -> H_t
+        if constexpr (D <= 16) {
+            // iterations t-1 .. 0 in pull form: node pass (H_{t-1}, e_{t-1} -> H_t) together with the
+            // edge pass that produced e_{t-1}
+            for (int u = t; u >= 1; --u) {
+                const float *Hu = H_all + (size_t)u * N * LDH;
+                const float *Hp = H_all + (size_t)(u - 1) * N * LDH;
+                const float *ep = e_all + (size_t)(u - 1) * E;
+                if (N > 0) {
+                    GNN_LAUNCH("kb_prs", (kb_prs<F, D>), grid_for(N), kBlock, s, Hp, LDH, p->W1, p->b1, p->W3, w.A, w.B, N);
+                    GNN_LAUNCH("k_hit_bwd", (k_hit_bwd<F, D>), grid_for(N), kBlock, s, Hp, Hu, LDH, ep, g->in_ptr,
+                               g->in_eid, g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, p->W3, p->b3, p->W4, gH,
+                               gHprev, w.A, w.B, rp + GL::oW3, rp + GL::ob3, rp + GL::oW4, rp + GL::ob4, RS, N);
+                    GNN_LAUNCH("k_seg_bwd", (k_seg_bwd<F, D>), grid_for(N), kBlock, s, Hp, LDH, w.A, w.B, ep, g->in_ptr,
+                               g->in_eid, g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, p->W1, p->W2, p->W3, gHprev,
+                               rp + GL::oW1, rp + GL::ob1, rp + GL::oW2, rp + GL::ob2, rp + GL::oW3, RS, N);
+                }
+                float *tmp = gH; gH = gHprev; gHprev = tmp;
+            }
+            break;
+        }
+        // (wide hidden layers: the per-pass kernels) node pass t-1 backward: H_{t-1}, e_{t-1} -> H_t
         const float *Hp = H_all + (size_t)(t - 1) * N * LDH;
         const float *ep = e_all + (size_t)(t - 1) * E;
         if (N > 0) {
