@@ -23,7 +23,7 @@
 // in LDS, each thread then owns output elements and sums over the 256 items (fixed order) and adds
 // the result to ITS WORKGROUP'S OWN ROW of a partial-sum table (row = blockIdx.x; one writer per
 // element, so the adds of successive launches land in launch order).  k_grad_fold1 / 2 then sum the
-// rows in row order, 256 rows per chunk, chunks in order: every float addition of a backward happens
+// rows in row order, 32 rows per chunk, chunks in order: every float addition of a backward happens
 // in a fixed order, and two runs give bit-identical gradients (deterministic by default).
 #include "common.h"
 
@@ -68,7 +68,7 @@ constexpr int kOuterCap = 128, kOuterStride = kBlock + 4;
 // A workgroup's partial gradient sums live in row blockIdx.x of the partial table (GradLayout::stride
 // floats per row): no other workgroup touches the row, so there is nothing to bounce between the
 // 8 L2s and nothing whose order could vary; the fold kernels add the rows up in a fixed order.
-constexpr int kFoldChunk = 256;           // rows summed sequentially by one thread of k_grad_fold1
+constexpr int kFoldChunk = 32;            // rows summed sequentially by one thread of k_grad_fold1
 __device__ __forceinline__ float *my_replica(float *g, int rep_stride)
 {
     return g + (size_t)blockIdx.x * rep_stride;
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(kBlock) void k_seg_bwd(
         load_row4<3 * D / 4>(B + n * 3 * D, b);
 #pragma unroll
         for (int i = 0; i < D; ++i) w2[i] = W2[i];
-        constexpr int U = D <= 8 ? 4 : 2;
+        constexpr int U = 2;                             // (4 rows of 3D floats in flight cost half the occupancy)
         // segments starting here (n -> d): the end hit supplies [Q | S | gp]
         csr_walk<3 * D / 4, U>(out_ptr[n], out_ptr[n + 1],
                                [&](int k) { return B + (int64_t)out_nbr[k] * 3 * D; },
@@ -734,7 +734,7 @@ struct GradLayout {
 };
 
 // rows of the partial table -> the caller's gradient tensors, in a fixed order: thread (element i,
-// chunk c) of k_grad_fold1 adds rows 256 c .. 256 c + 255 sequentially into tmp[c][i]; k_grad_fold2
+// chunk c) of k_grad_fold1 adds rows 32 c .. 32 c + 31 sequentially into tmp[c][i]; k_grad_fold2
 // adds the chunks of an element sequentially into the tensor.
 template <int F, int D>
 __global__ __launch_bounds__(kBlock) void k_grad_fold1(const float *__restrict__ rep, int64_t n_rows,
