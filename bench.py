@@ -169,17 +169,25 @@ def train_c4(dev, rank, world, rehearse, steps=60, warmup=15, n_global=512):
             dist.barrier()
             torch.cuda.synchronize()
 
+    def step_direct():                      # the same step without an autograd graph (GradBucket.step)
+        mean = bucket.step(m, batch, y)
+        opt.step()
+        return mean
+
     first = float(step())
     for _ in range(warmup):
         step()
     dt = time_steps(step, steps, sync_all)
+    for _ in range(warmup):
+        step_direct()
+    dd = time_steps(step_direct, steps, sync_all)
     last = float(step())
-    seg = torch.tensor([float(batch.n_segments), dt], dtype=torch.float64, device=dev)
+    seg = torch.tensor([float(batch.n_segments), dt, dd], dtype=torch.float64, device=dev)
     if world > 1:
         segs = seg.clone()
         dist.all_reduce(segs, op=dist.ReduceOp.SUM)
         dist.all_reduce(seg, op=dist.ReduceOp.MAX)
-        n_seg, dt = float(segs[0]), float(seg[1])
+        n_seg, dt, dd = float(segs[0]), float(seg[1]), float(seg[2])
     else:
         n_seg = float(seg[0])
     # did the collective see all ranks?  all-reduce of ones over the same backend
@@ -189,12 +197,15 @@ def train_c4(dev, rank, world, rehearse, steps=60, warmup=15, n_global=512):
     rec = {"workload": "c4: %d muon-schema graphs (F=11, D=8, T=3) sharded r::%d, %d per rank"
                        % (n_global, world, len(graphs)),
            "us_per_step": dt / steps * 1e6, "segments_per_s": n_seg * steps / dt,
+           "us_per_step_direct": dd / steps * 1e6, "segments_per_s_direct": n_seg * steps / dd,
+           "direct": "GradBucket.step: same kernels and collective, no autograd graph (backward adds "
+                     "straight into the bucket)",
            "segments_per_step": int(n_seg), "steps": steps,
            "collective": ("one all-reduce(sum) of the flat gradient bucket per step, %d floats, backend %s"
                           % (bucket.flat.numel(), ("gloo (rehearsal)" if rehearse else "nccl (RCCL)")
                              if world > 1 else "none (single rank)")),
            "rccl_ranks": int(ones.item()), "loss_first": first, "loss_last": last,
-           "mode": "eager"}
+           "mode": "eager; us_per_step = the reference-style loop (forward, loss.backward(), bucket all-reduce, Adam)"}
     if world == 1:
         # the whole step as ONE captured HIP graph (the library launches on the capturing stream and
         # allocates nothing; Adam capturable)

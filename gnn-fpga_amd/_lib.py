@@ -381,18 +381,14 @@ def segclf_forward_train(batch, weights, F, D, n_iters, layout=None):
     return e_all, H_all
 
 
-def segclf_backward(batch, weights, F, D, n_iters, e_all, H_all, grad_out):
-    """Gradients of the ten (effective) weight tensors, in state_dict order."""
+def segclf_backward(batch, weights, F, D, n_iters, e_all, H_all, grad_out, into=None):
+    """Gradients of the ten (effective) weight tensors, in state_dict order (`into`: ten tensors the
+    gradients are ADDED into instead of a fresh zero buffer)."""
     dev = batch.X.device
-    # one zero-filled buffer, ten views (one memset launch instead of ten)
-    flat = torch.zeros(sum(w.numel() for w in weights), dtype=torch.float32, device=dev)
-    grads, o = [], 0
-    for w in weights:
-        grads.append(flat[o:o + w.numel()].view_as(w))
-        o += w.numel()
-    gs = GnnGrads()
-    for name, t in zip(("Win", "bin", "W1", "b1", "W2", "b2", "W3", "b3", "W4", "b4"), grads):
-        setattr(gs, name, t.data_ptr())
+    if into is not None:
+        grads, gs = list(into), _grads_into(into)
+    else:       # one zero-filled buffer, ten views (one memset launch instead of ten)
+        grads, gs = _grad_views(weights, dev)
     need = int(load().gnn_backward_workspace_bytes(batch.n_hits, batch.n_segments, F, D))
     ws = torch.empty(need, dtype=torch.uint8, device=dev)
     g = cached_graph_struct(batch)
@@ -473,17 +469,23 @@ def events_backward_supported(F, D, max_hits, max_segments):
     return bool(load().gnn_events_backward_supported(F, D, max_hits, max_segments))
 
 
-def segclf_backward_events(batch, layout, weights, F, D, n_iters, e_all, H_all, grad_out):
-    """segclf_backward for a batch of small graphs in ONE launch (`layout` = batch.event_layout())."""
-    dev = batch.X.device
-    flat = torch.zeros(sum(w.numel() for w in weights), dtype=torch.float32, device=dev)
-    grads, o = [], 0
-    for w in weights:
-        grads.append(flat[o:o + w.numel()].view_as(w))
-        o += w.numel()
+def _grads_into(into):
+    """GnnGrads over ten caller-owned tensors (the backward ADDS into them)."""
     gs = GnnGrads()
-    for name, t in zip(("Win", "bin", "W1", "b1", "W2", "b2", "W3", "b3", "W4", "b4"), grads):
-        setattr(gs, name, t.data_ptr())
+    for name, t in zip(("Win", "bin", "W1", "b1", "W2", "b2", "W3", "b3", "W4", "b4"), into):
+        setattr(gs, name, _dev(t, torch.float32, "grad " + name))
+    return gs
+
+
+def segclf_backward_events(batch, layout, weights, F, D, n_iters, e_all, H_all, grad_out, into=None):
+    """segclf_backward for a batch of small graphs in ONE launch (`layout` = batch.event_layout()).
+    `into`: ten tensors the gradients are ADDED into (e.g. the views of a GradBucket) instead of a
+    fresh zero buffer."""
+    dev = batch.X.device
+    if into is not None:
+        grads, gs = list(into), _grads_into(into)
+    else:
+        grads, gs = _grad_views(weights, dev)
     ws = torch.empty(int(load().gnn_backward_events_workspace_bytes(batch.n_graphs, F, D)), dtype=torch.uint8,
                      device=dev)
     g = cached_graph_struct(batch)
