@@ -38,6 +38,18 @@ class _SegClf(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(grads)
 
 
+def training_batch(model, batch, use_events):
+    """The batch the training kernels run on: detector-size batches are renumbered in plan order once
+    (HitGraphBatch.level_ordered) so that the kernels' record gathers stay L2-local."""
+    if not getattr(model, "level_order_training", True) or batch.n_hits < 20000 or model.hidden_dim > 16:
+        return batch
+    if use_events:
+        lay = batch.event_layout()
+        if lay is not None and _lib.events_supported(model.input_dim, model.hidden_dim, lay.max_hits, lay.max_segments):
+            return batch                       # small graphs: the one-launch kernels
+    return batch.level_ordered(model.hidden_dim)
+
+
 def segclf_apply(model, batch):
     """Differentiable forward of `model` (a gnn_fpga_amd SegmentClassifier) on `batch`."""
     F, D = model.input_dim, model.hidden_dim
@@ -53,6 +65,7 @@ def segclf_apply(model, batch):
                nn_[0].effective_weight(), nn_[0].bias, nn_[2].effective_weight(), nn_[2].bias]
     # (the 1024-graph bound of the one-launch kernels: beyond it the per-pass kernels fill the chip)
     use_events = bool(getattr(model, "use_events", True)) and batch.n_graphs <= 1024
+    batch = training_batch(model, batch, use_events)
     e = _SegClf.apply(batch, F, D, model.n_iters, use_events, *weights)
     if batch.dense_shape:
         e = e.view(batch.dense_shape[0], batch.dense_shape[2])

@@ -149,6 +149,44 @@ class HitGraphBatch:
             self.plan.to(self.X.device)
         return self.plan
 
+    def level_ordered(self, hidden_dim=8):
+        """The same batch with its hits renumbered in PLAN order - (graph, detector level), tiles,
+        degree.  In that order the neighbours of consecutive hits lie in narrow id ranges, which makes
+        the training kernels' record gathers L2-local (c3 x 32 training step 1.68 -> 1.46 ms); scores
+        stay per segment in the caller's order and weight gradients do not depend on hit numbering,
+        so the twin is a drop-in for the training forward / backward.  Built once per batch (one plan
+        + two GPU sorts for its CSRs) and cached; returns self when there is nothing to gain (CPU
+        batch, no segments, no plan for this shape)."""
+        twin = getattr(self, "_twin", None)
+        if twin is not None:
+            return twin
+        self._twin = self
+        if not self.X.is_cuda or self.n_hits == 0 or self.n_segments == 0:
+            return self
+        try:
+            plan = self.build_plan(hidden_dim)
+        except Exception:                      # no fused kernels for this shape: keep the caller's order
+            return self
+        dev = self.X.device
+        perm = plan.perm.to(torch.int64)
+        order = perm[perm >= 0]                                   # twin id -> caller's hit id
+        rank = torch.empty(self.n_hits, dtype=torch.int64, device=dev)
+        rank[order] = torch.arange(self.n_hits, dtype=torch.int64, device=dev)
+        src, dst = self.src.to(torch.int64), self.dst.to(torch.int64)
+        t = HitGraphBatch.__new__(HitGraphBatch)
+        t.__dict__.update({k: v for k, v in self.__dict__.items() if not k.startswith("_")})
+        t.X = self.X[order].contiguous()
+        t.src = torch.where(src >= 0, rank[src.clamp_min(0)], src).to(torch.int32)
+        t.dst = torch.where(dst >= 0, rank[dst.clamp_min(0)], dst).to(torch.int32)
+        t._csr = None
+        t._src_host = t._dst_host = None
+        t._gstruct = None
+        t._event = (None,)                     # detector-size graphs: never the one-launch kernels
+        t.plan = None
+        t._twin = t
+        self._twin = t
+        return t
+
     def event_layout(self):
         """Per-graph layout for the one-workgroup-per-graph kernel (`_lib.segclf_forward_events`):
         device copies of hit_ptr / seg_ptr and the largest graph's size, or None when the batch is
@@ -389,6 +427,7 @@ class HitGraphBatch:
         if self.plan is not None:
             self.plan.to(device)
         self._gstruct = None         # cached C struct of raw device pointers (_lib.cached_graph_struct)
+        self._twin = None            # the level-ordered twin lives on the old device
         return self
 
     def cuda(self, device=None):

@@ -122,6 +122,9 @@ class GradBucket:
             if lay is not None and not (_lib.events_supported(F, D, lay.max_hits, lay.max_segments) and
                                         _lib.events_backward_supported(F, D, lay.max_hits, lay.max_segments)):
                 lay = None
+            if lay is None:
+                from .autograd import training_batch
+                batch = training_batch(model, batch, False)      # level-ordered twin: L2-local gathers
             e_all, H_all = _lib.segclf_forward_train(batch, w, F, D, T, layout=lay)
             yv = y.detach().to(torch.float32).contiguous().reshape(-1)
             loss_sum, ge = _lib.bce_loss(e_all[T], yv, 1.0)
