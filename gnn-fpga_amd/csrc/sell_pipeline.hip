@@ -2508,7 +2508,7 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_edge(
 // DL p .. of the start hit's P row and the end hit's Q row - a row is read as whole 128-byte lines
 // by the 16 lanes (one lane per segment made every load instruction touch 64 different rows:
 // 3.8 TB/s of gathered bytes, 66 % of the wave cycles waiting on issue, profiles/r02_c5_a).  XCD x
-// walks its own contiguous eighth of the segments (graphs stay in one L2), two passes in flight.
+// walks its own contiguous eighth of the segments (graphs stay in one L2), four passes in flight.
 template <int F, int D, bool XP>
 __global__ __launch_bounds__(256) void k_edge_w(const int32_t *__restrict__ src, const int32_t *__restrict__ dst,
                                                 const float *__restrict__ Pc, const float *__restrict__ Qc,
@@ -2526,10 +2526,13 @@ __global__ __launch_bounds__(256) void k_edge_w(const int32_t *__restrict__ src,
     const int64_t lo = (int64_t)(blockIdx.x & 7) * per;
     const int64_t hi = lo + per < n_segments ? lo + per : n_segments;
     const int64_t wave = (int64_t)(blockIdx.x >> 3) * 4 + (threadIdx.x >> 6), nwaves = (int64_t)(gridDim.x >> 3) * 4;
-    auto rows = [&](int64_t j, float *P, float *Q) {
-        const int s = j < hi ? src[j] : 0, d = j < hi ? dst[j] : 0;
-        load_vec<DL>(Pc + (int64_t)s * D + DL * p, P);
-        load_vec<DL>(Qc + (int64_t)d * D + DL * p, Q);
+    auto ends = [&](int64_t j, int &s_, int &d_) {
+        s_ = j < hi ? src[j] : 0;
+        d_ = j < hi ? dst[j] : 0;
+    };
+    auto rows = [&](int s_, int d_, float *P, float *Q) {
+        load_vec<DL>(Pc + (int64_t)s_ * D + DL * p, P);
+        load_vec<DL>(Qc + (int64_t)d_ * D + DL * p, Q);
     };
     auto score = [&](int64_t j, const float *P, const float *Q) {
         float acc = 0.0f;
@@ -2541,12 +2544,18 @@ __global__ __launch_bounds__(256) void k_edge_w(const int32_t *__restrict__ src,
         acc += dpp_row<0x128>(acc);
         if (p == 0 && j < hi) e[j] = r_f(acc + b2);
     };
-    for (int64_t b0 = lo + 8 * wave; b0 < hi; b0 += 8 * nwaves) {
-        float P0[DL], Q0[DL], P1[DL], Q1[DL];
-        rows(b0 + hs, P0, Q0);
-        rows(b0 + 4 + hs, P1, Q1);
-        score(b0 + hs, P0, Q0);
-        score(b0 + 4 + hs, P1, Q1);
+    // 16 segments per wave trip (4 passes of 4): all endpoint loads first, then all row loads, then the
+    // scores - the kernel waits on two dependent loads per segment and little else
+    constexpr int NP = 4;
+    for (int64_t b0 = lo + 4 * NP * wave; b0 < hi; b0 += 4 * NP * nwaves) {
+        int s_[NP], d_[NP];
+        float P[NP][DL], Q[NP][DL];
+#pragma unroll
+        for (int u = 0; u < NP; ++u) ends(b0 + 4 * u + hs, s_[u], d_[u]);
+#pragma unroll
+        for (int u = 0; u < NP; ++u) rows(s_[u], d_[u], P[u], Q[u]);
+#pragma unroll
+        for (int u = 0; u < NP; ++u) score(b0 + 4 * u + hs, P[u], Q[u]);
     }
 }
 
@@ -2749,7 +2758,7 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
         if constexpr (G::ed_rec == 0 && D % 16 == 0) {
             // wide rows, no LDS windows: every chunk is in global mode (absolute ids; padded
             // segments point at the NULL rows), so the chunk descriptors are not needed
-            const int64_t waves = (E + 7) / 8;                            // 8 segments per wave trip
+            const int64_t waves = (E + 15) / 16;                          // 16 segments per wave trip
             int64_t wg = (waves + 3) / 4;
             const int64_t cap = (int64_t)device_cus() * 8;                // 8 workgroups of 256 per CU
             wg = wg < cap ? wg : cap;
