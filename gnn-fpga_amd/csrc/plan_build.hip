@@ -168,17 +168,71 @@ __device__ __forceinline__ void hdr_add(int64_t *hdr, int slot, long long v)
 }
 
 // ---- stage 1 kernels ------------------------------------------------------------------------------
-__global__ __launch_bounds__(TB) void pb_degrees(const int *__restrict__ src, const int *__restrict__ dst, int64_t E,
-                                                 int *deg_in, int *deg_out, int64_t *hdr)
+// In / out degree of every hit.  Two global atomics per segment (51 M at c3 x 256) were 2 ms of a
+// 10 ms plan.  Segments arrive grouped (a graph's segments are contiguous, the reference emits them per
+// layer pair): a workgroup takes 16 k consecutive segments, finds the hit range their endpoints fall
+// into and, when it is narrow enough, counts in LDS and flushes only the touched counters - a few
+// thousand global atomics per workgroup instead of 32 k.  Wide ranges (shuffled input) count in global
+// memory as before.
+constexpr int kDegSegs = 16384, kDegRange = 16384;
+__global__ __launch_bounds__(1024) void pb_degrees(const int *__restrict__ src, const int *__restrict__ dst, int64_t E,
+                                                  int *deg_in, int *deg_out, int64_t *hdr)
 {
+    __shared__ int cin[kDegRange], cout[kDegRange];
+    __shared__ int red[2 * 16];
     int cnt = 0;
-    GS_LOOP(j, E) {
-        const int s = src[j];
-        if (s >= 0) {
-            atomicAdd(&deg_out[s], 1);
-            atomicAdd(&deg_in[dst[j]], 1);
-            ++cnt;
+    for (int64_t b0 = (int64_t)blockIdx.x * kDegSegs; b0 < E; b0 += (int64_t)gridDim.x * kDegSegs) {
+        const int64_t b1 = b0 + kDegSegs < E ? b0 + kDegSegs : E;
+        int mn = 0x7FFFFFFF, mx = -1;
+        for (int64_t j = b0 + threadIdx.x; j < b1; j += 1024) {
+            const int s = src[j];
+            if (s >= 0) {
+                const int d = dst[j];
+                mn = s < mn ? s : mn; mn = d < mn ? d : mn;
+                mx = s > mx ? s : mx; mx = d > mx ? d : mx;
+            }
         }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int a = __shfl_xor(mn, o, 64), b = __shfl_xor(mx, o, 64);
+            mn = a < mn ? a : mn;
+            mx = b > mx ? b : mx;
+        }
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) { red[2 * (threadIdx.x >> 6)] = mn; red[2 * (threadIdx.x >> 6) + 1] = mx; }
+        __syncthreads();
+        int lo = red[0], hi = red[1];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) {
+            lo = red[2 * w] < lo ? red[2 * w] : lo;
+            hi = red[2 * w + 1] > hi ? red[2 * w + 1] : hi;
+        }
+        const bool local = hi >= lo && hi - lo < kDegRange;
+        if (local)
+            for (int i = threadIdx.x; i <= hi - lo; i += 1024) cin[i] = cout[i] = 0;
+        __syncthreads();
+        for (int64_t j = b0 + threadIdx.x; j < b1; j += 1024) {
+            const int s = src[j];
+            if (s >= 0) {
+                const int d = dst[j];
+                if (local) {
+                    atomicAdd(&cout[s - lo], 1);
+                    atomicAdd(&cin[d - lo], 1);
+                } else {
+                    atomicAdd(&deg_out[s], 1);
+                    atomicAdd(&deg_in[d], 1);
+                }
+                ++cnt;
+            }
+        }
+        __syncthreads();
+        if (local)
+            for (int i = threadIdx.x; i <= hi - lo; i += 1024) {
+                const int a = cin[i], b = cout[i];
+                if (a) atomicAdd(&deg_in[lo + i], a);
+                if (b) atomicAdd(&deg_out[lo + i], b);
+            }
+        __syncthreads();
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
@@ -206,25 +260,38 @@ __global__ __launch_bounds__(TB) void pb_gid(const int64_t *__restrict__ hit_ptr
 // value, and a reader that sees a start hit already raised to t draws the same conclusion as one
 // that sees t-1.  (Values only come from earlier launches or are this very t: no stale-cache case.)
 // A sweep that stored nothing (chg[t] == 0) found the fixpoint; all later sweeps return at once.
+// Levels are swept as BYTES (the iterate never exceeds kMaxLevelIters = 64): 2.5 MB for the 2.56 M hits of
+// c3 x 256, which every XCD's 4 MB L2 holds, where the int32 table's 10 MB lived in the MALL - the
+// sweep is one random level[src] read per segment and nothing else.  pb_widen hands int32 levels on.
 __global__ __launch_bounds__(TB) void pb_level_sweep(const int *__restrict__ src, const int *__restrict__ dst, int64_t E,
-                                                     int *level, int *chg, int t)
+                                                     unsigned char *level, int *chg, int t)
 {
     if (t > 1 && chg[t - 1] == 0) return;
     int any = 0;
     GS_LOOP(j, E) {
         const int s = src[j];
         if (s < 0) continue;
-        if (level[s] >= t - 1) {
-            level[dst[j]] = t;
+        if ((int)level[s] >= t - 1) {
+            level[dst[j]] = (unsigned char)t;
             any = 1;
         }
     }
     if (__any(any) && (threadIdx.x & 63) == 0 && chg[t] == 0) chg[t] = 1;
 }
 
+__global__ __launch_bounds__(TB) void pb_widen(const unsigned char *__restrict__ a, int *b, int64_t n)
+{
+    GS_LOOP(i, n) b[i] = a[i];
+}
+
+// (One cooperative launch with grid.sync() between sweeps was measured and dropped: a grid barrier
+// with its cross-XCD L2 write-back costs 45-160 us per sweep on this part, against 5 us for an empty
+// launch and 20-210 us for a full one - 0.51 ms instead of 0.42 for one detector graph, 3.1 ms
+// instead of 2.3 for c3 x 256.)
 // Small batches: all sweeps in ONE launch by one workgroup (its waves share the CU's L1, so a
 // workgroup barrier orders the stores of sweep t before the loads of sweep t + 1) - 64 launches
 // would cost more than the sweeps themselves.
+constexpr int kSweepRound = 12;
 constexpr int64_t kSmallSweepSegments = 1 << 15;   // (100 k segments: 0.69 ms in one workgroup, 0.41 ms as 64 launches)
 __global__ __launch_bounds__(1024) void pb_levels_small(const int *__restrict__ src, const int *__restrict__ dst, int E,
                                                         int *level)
@@ -934,14 +1001,31 @@ int gnn_plan_build_sizes(const int32_t *src, const int32_t *dst, const int64_t *
     // header, sweep flags, degrees and both level buffers start at zero (adjacent in the workspace)
     HIP_OK(hipMemsetAsync(w.hdr, 0, (size_t)(reinterpret_cast<char *>(w.gid) - reinterpret_cast<char *>(w.hdr)), s), "memset");
     HIP_OK(hipMemsetAsync(w.degn, 0, (size_t)(b.np_max + 1) * sizeof(I2), s), "memset");
-    GNN_LAUNCH("pb_degrees", pb_degrees, gs(E), TB, s, src, dst, E, w.deg_in, w.deg_out, w.hdr);
+    {
+        const int64_t nb = (E + kDegSegs - 1) / kDegSegs;
+        GNN_LAUNCH("pb_degrees", pb_degrees, (unsigned)(nb < 2048 ? nb : 2048), 1024, s, src, dst, E, w.deg_in, w.deg_out,
+                   w.hdr);
+    }
     GNN_LAUNCH("pb_gid", pb_gid, gs(n), TB, s, hit_ptr, G, n, w.gid);
     int *level = w.lvA;
     if (E <= kSmallSweepSegments)
         GNN_LAUNCH("pb_levels_small", pb_levels_small, 1, 1024, s, src, dst, (int)E, level);
     else
-        for (int t = 1; t <= kMaxLevelIters; ++t)
-            GNN_LAUNCH("pb_level_sweep", pb_level_sweep, gs(E), TB, s, src, dst, E, level, w.chg, t);
+        // in rounds of 12 sweeps (a 10-layer detector graph is done after 11); one 4-byte read-back per
+        // round costs ~15 us, the 52 launches it usually saves cost 0.3 ms
+    {
+        unsigned char *lv8 = reinterpret_cast<unsigned char *>(w.lvB);   // (zeroed with the header)
+        for (int t = 1; t <= kMaxLevelIters; ++t) {
+            GNN_LAUNCH("pb_level_sweep", pb_level_sweep, gs(E), TB, s, src, dst, E, lv8, w.chg, t);
+            if (t % kSweepRound == 0 && t < kMaxLevelIters) {
+                int raised = 1;
+                HIP_OK(hipMemcpyAsync(&raised, w.chg + t, sizeof(int), hipMemcpyDeviceToHost, s), "sweep flag read-back");
+                HIP_OK(hipStreamSynchronize(s), "sweep flag read-back");
+                if (!raised) break;
+            }
+        }
+        GNN_LAUNCH("pb_widen", pb_widen, gs(n), TB, s, lv8, level, n);
+    }
     GNN_LAUNCH("pb_fill_i32", pb_fill_i32, gs(n), TB, s, w.down, n, 0x7FFFFFFF);
     GNN_LAUNCH("pb_down", pb_down, gs(E), TB, s, src, dst, E, level, w.deg_in, w.down);
     GNN_LAUNCH("pb_key1", pb_key1, gs(n), TB, s, n, w.deg_in, w.deg_out, w.gid, level, w.down, w.k64a, w.iota, w.hdr);
