@@ -13,7 +13,7 @@ import torch  # imported first: its bundled libamdhip64.so.7 is the one HIP runt
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgnn_hip.so")
 
-GNN_ABI_VERSION = 2
+GNN_ABI_VERSION = 3
 GNN_ERR_UNSUPPORTED = -10001
 GNN_ERR_BADARG = -10002
 GNN_ERR_WORKSPACE = -10003
@@ -88,10 +88,10 @@ SIGNATURES = {
                                                   _f, _f, _i64, _i32, _i32, _i32, _f, _f, _f,
                                                   ctypes.POINTER(GnnGrads), _f, _sz, _f]),
     "gnn_segclf_forward_train": (ctypes.c_int, [ctypes.POINTER(GnnGraph),
-                                                ctypes.POINTER(GnnParams), _i32, _f, _f, _f, _sz, _f]),
+                                                ctypes.POINTER(GnnParams), _i32, _f, _f, _f, _f, _sz, _f]),
     "gnn_backward_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
     "gnn_segclf_backward": (ctypes.c_int, [ctypes.POINTER(GnnGraph), ctypes.POINTER(GnnParams),
-                                           _i32, _f, _f, _f, ctypes.POINTER(GnnGrads), _f, _sz, _f]),
+                                           _i32, _f, _f, _f, _f, ctypes.POINTER(GnnGrads), _f, _sz, _f]),
     "gnn_bce_loss": (ctypes.c_int, [_f, _f, _i64, ctypes.c_float, _f, _f, _f, _f]),
     "gnn_dense_to_index": (ctypes.c_int, [_f, _f, _i64, _i64, _i64, _f, _f, _f, _f]),
     "gnn_edge_bwd": (ctypes.c_int, [_f, _i32, ctypes.POINTER(GnnGraph), ctypes.POINTER(GnnParams), _f, _f, _f,
@@ -354,7 +354,9 @@ def segclf_forward_events(batch, layout, weights, F, D, n_iters, out=None, param
 
 
 def segclf_forward_train(batch, weights, F, D, n_iters, layout=None):
-    """Training forward: returns (e_all [(T+1), E], H_all [(T+1), N, ldh]); scores = e_all[-1].
+    """Training forward: returns (e_all [(T+1), E], H_all [(T+1), N, ldh], Q_all [T, N, D]); scores =
+    e_all[-1].  Q_all (the node networks' hidden layers) is empty on the one-launch route, whose
+    backward keeps everything in LDS.
     `layout` (batch.event_layout() of a batch of small graphs): one launch for the whole forward."""
     dev = batch.X.device
     E, N = batch.n_segments, batch.n_hits
@@ -370,20 +372,24 @@ def segclf_forward_train(batch, weights, F, D, n_iters, layout=None):
                 _dev(layout.seg_ptr, torch.int32, "seg_ptr"), batch.n_graphs, layout.max_hits,
                 layout.max_segments, n_iters, _dev(e_all, torch.float32, "e_all"),
                 _dev(H_all, torch.float32, "H_all"), st))
-        return e_all, H_all
+        return e_all, H_all, torch.empty((0, N, D), dtype=torch.float32, device=dev)
+    Q_all = torch.empty((n_iters, N, D), dtype=torch.float32, device=dev)
     ws = torch.empty(workspace_bytes(N, E, F, D), dtype=torch.uint8, device=dev)
     g = cached_graph_struct(batch)
     p = params_struct(weights, F, D)
     with _on(batch.X, g, p) as st:
         _check(load().gnn_segclf_forward_train(ctypes.byref(g), ctypes.byref(p), n_iters,
-                                               e_all.data_ptr(), H_all.data_ptr(), ws.data_ptr(),
-                                               ws.numel(), st))
-    return e_all, H_all
+                                               e_all.data_ptr(), H_all.data_ptr(), Q_all.data_ptr(),
+                                               ws.data_ptr(), ws.numel(), st))
+    return e_all, H_all, Q_all
 
 
-def segclf_backward(batch, weights, F, D, n_iters, e_all, H_all, grad_out, into=None):
+def segclf_backward(batch, weights, F, D, n_iters, e_all, H_all, grad_out, into=None, Q_all=None):
     """Gradients of the ten (effective) weight tensors, in state_dict order (`into`: ten tensors the
-    gradients are ADDED into instead of a fresh zero buffer)."""
+    gradients are ADDED into instead of a fresh zero buffer; `Q_all`: the hidden layers kept by
+    segclf_forward_train - without them the node passes are walked a second time)."""
+    if Q_all is not None and Q_all.numel() != n_iters * batch.n_hits * D:
+        Q_all = None
     dev = batch.X.device
     if into is not None:
         grads, gs = list(into), _grads_into(into)
@@ -397,6 +403,7 @@ def segclf_backward(batch, weights, F, D, n_iters, e_all, H_all, grad_out, into=
         _check(load().gnn_segclf_backward(ctypes.byref(g), ctypes.byref(p), n_iters,
                                           _dev(e_all, torch.float32, "e_all"),
                                           _dev(H_all, torch.float32, "H_all"),
+                                          _dev(Q_all, torch.float32, "Q_all") if Q_all is not None and Q_all.numel() else None,
                                           _dev(grad_out, torch.float32, "grad_out"),
                                           ctypes.byref(gs), ws.data_ptr(), ws.numel(), st))
     return grads

@@ -17,16 +17,18 @@ class _SegClf(torch.autograd.Function):
         w = [t.detach().to(torch.float32).contiguous() for t in weights]
         # small graphs (the reference's muon events): the whole forward in one launch
         lay = batch.event_layout() if (use_events and batch.n_graphs > 0) else None
-        if lay is not None and not _lib.events_supported(F, D, lay.max_hits, lay.max_segments):
+        # (only when the backward has its one-launch form too: the per-pass backward wants Q_all)
+        if lay is not None and not (_lib.events_supported(F, D, lay.max_hits, lay.max_segments) and
+                                    _lib.events_backward_supported(F, D, lay.max_hits, lay.max_segments)):
             lay = None
-        e_all, H_all = _lib.segclf_forward_train(batch, w, F, D, n_iters, layout=lay)
+        e_all, H_all, Q_all = _lib.segclf_forward_train(batch, w, F, D, n_iters, layout=lay)
         ctx.batch, ctx.F, ctx.D, ctx.n_iters, ctx.use_events = batch, F, D, n_iters, use_events
-        ctx.save_for_backward(e_all, H_all, *w)
+        ctx.save_for_backward(e_all, H_all, Q_all, *w)
         return e_all[n_iters].clone()
 
     @staticmethod
     def backward(ctx, grad_out):
-        e_all, H_all, *w = ctx.saved_tensors
+        e_all, H_all, Q_all, *w = ctx.saved_tensors
         go = grad_out.to(torch.float32).contiguous()
         b = ctx.batch
         # small graphs (the reference's muon events): the whole backward in one launch
@@ -34,7 +36,7 @@ class _SegClf(torch.autograd.Function):
         if lay is not None and _lib.events_backward_supported(ctx.F, ctx.D, lay.max_hits, lay.max_segments):
             grads = _lib.segclf_backward_events(b, lay, list(w), ctx.F, ctx.D, ctx.n_iters, e_all, H_all, go)
         else:
-            grads = _lib.segclf_backward(b, list(w), ctx.F, ctx.D, ctx.n_iters, e_all, H_all, go)
+            grads = _lib.segclf_backward(b, list(w), ctx.F, ctx.D, ctx.n_iters, e_all, H_all, go, Q_all=Q_all)
         return (None, None, None, None, None) + tuple(grads)
 
 

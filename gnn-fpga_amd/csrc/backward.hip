@@ -502,9 +502,10 @@ __global__ __launch_bounds__(kBlock) void kb_prs(const float *__restrict__ H, in
     store_row4<2 * D / 4>(B + n * 3 * D, b);
 }
 
-template <int F, int D>
+template <int F, int D, bool KEPT>
 __global__ __launch_bounds__(kBlock) void k_hit_bwd(
-    const float *__restrict__ H, const float *__restrict__ Hn, int ldh, const float *__restrict__ e,
+    const float *__restrict__ H, const float *__restrict__ Hn, const float *__restrict__ Qk, int ldh,
+    const float *__restrict__ e,
     const int32_t *__restrict__ in_ptr, const int32_t *__restrict__ in_eid, const int32_t *__restrict__ in_nbr,
     const int32_t *__restrict__ out_ptr, const int32_t *__restrict__ out_eid, const int32_t *__restrict__ out_nbr,
     const float *__restrict__ W3, const float *__restrict__ b3, const float *__restrict__ W4,
@@ -529,26 +530,30 @@ __global__ __launch_bounds__(kBlock) void k_hit_bwd(
         load_row4<LDH / 4>(H + n * ldh, hp);
 #pragma unroll
         for (int k = 0; k < C; ++k) h[k] = hp[k];
-        float acc[D];
-#pragma unroll
-        for (int i = 0; i < D; ++i) {
-            float u = b3[i];
-#pragma unroll
-            for (int k = 0; k < C; ++k) u = fmaf(W3[i * 3 * C + 2 * C + k], h[k], u);
-            acc[i] = u;
+        if constexpr (KEPT) {
+            load_row4<D / 4>(Qk + n * D, q);                     // kept by the training forward (k_node)
+        } else {
+            float acc[D];
+    #pragma unroll
+            for (int i = 0; i < D; ++i) {
+                float u = b3[i];
+    #pragma unroll
+                for (int k = 0; k < C; ++k) u = fmaf(W3[i * 3 * C + 2 * C + k], h[k], u);
+                acc[i] = u;
+            }
+            auto add = [&](float w, const float *r) {
+    #pragma unroll
+                for (int i = 0; i < D; ++i) acc[i] = fmaf(w, r[i], acc[i]);
+            };
+            csr_walk<D / 4, 4>(in_ptr[n], in_ptr[n + 1],
+                               [&](int k) { return A + (int64_t)in_nbr[k] * 3 * D + D; },            // R[s]
+                               [&](int k) { return e[in_eid[k]]; }, add);
+            csr_walk<D / 4, 4>(out_ptr[n], out_ptr[n + 1],
+                               [&](int k) { return B + (int64_t)out_nbr[k] * 3 * D + D; },           // S[d]
+                               [&](int k) { return e[out_eid[k]]; }, add);
+    #pragma unroll
+            for (int i = 0; i < D; ++i) q[i] = tanh_f(acc[i]);
         }
-        auto add = [&](float w, const float *r) {
-#pragma unroll
-            for (int i = 0; i < D; ++i) acc[i] = fmaf(w, r[i], acc[i]);
-        };
-        csr_walk<D / 4, 4>(in_ptr[n], in_ptr[n + 1],
-                           [&](int k) { return A + (int64_t)in_nbr[k] * 3 * D + D; },            // R[s]
-                           [&](int k) { return e[in_eid[k]]; }, add);
-        csr_walk<D / 4, 4>(out_ptr[n], out_ptr[n + 1],
-                           [&](int k) { return B + (int64_t)out_nbr[k] * 3 * D + D; },           // S[d]
-                           [&](int k) { return e[out_eid[k]]; }, add);
-#pragma unroll
-        for (int i = 0; i < D; ++i) q[i] = tanh_f(acc[i]);
         float hn[D], gn[D];
         load_row4<D / 4>(Hn + n * ldh, hn);
         load_row4<D / 4>(gHn + n * ldh, gn);
@@ -831,8 +836,8 @@ BwdWs carve_bwd(char *b, int64_t N, int64_t E, int ldh, int C, int D)
 
 template <int F, int D>
 int backward_t(const gnn_graph_t *g, const gnn_params_t *p, int T, const float *e_all,
-               const float *H_all, const float *grad_out, const gnn_grads_t *gr, char *ws,
-               hipStream_t s)
+               const float *H_all, const float *Q_all, const float *grad_out, const gnn_grads_t *gr,
+               char *ws, hipStream_t s)
 {
     constexpr int C = Shape<F, D>::C, LDH = Shape<F, D>::LDH;
     const int64_t N = g->n_hits, E = g->n_segments;
@@ -873,9 +878,16 @@ int backward_t(const gnn_graph_t *g, const gnn_params_t *p, int T, const float *
                 const float *ep = e_all + (size_t)(u - 1) * E;
                 if (N > 0) {
                     GNN_LAUNCH("kb_prs", (kb_prs<F, D>), grid_for(N), kBlock, s, Hp, LDH, p->W1, p->b1, p->W3, w.A, w.B, N);
-                    GNN_LAUNCH("k_hit_bwd", (k_hit_bwd<F, D>), grid_for(N), kBlock, s, Hp, Hu, LDH, ep, g->in_ptr,
-                               g->in_eid, g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, p->W3, p->b3, p->W4, gH,
-                               gHprev, w.A, w.B, rp + GL::oW3, rp + GL::ob3, rp + GL::oW4, rp + GL::ob4, RS, N);
+                    if (Q_all)
+                        GNN_LAUNCH("k_hit_bwd", (k_hit_bwd<F, D, true>), grid_for(N), kBlock, s, Hp, Hu,
+                                   Q_all + (size_t)(u - 1) * N * D, LDH, ep, g->in_ptr, g->in_eid, g->in_nbr, g->out_ptr,
+                                   g->out_eid, g->out_nbr, p->W3, p->b3, p->W4, gH, gHprev, w.A, w.B, rp + GL::oW3,
+                                   rp + GL::ob3, rp + GL::oW4, rp + GL::ob4, RS, N);
+                    else
+                        GNN_LAUNCH("k_hit_bwd", (k_hit_bwd<F, D, false>), grid_for(N), kBlock, s, Hp, Hu, nullptr, LDH, ep,
+                                   g->in_ptr, g->in_eid, g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, p->W3, p->b3,
+                                   p->W4, gH, gHprev, w.A, w.B, rp + GL::oW3, rp + GL::ob3, rp + GL::oW4, rp + GL::ob4, RS,
+                                   N);
                     GNN_LAUNCH("k_seg_bwd", (k_seg_bwd<F, D>), grid_for(N), kBlock, s, Hp, LDH, w.A, w.B, ep, g->in_ptr,
                                g->in_eid, g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, p->W1, p->W2, p->W3, gHprev,
                                rp + GL::oW1, rp + GL::ob1, rp + GL::oW2, rp + GL::ob2, rp + GL::oW3, RS, N);
@@ -1459,14 +1471,14 @@ size_t backward_workspace_bytes(int64_t N, int64_t E, int F, int D)
 }
 
 int backward(const gnn_graph_t *g, const gnn_params_t *p, int T, const float *e_all,
-             const float *H_all, const float *grad_out, const gnn_grads_t *gr, void *ws,
-             size_t ws_bytes, hipStream_t s)
+             const float *H_all, const float *Q_all, const float *grad_out, const gnn_grads_t *gr,
+             void *ws, size_t ws_bytes, hipStream_t s)
 {
     if (ws_bytes < backward_workspace_bytes(g->n_hits, g->n_segments, p->F, p->D))
         return fail(GNN_ERR_WORKSPACE, "backward workspace too small: need %zu bytes",
                     backward_workspace_bytes(g->n_hits, g->n_segments, p->F, p->D));
     char *base = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
-#define X_(F_, D_) if (p->F == F_ && p->D == D_) return backward_t<F_, D_>(g, p, T, e_all, H_all, grad_out, gr, base, s);
+#define X_(F_, D_) if (p->F == F_ && p->D == D_) return backward_t<F_, D_>(g, p, T, e_all, H_all, Q_all, grad_out, gr, base, s);
     BWD_FOR_EACH_SHAPE(X_)
 #undef X_
     return fail(GNN_ERR_UNSUPPORTED, "no backward kernel for input_dim=%d hidden_dim=%d", p->F, p->D);

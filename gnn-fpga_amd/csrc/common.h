@@ -162,8 +162,8 @@ int backward_events(const gnn_graph_t *g, const gnn_params_t *p, const int32_t *
                     const float *e_all, const float *H_all, const float *grad_out,
                     const gnn_grads_t *gr, void *ws, size_t ws_bytes, hipStream_t s);
 int backward(const gnn_graph_t *g, const gnn_params_t *p, int T, const float *e_all,
-             const float *H_all, const float *grad_out, const gnn_grads_t *gr, void *ws,
-             size_t ws_bytes, hipStream_t s);
+             const float *H_all, const float *Q_all, const float *grad_out, const gnn_grads_t *gr,
+             void *ws, size_t ws_bytes, hipStream_t s);
 
 int edge_bwd(const float *H, const gnn_graph_t *g, const gnn_params_t *p, const float *e, const float *ge, float *gH,
              const gnn_grads_t *gr, void *ws, size_t ws_bytes, hipStream_t s);

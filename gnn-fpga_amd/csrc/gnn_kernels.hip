@@ -195,7 +195,7 @@ __global__ __launch_bounds__(kBlock) void k_node(
     const int32_t *__restrict__ out_eid, const int32_t *__restrict__ out_nbr,
     const float *__restrict__ W3, const float *__restrict__ b3, const float *__restrict__ W4,
     const float *__restrict__ b4, const float *__restrict__ W1, const float *__restrict__ b1,
-    float *__restrict__ Hn, int ldhn, float *__restrict__ PQ, int64_t n_hits)
+    float *__restrict__ Hn, int ldhn, float *__restrict__ PQ, float *__restrict__ Qkeep, int64_t n_hits)
 {
     constexpr int C = Shape<F, D>::C;
     constexpr int LDH = Shape<F, D>::LDH;
@@ -246,6 +246,7 @@ __global__ __launch_bounds__(kBlock) void k_node(
         for (int k = 0; k < C; ++k) acc = fmaf(W3[d * 3 * C + 2 * C + k], M[2 * LDH + k], acc);
         q[d] = tanh_f(acc);
     }
+    if (Qkeep) store_row4<D / 4>(Qkeep + n * D, q);         // training: the backward needs no second list walk
     float hn[LDH];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
@@ -616,12 +617,12 @@ int run_edge(const int32_t *src, const int32_t *dst, const float *PQ, const floa
 template <int F, int D>
 int run_node(const float *H, int ldh, const float *e, const gnn_graph_t *g, const float *W3,
              const float *b3, const float *W4, const float *b4, const float *W1, const float *b1,
-             float *Hn, int ldhn, float *PQ, hipStream_t s)
+             float *Hn, int ldhn, float *PQ, hipStream_t s, float *Qkeep = nullptr)
 {
     if (g->n_hits > 0)
         GNN_LAUNCH("k_node", (k_node<F, D>), grid_for(g->n_hits), kBlock, s, H, ldh, e, g->in_ptr,
                    g->in_eid, g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, W3, b3, W4, b4, W1, b1,
-                   Hn, ldhn, PQ, g->n_hits);
+                   Hn, ldhn, PQ, Qkeep, g->n_hits);
     return 0;
 }
 
@@ -646,7 +647,8 @@ Workspace carve(void *base, int64_t n_hits, int64_t n_seg, int ldh, int D)
 
 template <int F, int D>
 int forward_impl(const gnn_graph_t *g, const gnn_params_t *p, int n_iters, float *e_out,
-                 float *e_trace, float *H_trace, void *ws, hipStream_t s, float *H_all = nullptr)
+                 float *e_trace, float *H_trace, void *ws, hipStream_t s, float *H_all = nullptr,
+                 float *Q_all = nullptr)
 {
     constexpr int C = Shape<F, D>::C;
     constexpr int LDH = Shape<F, D>::LDH;
@@ -673,7 +675,7 @@ int forward_impl(const gnn_graph_t *g, const gnn_params_t *p, int n_iters, float
             break;
         }
         rc = run_node<F, D>(H, LDH, e_t, g, p->W3, p->b3, p->W4, p->b4, p->W1, p->b1, Hn, LDH,
-                            w.PQ, s);
+                            w.PQ, s, Q_all ? Q_all + (size_t)t * N * D : nullptr);
         if (rc) return rc;
         if (H_all) {
             H = Hn;
@@ -817,8 +819,8 @@ int gnn_segclf_forward(const gnn_graph_t *g, const gnn_params_t *p, int32_t n_it
 }
 
 int gnn_segclf_forward_train(const gnn_graph_t *g, const gnn_params_t *p, int32_t n_iters,
-                             float *e_all, float *H_all, void *workspace, size_t workspace_bytes,
-                             void *stream)
+                             float *e_all, float *H_all, float *Q_all, void *workspace,
+                             size_t workspace_bytes, void *stream)
 {
     if (!g || !p || n_iters < 0 || g->n_hits < 0 || g->n_segments < 0)
         return fail(GNN_ERR_BADARG, "gnn_segclf_forward_train: bad argument");
@@ -833,7 +835,7 @@ int gnn_segclf_forward_train(const gnn_graph_t *g, const gnn_params_t *p, int32_
     // e_trace = e_all makes every edge pass land in its row; the "final scores" copy goes to the
     // last row itself (no-op copy avoided by passing that row as e_out)
     float *last = e_all ? e_all + (size_t)n_iters * g->n_segments : nullptr;
-#define X_(F_, D_) if (p->F == F_ && p->D == D_) return forward_impl<F_, D_>(g, p, n_iters, last, e_all, nullptr, ws, s, H_all);
+#define X_(F_, D_) if (p->F == F_ && p->D == D_) return forward_impl<F_, D_>(g, p, n_iters, last, e_all, nullptr, ws, s, H_all, Q_all);
     GNN_FOR_EACH_SHAPE(X_)
 #undef X_
     return fail(GNN_ERR_UNSUPPORTED, "unreachable");
@@ -846,9 +848,9 @@ size_t gnn_backward_workspace_bytes(int64_t n_hits, int64_t n_segments, int32_t 
 }
 
 int gnn_segclf_backward(const gnn_graph_t *g, const gnn_params_t *p, int32_t n_iters,
-                        const float *e_all, const float *H_all, const float *grad_out,
-                        const gnn_grads_t *gr, void *workspace, size_t workspace_bytes,
-                        void *stream)
+                        const float *e_all, const float *H_all, const float *Q_all,
+                        const float *grad_out, const gnn_grads_t *gr, void *workspace,
+                        size_t workspace_bytes, void *stream)
 {
     if (!g || !p || !gr || n_iters < 0 || g->n_hits < 0 || g->n_segments < 0 || !workspace)
         return fail(GNN_ERR_BADARG, "gnn_segclf_backward: bad argument");
@@ -856,7 +858,7 @@ int gnn_segclf_backward(const gnn_graph_t *g, const gnn_params_t *p, int32_t n_i
         return fail(GNN_ERR_BADARG, "gnn_segclf_backward: saved tensors missing");
     if (!gr->Win || !gr->bin || !gr->W1 || !gr->b1 || !gr->W2 || !gr->b2 || !gr->W3 || !gr->b3 || !gr->W4 || !gr->b4)
         return fail(GNN_ERR_BADARG, "gnn_segclf_backward: gradient pointer missing");
-    return backward(g, p, n_iters, e_all, H_all, grad_out, gr, workspace, workspace_bytes,
+    return backward(g, p, n_iters, e_all, H_all, Q_all, grad_out, gr, workspace, workspace_bytes,
                     static_cast<hipStream_t>(stream));
 }
 

@@ -125,14 +125,14 @@ class GradBucket:
             if lay is None:
                 from .autograd import training_batch
                 batch = training_batch(model, batch, False)      # level-ordered twin: L2-local gathers
-            e_all, H_all = _lib.segclf_forward_train(batch, w, F, D, T, layout=lay)
+            e_all, H_all, Q_all = _lib.segclf_forward_train(batch, w, F, D, T, layout=lay)
             yv = y.detach().to(torch.float32).contiguous().reshape(-1)
             loss_sum, ge = _lib.bce_loss(e_all[T], yv, 1.0)
             into = [p.grad for p in self.params]
             if lay is not None:
                 _lib.segclf_backward_events(batch, lay, w, F, D, T, e_all, H_all, ge, into=into)
             else:
-                _lib.segclf_backward(batch, w, F, D, T, e_all, H_all, ge, into=into)
+                _lib.segclf_backward(batch, w, F, D, T, e_all, H_all, ge, into=into, Q_all=Q_all)
             for layer in layers:                        # d/dW of W * mask (gnn/model.py:30)
                 if layer.mask_flag:
                     layer.weight.grad.mul_(layer.mask.to(layer.weight.device))

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNN_ABI_VERSION 2
+#define GNN_ABI_VERSION 3
 
 #define GNN_ERR_UNSUPPORTED (-10001) /* (F, D) has no kernel instantiation            */
 #define GNN_ERR_BADARG      (-10002) /* null pointer, negative size, bad stride ...   */
@@ -168,11 +168,13 @@ int gnn_segclf_forward_events(const gnn_graph_t *g, const gnn_params_t *p, const
                               int32_t max_segments, int32_t n_iters, float *e_out, void *stream);
 
 /* Training forward: like gnn_segclf_forward but keeps what the backward needs - the scores of
- * every edge pass e_all [(n_iters+1), n_segments] (the last row is the model output) and the hit
- * features of every iteration H_all [(n_iters+1), n_hits, ldh] (padded rows). */
+ * every edge pass e_all [(n_iters+1), n_segments] (the last row is the model output), the hit
+ * features of every iteration H_all [(n_iters+1), n_hits, ldh] (padded rows) and, optionally, the
+ * hidden layer of every node pass Q_all [n_iters, n_hits, hidden_dim] (NULL: not kept; the backward
+ * then rebuilds it with a second walk over both segment lists). */
 int gnn_segclf_forward_train(const gnn_graph_t *g, const gnn_params_t *p, int32_t n_iters,
-                             float *e_all, float *H_all, void *workspace, size_t workspace_bytes,
-                             void *stream);
+                             float *e_all, float *H_all, float *Q_all, void *workspace,
+                             size_t workspace_bytes, void *stream);
 
 /* The same for a batch of small graphs in one launch (gnn_segclf_forward_events that also keeps
  * e_all / H_all; bit-identical to gnn_segclf_forward_train). */
@@ -198,9 +200,9 @@ size_t gnn_backward_workspace_bytes(int64_t n_hits, int64_t n_segments, int32_t 
 int gnn_bce_loss(const float *e, const float *y, int64_t n, float scale, float *loss_out,
                  float *grad_e, void *workspace, void *stream);
 int gnn_segclf_backward(const gnn_graph_t *g, const gnn_params_t *p, int32_t n_iters,
-                        const float *e_all, const float *H_all, const float *grad_out,
-                        const gnn_grads_t *grads, void *workspace, size_t workspace_bytes,
-                        void *stream);
+                        const float *e_all, const float *H_all, const float *Q_all /* or NULL */,
+                        const float *grad_out, const gnn_grads_t *grads, void *workspace,
+                        size_t workspace_bytes, void *stream);
 
 /* The same gradients for a batch of SMALL graphs (gnn/prepareMuonGraphs.py sizes) in ONE launch:
  * one workgroup per graph keeps the graph's saved rows and every intermediate in LDS (counterpart

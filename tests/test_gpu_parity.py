@@ -763,6 +763,27 @@ def test_training_on_the_level_ordered_twin(hip):
         assert err < 1e-7 + 1e-4 * a.abs().max().item(), (k, err)
 
 
+def test_backward_with_and_without_the_kept_hidden_layers(hip):
+    """gnn_segclf_forward_train keeps the node networks' hidden layers (Q_all) so that the backward
+    needs no second walk over the segment lists; a caller that did not keep them (Q_all = NULL) gets
+    the same gradients from the rebuilt sums (1e-5 of the largest entry: the sums run over records,
+    in another order)."""
+    torch.manual_seed(8)
+    g = synth.layered_graph(3000, 24000, 3, seed=17)
+    b = HitGraphBatch.from_graphs([g]).cuda()
+    from gnn_fpga_amd.model import SegmentClassifier
+    _lib = hip
+    m = SegmentClassifier(input_dim=3, hidden_dim=8, n_iters=3).cuda()
+    w = [t.detach().contiguous() for t in m.state_dict().values()]
+    e_all, H_all, Q_all = _lib.segclf_forward_train(b, w, 3, 8, 3)
+    assert Q_all.shape == (3, b.n_hits, 8) and float(Q_all.abs().max()) <= 1.0
+    go = torch.randn(b.n_segments, device="cuda") / b.n_segments
+    with_q = _lib.segclf_backward(b, w, 3, 8, 3, e_all, H_all, go, Q_all=Q_all)
+    without = _lib.segclf_backward(b, w, 3, 8, 3, e_all, H_all, go)
+    for a, c in zip(with_q, without):
+        assert (a - c).abs().max().item() <= 1e-9 + 1e-5 * c.abs().max().item()
+
+
 TOL_BF16 = 2e-3     # bf16 records and matrix-core operands (GNN_FLAG_BF16_MLP): stated separately from the
                     # fp32 path's 1e-5 (SURVEY 8(d): "1e-5 does not apply to bf16"); measured max 6e-4, mean 8e-5
 
@@ -901,6 +922,7 @@ def test_one_launch_training_forward_keeps_the_same_tensors(hip):
     b = HitGraphBatch(b.X.numpy(), src, dst, hit_ptr=b.hit_ptr, seg_ptr=b.seg_ptr).cuda()
     m = SegmentClassifier(input_dim=11, hidden_dim=8, n_iters=3).cuda()
     w = [t.detach().contiguous() for t in m.state_dict().values()]
-    e1, H1 = _lib.segclf_forward_train(b, w, 11, 8, 3)
-    e2, H2 = _lib.segclf_forward_train(b, w, 11, 8, 3, layout=b.event_layout())
+    e1, H1, Q1 = _lib.segclf_forward_train(b, w, 11, 8, 3)
+    e2, H2, Q2 = _lib.segclf_forward_train(b, w, 11, 8, 3, layout=b.event_layout())
+    assert Q1.shape == (3, b.n_hits, 8) and Q2.numel() == 0
     assert torch.equal(e1, e2) and torch.equal(H1, H2)
