@@ -701,6 +701,292 @@ __global__ __launch_bounds__(kBlock) void k_seg_bwd(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same pull with FOUR LANES PER HIT (Q_all kept by the forward).  One lane per hit reading 96-byte
+// rows touches 64 different lines per load instruction and keeps 243 registers; here a quad owns a
+// hit, lane q holds dims [q D/4, (q+1) D/4) of every vector, a record is stored so that a lane's
+// share is contiguous ([P(dl) R(dl)] x 4 | gp), a wave instruction touches 16 rows instead of 64, four
+// list entries are taken per step (indices and scores loaded one per lane, rows broadcast in the
+// quad), and a segment's ge is finished by two quad adds.  The per-hit dense tail (W^T products and
+// the outer-product sums) stays with one lane per hit in k_seg_fin, through 4D floats per hit.
+//   k_hit_bwd4  per hit (1 lane): P R Q S from H, gp from the kept q -> A, B;  gH_prev = W3c^T gp; gW3c, gb3, gW4, gb4
+//   k_seg_bwd4  per hit (4 lanes): both list walks -> G4 = [gP gQ Gout Gin];  gW2, gb2
+//   k_seg_fin   per hit (1 lane): gH_prev += W1a^T gP + W1b^T gQ + W3a^T Gout + W3b^T Gin;  gW1, gb1, gW3a, gW3b
+template <int SEL>
+__device__ __forceinline__ float quad_bcast(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), SEL * 0x55, 0xf, 0xf, true));
+}
+template <int SEL>
+__device__ __forceinline__ int quad_bcast(int x) { return __builtin_amdgcn_mov_dpp(x, SEL * 0x55, 0xf, 0xf, true); }
+__device__ __forceinline__ float quad_sum(float x)
+{
+    x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true));   // lane ^ 1
+    x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true));   // lane ^ 2
+    return x;
+}
+template <int N>
+__device__ __forceinline__ void load_vec(const float *__restrict__ p, float *v)
+{
+    if constexpr (N == 1) {
+        v[0] = p[0];
+    } else if constexpr (N == 2) {
+        const float2 a = *reinterpret_cast<const float2 *>(p);
+        v[0] = a.x; v[1] = a.y;
+    } else {
+#pragma unroll
+        for (int i = 0; i < N / 4; ++i) {
+            const float4 a = reinterpret_cast<const float4 *>(p)[i];
+            v[4 * i] = a.x; v[4 * i + 1] = a.y; v[4 * i + 2] = a.z; v[4 * i + 3] = a.w;
+        }
+    }
+}
+template <int N>
+__device__ __forceinline__ void store_vec(float *__restrict__ p, const float *v)
+{
+    if constexpr (N == 1) {
+        p[0] = v[0];
+    } else if constexpr (N == 2) {
+        *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[1]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < N / 4; ++i)
+            reinterpret_cast<float4 *>(p)[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+    }
+}
+
+template <int F, int D>
+__global__ __launch_bounds__(kBlock) void k_hit_bwd4(
+    const float *__restrict__ H, const float *__restrict__ Hn, const float *__restrict__ Qk, int ldh,
+    const float *__restrict__ W1, const float *__restrict__ b1, const float *__restrict__ W3,
+    const float *__restrict__ W4, const float *__restrict__ gHn, float *__restrict__ gH, float *__restrict__ A,
+    float *__restrict__ B, float *__restrict__ gW3, float *__restrict__ gb3, float *__restrict__ gW4,
+    float *__restrict__ gb4, int rep_stride, int64_t n_hits)
+{
+    gW3 = my_replica(gW3, rep_stride);
+    gb3 = my_replica(gb3, rep_stride);
+    gW4 = my_replica(gW4, rep_stride);
+    gb4 = my_replica(gb4, rep_stride);
+    constexpr int C = Shape<F, D>::C, LDH = Shape<F, D>::LDH, DL = D / 4;
+    __shared__ __attribute__((aligned(16))) float lds[outer_lds_floats<D, C>()];
+    const int64_t n = xcd_block() * kBlock + threadIdx.x;
+    const bool active = n < n_hits;
+    float h[C], q[D], gr[D], gp[D];
+#pragma unroll
+    for (int k = 0; k < C; ++k) h[k] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < D; ++i) q[i] = gr[i] = gp[i] = 0.0f;
+    if (active) {
+        float hp[LDH];
+        load_row4<LDH / 4>(H + n * ldh, hp);
+#pragma unroll
+        for (int k = 0; k < C; ++k) h[k] = hp[k];
+        load_row4<D / 4>(Qk + n * D, q);
+        float hn[D], gn[D];
+        load_row4<D / 4>(Hn + n * ldh, hn);
+        load_row4<D / 4>(gHn + n * ldh, gn);
+#pragma unroll
+        for (int i = 0; i < D; ++i) gr[i] = gn[i] * (1.0f - hn[i] * hn[i]);
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            float s = 0.0f;
+#pragma unroll
+            for (int i = 0; i < D; ++i) s = fmaf(W4[i * D + k], gr[i], s);
+            gp[k] = s * (1.0f - q[k] * q[k]);
+        }
+        float gh[LDH];
+#pragma unroll
+        for (int k = 0; k < LDH; ++k) gh[k] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            float s = 0.0f;
+#pragma unroll
+            for (int i = 0; i < D; ++i) s = fmaf(W3[i * 3 * C + 2 * C + k], gp[i], s);
+            gh[k] = s;
+        }
+        store_row4<LDH / 4>(gH + n * ldh, gh);                     // gHself initialises gH_prev
+        float a[3 * D], b[3 * D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            float pp = b1[i], qq = 0.0f, rr = 0.0f, ss = 0.0f;
+#pragma unroll
+            for (int k = 0; k < C; ++k) {
+                pp = fmaf(W1[i * 2 * C + k], h[k], pp);
+                qq = fmaf(W1[i * 2 * C + C + k], h[k], qq);
+                rr = fmaf(W3[i * 3 * C + k], h[k], rr);
+                ss = fmaf(W3[i * 3 * C + C + k], h[k], ss);
+            }
+            const int at = (i / DL) * 2 * DL + (i % DL);            // lane i / DL's share: [P(DL) R(DL)]
+            a[at] = pp; a[at + DL] = rr; b[at] = qq; b[at + DL] = ss;
+            a[2 * D + i] = gp[i]; b[2 * D + i] = gp[i];
+        }
+        store_row4<3 * D / 4>(A + n * 3 * D, a);
+        store_row4<3 * D / 4>(B + n * 3 * D, b);
+    }
+    accum_outer<D, C>(gp, h, active, gW3, 3 * C, 2 * C, gb3, lds);
+    accum_outer<D, D>(gr, q, active, gW4, D, 0, gb4, lds);
+}
+
+// one direction of a hit's pull: REC = the far ends' records, own_pq / own_r / own_gp the hit's own
+// shares (out list: P, R of the start hit against [Q S gp] of the end hits; in list: Q, S against [P R gp])
+template <int D, bool IN>
+__device__ __forceinline__ void quad_walk(int beg, int end, int n, int q, const int32_t *__restrict__ nbr,
+                                          const int32_t *__restrict__ eid, const float *__restrict__ e,
+                                          const float *__restrict__ REC, const float *own_pq, const float *own_r,
+                                          const float *own_gp, const float *w2, float *gZ, float *G, float *sw2)
+{
+    constexpr int DL = D / 4;
+    for (int k = beg; k < end; k += 4) {
+        const int kk = k + q;
+        const bool ok = kk < end;
+        const int nb = ok ? nbr[kk] : n;                        // (a masked entry reads the own record with score 0)
+        const float ev = ok ? e[eid[kk]] : 0.0f;
+        float pr[4][2 * DL], gv[4][DL], part[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nbj = j == 0 ? quad_bcast<0>(nb) : j == 1 ? quad_bcast<1>(nb) : j == 2 ? quad_bcast<2>(nb) : quad_bcast<3>(nb);
+            const float *r = REC + (int64_t)nbj * 3 * D;
+            load_vec<2 * DL>(r + q * 2 * DL, pr[j]);
+            load_vec<DL>(r + 2 * D + q * DL, gv[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float p = 0.0f;
+#pragma unroll
+            for (int i = 0; i < DL; ++i) {
+                p = fmaf(gv[j][i], own_r[i], p);
+                p = fmaf(own_gp[i], pr[j][DL + i], p);
+            }
+            part[j] = quad_sum(p);
+        }
+        const float ge = q == 0 ? part[0] : q == 1 ? part[1] : q == 2 ? part[2] : part[3];
+        const float gu = ge * ev * (1.0f - ev);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float guj = j == 0 ? quad_bcast<0>(gu) : j == 1 ? quad_bcast<1>(gu) : j == 2 ? quad_bcast<2>(gu) : quad_bcast<3>(gu);
+            const float evj = j == 0 ? quad_bcast<0>(ev) : j == 1 ? quad_bcast<1>(ev) : j == 2 ? quad_bcast<2>(ev) : quad_bcast<3>(ev);
+#pragma unroll
+            for (int i = 0; i < DL; ++i) {
+                const float t = tanh_f(own_pq[i] + pr[j][i]);
+                gZ[i] = fmaf(guj * w2[i], 1.0f - t * t, gZ[i]);
+                G[i] = fmaf(evj, gv[j][i], G[i]);
+                if constexpr (IN) sw2[i] = fmaf(guj, t, sw2[i]);
+            }
+            if constexpr (IN) sw2[DL] += guj;
+        }
+    }
+}
+
+constexpr int kQuadBlock = 1024;          // 256 hits per workgroup: the same partial-table rows as the 1-lane kernels
+template <int F, int D>
+__global__ __launch_bounds__(kQuadBlock) void k_seg_bwd4(
+    const float *__restrict__ A, const float *__restrict__ B, const float *__restrict__ e,
+    const int32_t *__restrict__ in_ptr, const int32_t *__restrict__ in_eid, const int32_t *__restrict__ in_nbr,
+    const int32_t *__restrict__ out_ptr, const int32_t *__restrict__ out_eid, const int32_t *__restrict__ out_nbr,
+    const float *__restrict__ W2, float *__restrict__ G4, float *__restrict__ gW2, float *__restrict__ gb2,
+    int rep_stride, int64_t n_hits)
+{
+    gW2 = my_replica(gW2, rep_stride);
+    gb2 = my_replica(gb2, rep_stride);
+    constexpr int DL = D / 4, NW = kQuadBlock / 64;
+    __shared__ float red[NW * (D + 1)];
+    const int q = threadIdx.x & 3;
+    const int64_t n = xcd_block() * (kQuadBlock / 4) + (threadIdx.x >> 2);
+    const bool active = n < n_hits;
+    float gP[DL], gQ[DL], Gout[DL], Gin[DL], sw2[DL + 1], w2[DL];
+#pragma unroll
+    for (int i = 0; i < DL; ++i) {
+        gP[i] = gQ[i] = Gout[i] = Gin[i] = sw2[i] = 0.0f;
+        w2[i] = W2[q * DL + i];
+    }
+    sw2[DL] = 0.0f;
+    if (active) {
+        float a[2 * DL], b[2 * DL], gp[DL];
+        load_vec<2 * DL>(A + n * 3 * D + q * 2 * DL, a);
+        load_vec<2 * DL>(B + n * 3 * D + q * 2 * DL, b);
+        load_vec<DL>(A + n * 3 * D + 2 * D + q * DL, gp);
+        // segments starting here (n -> d): [Q | S | gp] of the end hits
+        quad_walk<D, false>(out_ptr[n], out_ptr[n + 1], (int)n, q, out_nbr, out_eid, e, B, a, a + DL, gp, w2, gP, Gout, sw2);
+        // segments ending here (s -> n): [P | R | gp] of the start hits; the W2 / b2 sums are taken here
+        quad_walk<D, true>(in_ptr[n], in_ptr[n + 1], (int)n, q, in_nbr, in_eid, e, A, b, b + DL, gp, w2, gQ, Gin, sw2);
+        float out[4 * DL];
+#pragma unroll
+        for (int i = 0; i < DL; ++i) {
+            out[i] = gP[i]; out[DL + i] = gQ[i]; out[2 * DL + i] = Gout[i]; out[3 * DL + i] = Gin[i];
+        }
+        store_vec<4 * DL>(G4 + n * 4 * D + q * 4 * DL, out);
+    }
+    // gW2[D] | gb2: lanes with the same q across the wave, then the waves in order
+#pragma unroll
+    for (int i = 0; i <= DL; ++i) {
+        float x = sw2[i];
+#pragma unroll
+        for (int o = 32; o >= 4; o >>= 1) x += __shfl_xor(x, o, 64);
+        if ((threadIdx.x & 63) < 4) {
+            if (i < DL) red[(threadIdx.x >> 6) * (D + 1) + q * DL + i] = x;
+            else if (q == 0) red[(threadIdx.x >> 6) * (D + 1) + D] = x;
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x <= D) {
+        float x = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) x += red[w * (D + 1) + threadIdx.x];
+        *((int)threadIdx.x < D ? gW2 + threadIdx.x : gb2) += x;
+    }
+}
+
+template <int F, int D>
+__global__ __launch_bounds__(kBlock) void k_seg_fin(
+    const float *__restrict__ H, int ldh, const float *__restrict__ G4, const float *__restrict__ W1,
+    const float *__restrict__ W3, float *__restrict__ gH, float *__restrict__ gW1, float *__restrict__ gb1,
+    float *__restrict__ gW3, int rep_stride, int64_t n_hits)
+{
+    gW1 = my_replica(gW1, rep_stride);
+    gb1 = my_replica(gb1, rep_stride);
+    gW3 = my_replica(gW3, rep_stride);
+    constexpr int C = Shape<F, D>::C, LDH = Shape<F, D>::LDH, DL = D / 4;
+    __shared__ __attribute__((aligned(16))) float lds[outer_lds_floats<D, C>()];
+    const int64_t n = xcd_block() * kBlock + threadIdx.x;
+    const bool active = n < n_hits;
+    float gP[D], gQ[D], Gout[D], Gin[D], h[C];
+#pragma unroll
+    for (int i = 0; i < D; ++i) gP[i] = gQ[i] = Gout[i] = Gin[i] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < C; ++k) h[k] = 0.0f;
+    if (active) {
+        float g4[4 * D];
+        load_row4<D>(G4 + n * 4 * D, g4);
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const int at = (i / DL) * 4 * DL + (i % DL);
+            gP[i] = g4[at]; gQ[i] = g4[at + DL]; Gout[i] = g4[at + 2 * DL]; Gin[i] = g4[at + 3 * DL];
+        }
+        float hr[LDH], gh[LDH];
+        load_row4<LDH / 4>(H + n * ldh, hr);
+        load_row4<LDH / 4>(gH + n * ldh, gh);
+#pragma unroll
+        for (int k = 0; k < C; ++k) h[k] = hr[k];
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            float s = 0.0f;
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                s = fmaf(W1[i * 2 * C + k], gP[i], s);
+                s = fmaf(W1[i * 2 * C + C + k], gQ[i], s);
+                s = fmaf(W3[i * 3 * C + k], Gout[i], s);
+                s = fmaf(W3[i * 3 * C + C + k], Gin[i], s);
+            }
+            gh[k] += s;
+        }
+        store_row4<LDH / 4>(gH + n * ldh, gh);
+    }
+    accum_outer<D, C>(gP, h, active, gW1, 2 * C, 0, gb1, lds);
+    accum_outer<D, C>(gQ, h, active, gW1, 2 * C, C, nullptr, lds);
+    accum_outer<D, C>(Gout, h, active, gW3, 3 * C, 0, nullptr, lds);
+    accum_outer<D, C>(Gin, h, active, gW3, 3 * C, C, nullptr, lds);
+}
+
 // gradient w.r.t. the scores a node pass consumed: ge[j] = <gmi[d], H[s]> + <gmo[s], H[d]>, zero for
 // padded segments (the whole-model backward folds this into k_edge_bwd; the per-module entry point
 // gnn_node_bwd hands it to the caller)
@@ -800,7 +1086,7 @@ inline int64_t bwd_rows(int64_t N, int64_t E)
 }
 
 struct BwdWs {
-    float *PQ, *gu, *gHa, *gHb, *gmio, *rep, *tmp, *A, *B;
+    float *PQ, *gu, *gHa, *gHb, *gmio, *rep, *tmp, *A, *B, *G4;
     char *rep_end;
     int64_t rows;
     size_t bytes;
@@ -830,6 +1116,7 @@ BwdWs carve_bwd(char *b, int64_t N, int64_t E, int ldh, int C, int D)
     w.tmp = take((size_t)fold_chunks(w.rows) * stride);
     w.A = take((size_t)N * 3 * D);           // [P | R | gp], [Q | S | gp] of the pull-form kernels
     w.B = take((size_t)N * 3 * D);
+    w.G4 = take((size_t)N * 4 * D);           // [gP gQ Gout Gin] between k_seg_bwd4 and k_seg_fin
     w.bytes = off;
     return w;
 }
@@ -877,17 +1164,23 @@ int backward_t(const gnn_graph_t *g, const gnn_params_t *p, int T, const float *
                 const float *Hp = H_all + (size_t)(u - 1) * N * LDH;
                 const float *ep = e_all + (size_t)(u - 1) * E;
                 if (N > 0) {
+                    if (Q_all) {
+                        GNN_LAUNCH("k_hit_bwd4", (k_hit_bwd4<F, D>), grid_for(N), kBlock, s, Hp, Hu,
+                                   Q_all + (size_t)(u - 1) * N * D, LDH, p->W1, p->b1, p->W3, p->W4, gH, gHprev, w.A, w.B,
+                                   rp + GL::oW3, rp + GL::ob3, rp + GL::oW4, rp + GL::ob4, RS, N);
+                        GNN_LAUNCH("k_seg_bwd4", (k_seg_bwd4<F, D>), grid_for(N), kQuadBlock, s, w.A, w.B, ep, g->in_ptr,
+                                   g->in_eid, g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, p->W2, w.G4, rp + GL::oW2,
+                                   rp + GL::ob2, RS, N);
+                        GNN_LAUNCH("k_seg_fin", (k_seg_fin<F, D>), grid_for(N), kBlock, s, Hp, LDH, w.G4, p->W1, p->W3, gHprev,
+                                   rp + GL::oW1, rp + GL::ob1, rp + GL::oW3, RS, N);
+                        float *tmp = gH; gH = gHprev; gHprev = tmp;
+                        continue;
+                    }
                     GNN_LAUNCH("kb_prs", (kb_prs<F, D>), grid_for(N), kBlock, s, Hp, LDH, p->W1, p->b1, p->W3, w.A, w.B, N);
-                    if (Q_all)
-                        GNN_LAUNCH("k_hit_bwd", (k_hit_bwd<F, D, true>), grid_for(N), kBlock, s, Hp, Hu,
-                                   Q_all + (size_t)(u - 1) * N * D, LDH, ep, g->in_ptr, g->in_eid, g->in_nbr, g->out_ptr,
-                                   g->out_eid, g->out_nbr, p->W3, p->b3, p->W4, gH, gHprev, w.A, w.B, rp + GL::oW3,
-                                   rp + GL::ob3, rp + GL::oW4, rp + GL::ob4, RS, N);
-                    else
-                        GNN_LAUNCH("k_hit_bwd", (k_hit_bwd<F, D, false>), grid_for(N), kBlock, s, Hp, Hu, nullptr, LDH, ep,
-                                   g->in_ptr, g->in_eid, g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, p->W3, p->b3,
-                                   p->W4, gH, gHprev, w.A, w.B, rp + GL::oW3, rp + GL::ob3, rp + GL::oW4, rp + GL::ob4, RS,
-                                   N);
+                    GNN_LAUNCH("k_hit_bwd", (k_hit_bwd<F, D, false>), grid_for(N), kBlock, s, Hp, Hu, nullptr, LDH, ep,
+                               g->in_ptr, g->in_eid, g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, p->W3, p->b3,
+                               p->W4, gH, gHprev, w.A, w.B, rp + GL::oW3, rp + GL::ob3, rp + GL::oW4, rp + GL::ob4, RS,
+                               N);
                     GNN_LAUNCH("k_seg_bwd", (k_seg_bwd<F, D>), grid_for(N), kBlock, s, Hp, LDH, w.A, w.B, ep, g->in_ptr,
                                g->in_eid, g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, p->W1, p->W2, p->W3, gHprev,
                                rp + GL::oW1, rp + GL::ob1, rp + GL::oW2, rp + GL::ob2, rp + GL::oW3, RS, N);
