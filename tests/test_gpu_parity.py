@@ -763,24 +763,33 @@ def test_training_on_the_level_ordered_twin(hip):
         assert err < 1e-7 + 1e-4 * a.abs().max().item(), (k, err)
 
 
-def test_backward_with_and_without_the_kept_hidden_layers(hip):
-    """gnn_segclf_forward_train keeps the node networks' hidden layers (Q_all) so that the backward
-    needs no second walk over the segment lists; a caller that did not keep them (Q_all = NULL) gets
-    the same gradients from the rebuilt sums (1e-5 of the largest entry: the sums run over records,
-    in another order)."""
-    torch.manual_seed(8)
-    g = synth.layered_graph(3000, 24000, 3, seed=17)
-    b = HitGraphBatch.from_graphs([g]).cuda()
+@pytest.mark.parametrize("F,D,T", [(3, 8, 3), (11, 16, 2), (3, 4, 2), (11, 8, 1)])
+def test_backward_with_and_without_the_kept_hidden_layers(hip, F, D, T):
+    """gnn_segclf_forward_train keeps the node networks' hidden layers (Q_all): the backward then runs
+    its four-lanes-per-hit kernels (k_hit_bwd4 / k_seg_bwd4 / k_seg_fin) and needs no second walk over
+    the segment lists.  A caller that did not keep them (Q_all = NULL) gets the same gradients from the
+    one-lane kernels, which rebuild the sums (1e-5 of the largest entry: other summation orders).
+    Ragged lists (lengths not multiples of the quad's 4 entries per step), hits without segments and
+    padded segments included; the four-lane route is bit-reproducible."""
     from gnn_fpga_amd.model import SegmentClassifier
-    _lib = hip
-    m = SegmentClassifier(input_dim=3, hidden_dim=8, n_iters=3).cuda()
+    torch.manual_seed(8)
+    g = synth.layered_graph(3000, 24000, F, seed=17)
+    b = HitGraphBatch.from_graphs([g, synth.layered_graph(40, 31, F, seed=18)])
+    src, dst = b.src.numpy().copy(), b.dst.numpy().copy()
+    src[5::11] = -1
+    dst[5::11] = -1
+    b = HitGraphBatch(b.X.numpy(), src, dst, hit_ptr=b.hit_ptr, seg_ptr=b.seg_ptr).cuda()
+    m = SegmentClassifier(input_dim=F, hidden_dim=D, n_iters=T).cuda()
     w = [t.detach().contiguous() for t in m.state_dict().values()]
-    e_all, H_all, Q_all = _lib.segclf_forward_train(b, w, 3, 8, 3)
-    assert Q_all.shape == (3, b.n_hits, 8) and float(Q_all.abs().max()) <= 1.0
+    e_all, H_all, Q_all = hip.segclf_forward_train(b, w, F, D, T)
+    assert Q_all.shape == (T, b.n_hits, D) and float(Q_all.abs().max()) <= 1.0
     go = torch.randn(b.n_segments, device="cuda") / b.n_segments
-    with_q = _lib.segclf_backward(b, w, 3, 8, 3, e_all, H_all, go, Q_all=Q_all)
-    without = _lib.segclf_backward(b, w, 3, 8, 3, e_all, H_all, go)
-    for a, c in zip(with_q, without):
+    with_q = hip.segclf_backward(b, w, F, D, T, e_all, H_all, go, Q_all=Q_all)
+    again = hip.segclf_backward(b, w, F, D, T, e_all, H_all, go, Q_all=Q_all)
+    without = hip.segclf_backward(b, w, F, D, T, e_all, H_all, go)
+    for a, a2, c in zip(with_q, again, without):
+        assert torch.equal(a, a2)
+        assert float(c.abs().max()) > 0
         assert (a - c).abs().max().item() <= 1e-9 + 1e-5 * c.abs().max().item()
 
 
