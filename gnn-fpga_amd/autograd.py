@@ -24,13 +24,17 @@ class _SegClf(torch.autograd.Function):
         e_all, H_all, Q_all = _lib.segclf_forward_train(batch, w, F, D, n_iters, layout=lay)
         ctx.batch, ctx.F, ctx.D, ctx.n_iters, ctx.use_events = batch, F, D, n_iters, use_events
         ctx.save_for_backward(e_all, H_all, Q_all, *w)
-        return e_all[n_iters].clone()
+        rank = getattr(batch, "seg_rank", None)          # level-ordered twin: back to the caller's segment order
+        return e_all[n_iters].clone() if rank is None else e_all[n_iters].index_select(0, rank)
 
     @staticmethod
     def backward(ctx, grad_out):
         e_all, H_all, Q_all, *w = ctx.saved_tensors
         go = grad_out.to(torch.float32).contiguous()
         b = ctx.batch
+        order = getattr(b, "seg_order", None)
+        if order is not None:
+            go = go.index_select(0, order)
         # small graphs (the reference's muon events): the whole backward in one launch
         lay = b.event_layout() if (ctx.use_events and b.n_graphs > 0) else None
         if lay is not None and _lib.events_backward_supported(ctx.F, ctx.D, lay.max_hits, lay.max_segments):

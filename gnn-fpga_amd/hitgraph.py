@@ -153,8 +153,9 @@ class HitGraphBatch:
         """The same batch with its hits renumbered in PLAN order - (graph, detector level), tiles,
         degree.  In that order the neighbours of consecutive hits lie in narrow id ranges, which makes
         the training kernels' record gathers L2-local (c3 x 32 training step 1.68 -> 1.46 ms); scores
-        stay per segment in the caller's order and weight gradients do not depend on hit numbering,
-        so the twin is a drop-in for the training forward / backward.  Built once per batch (one plan
+        are handed back per segment in the caller's order (the twin's own segments are sorted by end
+        hit: `seg_order` / `seg_rank`) and weight gradients do not depend on numbering, so the twin is
+        a drop-in for the training forward / backward.  Built once per batch (one plan
         + two GPU sorts for its CSRs) and cached; returns self when there is nothing to gain (CPU
         batch, no segments, no plan for this shape)."""
         twin = getattr(self, "_twin", None)
@@ -176,8 +177,21 @@ class HitGraphBatch:
         t = HitGraphBatch.__new__(HitGraphBatch)
         t.__dict__.update({k: v for k, v in self.__dict__.items() if not k.startswith("_")})
         t.X = self.X[order].contiguous()
-        t.src = torch.where(src >= 0, rank[src.clamp_min(0)], src).to(torch.int32)
-        t.dst = torch.where(dst >= 0, rank[dst.clamp_min(0)], dst).to(torch.int32)
+        ts = torch.where(src >= 0, rank[src.clamp_min(0)], src)
+        td = torch.where(dst >= 0, rank[dst.clamp_min(0)], dst)
+        # segments sorted by (end hit, start hit), padded ones last: the scores of a hit's incoming
+        # segments become contiguous and the edge passes gather nearly sequentially (c3 x 32 training
+        # step 1.15 -> 1.02 ms).  seg_order[k] = caller's index of the twin's segment k; the autograd
+        # function hands scores back (and takes their gradient) in the caller's order.
+        key = torch.where(ts >= 0, td * (self.n_hits + 1) + ts, torch.full_like(ts, 2 ** 62))
+        seg_order = torch.argsort(key, stable=True)
+        t.src = ts[seg_order].to(torch.int32).contiguous()
+        t.dst = td[seg_order].to(torch.int32).contiguous()
+        t.seg_order = seg_order
+        t.seg_rank = torch.empty_like(seg_order)
+        t.seg_rank[seg_order] = torch.arange(self.n_segments, dtype=torch.int64, device=dev)
+        if getattr(self, "y", None) is not None and torch.is_tensor(self.y) and self.y.numel() == self.n_segments:
+            t.y = self.y.to(dev)[seg_order]
         t._csr = None
         t._src_host = t._dst_host = None
         t._gstruct = None

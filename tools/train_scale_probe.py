@@ -37,5 +37,16 @@ def timeit(fn, n):
 
 tf = timeit(fwd_only, steps)
 ts = timeit(step, steps)
-print("c3 x %d graphs (%d segments): inference forward %.3f ms (%.3g seg/s); training step %.3f ms (%.3g seg/s), loss %.4f"
-      % (G, batch.n_segments, tf * 1e3, batch.n_segments / tf, ts * 1e3, batch.n_segments / ts, float(step())))
+
+from gnn_fpga_amd import shard
+bucket = shard.GradBucket(m.parameters())
+def direct():                       # no autograd graph: the backward adds straight into the bucket's views
+    bucket.zero()
+    loss = bucket.step(m, batch, y)
+    opt.step()
+    return loss
+td = timeit(direct, steps)
+print("c3 x %d graphs (%d segments): inference forward %.3f ms (%.3g seg/s); training step %.3f ms (%.3g seg/s), "
+      "GradBucket.step %.3f ms (%.3g seg/s), loss %.4f"
+      % (G, batch.n_segments, tf * 1e3, batch.n_segments / tf, ts * 1e3, batch.n_segments / ts,
+         td * 1e3, batch.n_segments / td, float(step())))
