@@ -512,7 +512,7 @@ def bce_loss(e, y, scale, want_grad=True):
     dev = e.device
     loss = torch.empty(1, dtype=torch.float32, device=dev)
     grad = torch.empty(n, dtype=torch.float32, device=dev) if want_grad else None
-    ws = torch.empty(256, dtype=torch.float32, device=dev)          # GNN_BCE_WORKSPACE_BYTES
+    ws = torch.empty(1024, dtype=torch.float32, device=dev)         # GNN_BCE_WORKSPACE_BYTES
     with _on(e) as st:
         _check(load().gnn_bce_loss(_dev(e, torch.float32, "scores"), _dev(y, torch.float32, "targets"), n,
                                    float(scale), loss.data_ptr(), grad.data_ptr() if want_grad else None,

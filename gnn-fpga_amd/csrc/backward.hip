@@ -1036,8 +1036,14 @@ __global__ __launch_bounds__(kBlock) void k_grad_fold1(const float *__restrict__
     if (i >= G::total) return;
     const int64_t r0 = (int64_t)blockIdx.y * kFoldChunk;
     const int64_t r1 = r0 + kFoldChunk < n_rows ? r0 + kFoldChunk : n_rows;
+    // all 32 loads in flight, then the adds in row order (one dependent load per add was 61 us
+    // for 3 MB of partial rows)
+    float v[kFoldChunk];
+#pragma unroll
+    for (int k = 0; k < kFoldChunk; ++k) v[k] = r0 + k < r1 ? rep[(r0 + k) * G::stride + i] : 0.0f;
     float sum = 0.0f;
-    for (int64_t r = r0; r < r1; ++r) sum += rep[r * G::stride + i];
+#pragma unroll
+    for (int k = 0; k < kFoldChunk; ++k) sum += v[k];
     tmp[(int64_t)blockIdx.y * G::stride + i] = sum;
 }
 
@@ -1672,7 +1678,7 @@ int backward_events_t(const gnn_graph_t *g, const gnn_params_t *p, const int32_t
 // torch.nn.BCELoss semantics (the loss of gnn/estimator.py:57): logs clamped at -100,
 // d/de = (e - y) / max(e (1 - e), 1e-12).  Every workgroup sums a fixed set of elements in a fixed
 // order and writes one partial; k_bce_final adds the partials in index order: deterministic.
-constexpr int kBceBlocks = 256;
+constexpr int kBceBlocks = 1024;          // 4 workgroups per CU (256 left one wave per SIMD: 40 us at 3.2 M segments)
 
 __global__ __launch_bounds__(kBlock) void k_bce(const float *__restrict__ e, const float *__restrict__ y,
                                                 int64_t n, float scale, float *__restrict__ grad_e,
@@ -1695,14 +1701,20 @@ __global__ __launch_bounds__(kBlock) void k_bce(const float *__restrict__ e, con
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
+// lane l adds partials 16 l .. 16 l + 15 in index order, the 64 lane sums meet in a fixed butterfly
 __global__ __launch_bounds__(64) void k_bce_final(const float *__restrict__ partial, int n_partial,
                                                   float scale, float *__restrict__ loss)
 {
-    if (threadIdx.x == 0) {
-        float s = 0.0f;
-        for (int i = 0; i < n_partial; ++i) s += partial[i];
-        loss[0] = s * scale;
+    static_assert(kBceBlocks == 64 * 16, "one wavefront folds all partials");
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int k = (int)threadIdx.x * 16 + i;
+        s += k < n_partial ? partial[k] : 0.0f;
     }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
+    if (threadIdx.x == 0) loss[0] = s * scale;
 }
 
 #define BWD_FOR_EACH_SHAPE(X_) \

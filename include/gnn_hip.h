@@ -196,7 +196,7 @@ size_t gnn_backward_workspace_bytes(int64_t n_hits, int64_t n_segments, int32_t 
  * scale = 1/n for the reference's "mean" reduction (n counts padded segments too, like the
  * reference's mean over B x E_max), 1 for "sum".  Same clamps as torch; deterministic (fixed
  * summation order).  workspace: GNN_BCE_WORKSPACE_BYTES of device scratch. */
-#define GNN_BCE_WORKSPACE_BYTES 1024
+#define GNN_BCE_WORKSPACE_BYTES 4096
 int gnn_bce_loss(const float *e, const float *y, int64_t n, float scale, float *loss_out,
                  float *grad_e, void *workspace, void *stream);
 int gnn_segclf_backward(const gnn_graph_t *g, const gnn_params_t *p, int32_t n_iters,
