@@ -795,6 +795,173 @@ __device__ __forceinline__ void mfma_records(const bf16x8_t *Tm, const float *bm
 }
 
 // ---------------------------------------------------------------------------------------------
+// the same tail in EXACT fp32 (the default for hidden_dim 32 / 64): v_mfma_f32_16x16x4_f32
+// ---------------------------------------------------------------------------------------------
+// The fp32 vector form of this tail reads 1600 16-byte weight pieces from LDS per hit and lane
+// (0.5 ms of LDS time per iteration at c5 x 8).  v_mfma_f32_16x16x4_f32 is a k-ordered chain of
+// fp32 fmas - no operand is rounded - so the same products run on the matrix cores within the fp32
+// path's 1e-5: lane l supplies ONE weight (row l & 15, k-slot l >> 4) and ONE activation (hit l & 15,
+// k-slot l >> 4) per instruction and receives rows 4 (l >> 4) .. + 3.  With k-step s <-> features
+// 16 (s / 4) + 4 g + s % 4 (g = l >> 4) a lane's B operand of step s is output r = s % 4 of tile s / 4
+// of the previous product: the chain needs no data movement and no packing at all.  Records are fp32
+// rows in k_iter_w's position order ([P(DL) R(DL)] per lane of a hit's 16).
+template <int F, int D>
+struct BX {                      // fp32 fragment layout, in floats
+    static_assert(D % 32 == 0 && F <= 4, "exact matrix-core path: D = 32 or 64, X in one k-step");
+    static constexpr int NT1 = D / 16, KS1 = D / 4;             // W4: tiles, k-steps
+    static constexpr int KS2 = D / 4 + 1;                       // records: hn steps + the X step
+    static constexpr int NT2N = 5 * D / 16, NT2L = 2 * D / 16;
+    static constexpr int o_t4 = 0;                              // [NT1][KS1][64 lanes]
+    static constexpr int o_tmn = o_t4 + NT1 * KS1 * 64;         // [NT2N][KS2][64]
+    static constexpr int o_tml = o_tmn + NT2N * KS2 * 64;       // [NT2L][KS2][64]
+    static constexpr int o_b4 = o_tml + NT2L * KS2 * 64;        // [D]
+    static constexpr int o_bmn = o_b4 + D;                      // [5D], output order
+    static constexpr int o_bml = o_bmn + 5 * D;                 // [2D]
+    static constexpr int total = o_bml + 2 * D;
+    template <bool LAST> static constexpr int tm_words() { return (LAST ? NT2L : NT2N) * KS2 * 64; }
+    template <bool LAST> static constexpr int lds_words() { return NT1 * KS1 * 64 + tm_words<LAST>() + D + (LAST ? 2 : 5) * D; }
+    static constexpr int tr_stride = D + 4;
+    static constexpr int kidx(int s, int g) { return 16 * (s / 4) + 4 * g + s % 4; }
+};
+
+template <int F, int D>
+__global__ __launch_bounds__(256) void k_pack32(gnn_params_t p, float *__restrict__ tf,
+                                                float *PRa, float *PRb, float *QSa, float *QSb,
+                                                int64_t n_pad, int xp)
+{
+    using B = BX<F, D>;
+    if (blockIdx.x == 0 && threadIdx.x < 2 * D) {       // fp32 NULL records in k_iter_w's row order
+        constexpr int DL = D / 16;
+        const int t = threadIdx.x, blk = t / (2 * DL), w = t % (2 * DL);
+        const bool is_p = w < DL;
+        float pv = is_p ? kTwoLog2e * p.b1[blk * DL + w] : 0.0f;
+        if (xp && is_p) pv = __builtin_amdgcn_exp2f(pv);
+        const float qv = (xp && is_p) ? 1.0f : 0.0f;
+        PRa[n_pad * 2 * D + t] = PRb[n_pad * 2 * D + t] = pv;
+        QSa[n_pad * 2 * D + t] = QSb[n_pad * 2 * D + t] = qv;
+    }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < B::o_b4; i += gridDim.x * 256) {
+        const int l = i & 63, g = l >> 4, frag = i >> 6;
+        float v;
+        if (i < B::o_tmn) {                                       // W4
+            const int T = frag / B::KS1, st = frag % B::KS1;
+            v = p.W4[(16 * T + (l & 15)) * D + B::kidx(st, g)];
+        } else {
+            const bool last = i >= B::o_tml;
+            const int fr = frag - (last ? B::o_tml : B::o_tmn) / 64;
+            const int T = fr / B::KS2, st = fr % B::KS2, o = 16 * T + (l & 15);
+            const int k = st < B::KS1 ? B::kidx(st, g) : (g < F ? D + g : -1);
+            v = k < 0 ? 0.0f : record_weight<F, D>(p, last, o, k, false);
+        }
+        tf[i] = v;
+    }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 8 * D; i += gridDim.x * 256) {
+        float v;
+        if (i < D) v = p.b4[i];
+        else if (i < 6 * D) v = record_weight<F, D>(p, false, i - D, 0, true);
+        else v = record_weight<F, D>(p, true, i - 6 * D, 0, true);
+        tf[B::o_b4 + i] = v;
+    }
+}
+
+// records = Wm [hl | x] + bias from this lane's features h[t][r] (feature 16 t + 4 g + r of hit
+// lane & 15) and its X slot xb; record tiles T0, T0 + TS, ... only
+template <int F, int D, bool LAST, bool XP>
+__device__ __forceinline__ void mfma_records_x(const float *Tm, const float *bm, const float (*h)[4], float xb,
+                                               int lane, int64_t n0, float *__restrict__ PRn,
+                                               float *__restrict__ QSn, float *__restrict__ U,
+                                               float *__restrict__ Pc, float *__restrict__ Qc, int T0 = 0, int TS = 1)
+{
+    using B = BX<F, D>;
+    constexpr int KS1 = B::KS1, KS2 = B::KS2, NT2 = LAST ? B::NT2L : B::NT2N;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const int hit = lane & 15, g = lane >> 4;
+    const int64_t n = n0 + hit;
+#pragma unroll
+    for (int T = 0; T < NT2; ++T) {
+        if (TS != 1 && (T % 4) != T0) continue;                    // (TS is 1 or 4; wave-uniform)
+        f4v c = *reinterpret_cast<const f4v *>(bm + 16 * T + 4 * g);
+#pragma unroll
+        for (int st = 0; st < KS1; ++st)
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(Tm[(T * KS2 + st) * 64 + lane], h[st / 4][st % 4], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(Tm[(T * KS2 + KS1) * 64 + lane], xb, c, 0, 0, 0);
+        const int o = 16 * T + 4 * g;                              // first of this lane's 4 outputs
+        float *dst;
+        bool expo, expo_half = false;                              // P / Q positions: 2^x in XP mode
+        if constexpr (LAST) {
+            dst = (o < D ? Pc + n * D + o : Qc + n * D + (o - D));
+            expo = true;
+        } else if (o >= 4 * D) {
+            dst = U + n * D + (o - 4 * D);
+            expo = false;
+        } else {
+            dst = (o < 2 * D ? PRn + n * 2 * D + o : QSn + n * 2 * D + (o - 2 * D));
+            constexpr int DL = D / 16;
+            expo = (o % (2 * DL)) < DL;
+            expo_half = DL == 2;
+        }
+        if (XP && expo) {
+            c.x = __builtin_amdgcn_exp2f(c.x); c.y = __builtin_amdgcn_exp2f(c.y);
+            if (!expo_half) { c.z = __builtin_amdgcn_exp2f(c.z); c.w = __builtin_amdgcn_exp2f(c.w); }
+        }
+        *reinterpret_cast<f4v *>(dst) = c;
+    }
+}
+
+// Hit update of a TEAM's slice, stage 1: tr[hit][0 .. D) = q = tanh(acc) -> this wave's share of
+// hl = tanh(W4 q + b4) (tiles T0, T0 + 4, ..) into th[hit][16 T + 4 g ..].  The four waves of a team
+// split the D / 16 tiles (every wave doing all of them was 64 of 149 MFMAs per wave at D = 64).
+template <int F, int D, bool LAST>
+__device__ __forceinline__ void mfma_hidden_x(const float *tf, const float *tr, float *th, int lane, int T0)
+{
+    using B = BX<F, D>;
+    constexpr int NT1 = B::NT1, KS1 = B::KS1;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const float *T4 = tf, *b4 = tf + NT1 * KS1 * 64 + B::template tm_words<LAST>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int hit = lane & 15, g = lane >> 4;
+    float v[NT1][4];
+#pragma unroll
+    for (int t = 0; t < NT1; ++t) {
+        const f4v r = *reinterpret_cast<const f4v *>(tr + hit * B::tr_stride + 16 * t + 4 * g);
+        v[t][0] = r.x; v[t][1] = r.y; v[t][2] = r.z; v[t][3] = r.w;
+    }
+#pragma unroll
+    for (int T = 0; T < NT1; ++T) {
+        if ((T & 3) != T0) continue;                              // (wave-uniform)
+        f4v c = *reinterpret_cast<const f4v *>(b4 + 16 * T + 4 * g);
+#pragma unroll
+        for (int st = 0; st < KS1; ++st)
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(T4[(T * KS1 + st) * 64 + lane], v[st / 4][st % 4], c, 0, 0, 0);
+        *reinterpret_cast<f4v *>(th + hit * B::tr_stride + 16 * T + 4 * g) =
+            f4v{tanh_f(c.x), tanh_f(c.y), tanh_f(c.z), tanh_f(c.w)};
+    }
+}
+
+// stage 2 (after a barrier): all of hl from th, X from tr, this wave's quarter of the record tiles
+template <int F, int D, bool LAST, bool XP>
+__device__ __forceinline__ void mfma_tail_scratch_x(const float *tf, const float *tr, const float *th, int lane,
+                                                    int64_t n0, float *__restrict__ PRn, float *__restrict__ QSn,
+                                                    float *__restrict__ U, float *__restrict__ Pc,
+                                                    float *__restrict__ Qc, int T0, int TS)
+{
+    using B = BX<F, D>;
+    constexpr int NT1 = B::NT1, KS1 = B::KS1;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const float *Tm = tf + NT1 * KS1 * 64;
+    const float *bm = Tm + B::template tm_words<LAST>() + D;
+    const int hit = lane & 15, g = lane >> 4;
+    float h[NT1][4];
+#pragma unroll
+    for (int t = 0; t < NT1; ++t) {
+        const f4v r = *reinterpret_cast<const f4v *>(th + hit * B::tr_stride + 16 * t + 4 * g);
+        h[t][0] = r.x; h[t][1] = r.y; h[t][2] = r.z; h[t][3] = r.w;
+    }
+    const float xb = g < F ? tr[hit * B::tr_stride + D + (g < F ? g : 0)] : 0.0f;
+    mfma_records_x<F, D, LAST, XP>(Tm, bm, h, xb, lane, n0, PRn, QSn, U, Pc, Qc, T0, TS);
+}
+
+// ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
 // input network (model.py:144-146) + records of iteration 0.  4 lanes per hit, over the padded
@@ -856,6 +1023,58 @@ __global__ __launch_bounds__(256) void k_input4_bf(const float *__restrict__ X,
         // first hit of this wave's 16 (n is this lane's hit in the 4-lanes-per-hit layout)
         const int64_t n0 = n - (lane >> 2);
         mfma_records<F, D, LAST, XP>(Tm, bm, v, xb, lane, n0, PRn, QSn, U, Pc, Qc);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // scratch is rewritten next round
+    }
+}
+
+// the same with the exact fp32 products (BX / k_pack32)
+template <int F, int D, bool LAST, bool XP>
+__global__ __launch_bounds__(256) void k_input4_x(const float *__restrict__ X,
+                                                  const float *__restrict__ table,
+                                                  const float *__restrict__ tfg,
+                                                  float *__restrict__ PRn, float *__restrict__ QSn,
+                                                  float *__restrict__ U, float *__restrict__ Pc,
+                                                  float *__restrict__ Qc, int64_t n_pad)
+{
+    using L = TL<F, D>;
+    using B = BX<F, D>;
+    constexpr int d4 = L::d4, NT1 = B::NT1;
+    constexpr int nm = B::template tm_words<LAST>(), nb = (LAST ? 2 : 5) * D;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float smem_inx[];
+    float *tb = smem_inx;                                           // [Tm | bm]
+    for (int i = threadIdx.x; i < nm; i += 256) tb[i] = tfg[(LAST ? B::o_tml : B::o_tmn) + i];
+    for (int i = threadIdx.x; i < nb; i += 256) tb[nm + i] = tfg[(LAST ? B::o_bml : B::o_bmn) + i];
+    __syncthreads();
+    float *tr = smem_inx + nm + nb + (threadIdx.x >> 6) * 16 * B::tr_stride;
+    const int lane = threadIdx.x & 63, q = lane & 3;
+    for (int64_t n = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 2; n < n_pad;
+         n += (int64_t)gridDim.x * 64) {
+        float x[F], hl[d4];
+#pragma unroll
+        for (int k = 0; k < F; ++k) x[k] = X[n * F + k];
+        role_gemv<d4, 0, F, false>(table + q * L::stride + L::o_in, x, x, hl);   // in-MLP, fp32
+        {
+            const int hit = lane >> 2;
+#pragma unroll
+            for (int i = 0; i < d4; i += 4)
+                *reinterpret_cast<f4v *>(tr + hit * B::tr_stride + q * d4 + i) =
+                    f4v{tanh_f(hl[i]), tanh_f(hl[i + 1]), tanh_f(hl[i + 2]), tanh_f(hl[i + 3])};
+            if (q == 0)
+#pragma unroll
+                for (int k = 0; k < F; ++k) tr[hit * B::tr_stride + D + k] = x[k];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int hit = lane & 15, g = lane >> 4;
+        float h[NT1][4];
+#pragma unroll
+        for (int t = 0; t < NT1; ++t) {
+            const f4v r = *reinterpret_cast<const f4v *>(tr + hit * B::tr_stride + 16 * t + 4 * g);
+            h[t][0] = r.x; h[t][1] = r.y; h[t][2] = r.z; h[t][3] = r.w;
+        }
+        const float xb = g < F ? tr[hit * B::tr_stride + D + (g < F ? g : 0)] : 0.0f;
+        const int64_t n0 = n - (lane >> 2);
+        mfma_records_x<F, D, LAST, XP>(tb, tb + nm, h, xb, lane, n0, PRn, QSn, U, Pc, Qc);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // scratch is rewritten next round
     }
 }
@@ -1579,37 +1798,55 @@ __device__ __forceinline__ float dpp_row(float v)     // row_ror:n etc.: all 16 
 template <int DL> struct PieceW;
 template <> struct PieceW<4> {
     uint4 w;
-    __device__ __forceinline__ void load(const unsigned *a) { w = *reinterpret_cast<const uint4 *>(a); }
+    __device__ __forceinline__ void load(const void *a) { w = *reinterpret_cast<const uint4 *>(a); }
     __device__ __forceinline__ void first(float *f) const { f[0] = bf_lo(w.x); f[1] = bf_hi(w.x); f[2] = bf_lo(w.y); f[3] = bf_hi(w.y); }
     __device__ __forceinline__ void second(float *f) const { f[0] = bf_lo(w.z); f[1] = bf_hi(w.z); f[2] = bf_lo(w.w); f[3] = bf_hi(w.w); }
 };
 template <> struct PieceW<2> {
     uint2 w;
-    __device__ __forceinline__ void load(const unsigned *a) { w = *reinterpret_cast<const uint2 *>(a); }
+    __device__ __forceinline__ void load(const void *a) { w = *reinterpret_cast<const uint2 *>(a); }
     __device__ __forceinline__ void first(float *f) const { f[0] = bf_lo(w.x); f[1] = bf_hi(w.x); }
     __device__ __forceinline__ void second(float *f) const { f[0] = bf_lo(w.y); f[1] = bf_hi(w.y); }
 };
+// the same pieces of fp32 rows (exact mode): 32 bytes at D = 64, 16 at D = 32
+template <int DL> struct PieceX;
+template <> struct PieceX<4> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const void *p)
+    {
+        a = reinterpret_cast<const float4 *>(p)[0];
+        b = reinterpret_cast<const float4 *>(p)[1];
+    }
+    __device__ __forceinline__ void first(float *f) const { f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; }
+    __device__ __forceinline__ void second(float *f) const { f[0] = b.x; f[1] = b.y; f[2] = b.z; f[3] = b.w; }
+};
+template <> struct PieceX<2> {
+    float4 a;
+    __device__ __forceinline__ void load(const void *p) { a = *reinterpret_cast<const float4 *>(p); }
+    __device__ __forceinline__ void first(float *f) const { f[0] = a.x; f[1] = a.y; }
+    __device__ __forceinline__ void second(float *f) const { f[0] = a.z; f[1] = a.w; }
+};
 
-template <int D>
+template <int D, bool EX = false>
 struct RecW {                   // one step group (4 list steps): this lane's piece of each of the 4 records
     static constexpr int DL = D / 16;
-    PieceW<DL> r[4];
+    static constexpr unsigned row_bytes = (EX ? 8 : 4) * D;      // 2D fp32 or 2D bf16
+    std::conditional_t<EX, PieceX<DL>, PieceW<DL>> r[4];
     // 32-bit byte offsets off the wave-uniform table base (one v_lshl_or / v_mad per address instead
     // of a 64-bit multiply-add; the host checks that the table is below 4 GB)
-    __device__ __forceinline__ void read(int cur, const unsigned *__restrict__ REC, unsigned lane_off)
+    __device__ __forceinline__ void read(int cur, const void *__restrict__ REC, unsigned lane_off)
     {
         const int nb[4] = {quad_bcast_i<0>(cur), quad_bcast_i<1>(cur), quad_bcast_i<2>(cur), quad_bcast_i<3>(cur)};
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            r[j].load(reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(REC) +
-                                                         ((unsigned)nb[j] * (unsigned)(4 * D) + lane_off)));
+            r[j].load(reinterpret_cast<const char *>(REC) + ((unsigned)nb[j] * row_bytes + lane_off));
     }
 };
 
 // score the 4 segments of a group for the 4 hits of this wave pass and add their weighted R / S;
 // dimension pairs run on packed fp32 (v_pk_fma_f32 / v_pk_mul_f32: two lanes of math per issue slot)
-template <int D, bool XP>
-__device__ __forceinline__ void score_w(const RecW<D> &g, const float *own, const float *w2, float b2, int p,
+template <int D, bool XP, bool EX = false>
+__device__ __forceinline__ void score_w(const RecW<D, EX> &g, const float *own, const float *w2, float b2, int p,
                                         float *acc)
 {
     constexpr int DL = D / 16;
@@ -1664,37 +1901,37 @@ __device__ __forceinline__ void score_w(const RecW<D> &g, const float *own, cons
 
 // walk one hit's list (all 16 lanes of the hit together); `lst` = nbr + the slice's list base
 // (wave-uniform), `i16` the hit's index in the slice; two record groups in flight
-template <int D, bool XP>
+template <int D, bool XP, bool EX = false>
 __device__ __forceinline__ void sweep_w(const int32_t *__restrict__ lst, int i16, int len, int null_idx,
-                                        const unsigned *__restrict__ REC, int p, const float *own, const float *w2,
+                                        const void *__restrict__ REC, int p, const float *own, const float *w2,
                                         float b2, float *acc)
 {
     if (len <= 0) return;
     constexpr int DL = D / 16;
     const int ng = (len + 3) >> 2;
-    const unsigned lane_off = (unsigned)(4 * DL * p);
+    const unsigned lane_off = (unsigned)((EX ? 8 : 4) * DL * p);
     const unsigned st_off = (unsigned)((SLICE * (p & 3) + i16) * 4);      // byte offset of step (p & 3)
     auto index_of = [&](int c) {               // lane p reads step 4c + (p & 3); quads broadcast it
         const int cur = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(lst) +
                                                              ((unsigned)(c * 4 * SLICE * 4) + st_off));
         return 4 * c + (p & 3) < len ? cur : null_idx;   // (up to 3 steps past the end: plan.py pads the arrays)
     };
-    RecW<D> a, b;
+    RecW<D, EX> a, b;
     int ia = index_of(0), ib = ng > 1 ? index_of(1) : 0;
     a.read(ia, REC, lane_off);
     for (int c = 0; c < ng; c += 2) {
         if (c + 1 < ng) b.read(ib, REC, lane_off);
         if (c + 2 < ng) ia = index_of(c + 2);
-        score_w<D, XP>(a, own, w2, b2, p, acc);
+        score_w<D, XP, EX>(a, own, w2, b2, p, acc);
         if (c + 1 < ng) {
             if (c + 2 < ng) a.read(ia, REC, lane_off);
             if (c + 3 < ng) ib = index_of(c + 3);
-            score_w<D, XP>(b, own, w2, b2, p, acc);
+            score_w<D, XP, EX>(b, own, w2, b2, p, acc);
         }
     }
 }
 
-template <int F, int D, bool LAST, bool XP>
+template <int F, int D, bool LAST, bool XP, bool EX = false>
 __global__ __launch_bounds__(1024) void k_iter_w(
     const float *__restrict__ X, const float *__restrict__ table, const unsigned *__restrict__ t16,
     const int32_t *__restrict__ tiles, const int32_t *__restrict__ in_off, const int32_t *__restrict__ in_nbr,
@@ -1703,13 +1940,13 @@ __global__ __launch_bounds__(1024) void k_iter_w(
     float *__restrict__ Pc, float *__restrict__ Qc, int64_t n_pad, int tiles_per_xcd, int n_tiles)
 {
     using L = TL<F, D>;
-    using B = BL<F, D>;
+    using B = std::conditional_t<EX, BX<F, D>, BL<F, D>>;      // EX: exact fp32 fragments and fp32 record rows
     static_assert(D % 32 == 0, "16 lanes x 4 dims per hit, matrix-core tail");
     (void)tiles; (void)tiles_per_xcd; (void)n_tiles;   // (the walk is over slices; tiles only order them)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned *tb = reinterpret_cast<unsigned *>(smem);
     {
-        constexpr int n1 = B::NT1 * B::KS1 * 256, nm = B::template tm_words<LAST>();
+        constexpr int n1 = B::NT1 * B::KS1 * (EX ? 64 : 256), nm = B::template tm_words<LAST>();
         for (int i = threadIdx.x; i < n1; i += 1024) tb[i] = t16[B::o_t4 + i];
         for (int i = threadIdx.x; i < nm; i += 1024) tb[n1 + i] = t16[(LAST ? B::o_tml : B::o_tmn) + i];
         for (int i = threadIdx.x; i < D; i += 1024) tb[n1 + nm + i] = t16[B::o_b4 + i];
@@ -1752,14 +1989,15 @@ __global__ __launch_bounds__(1024) void k_iter_w(
                 const int64_t n = (int64_t)sl * SLICE + i16;
                 float acc[DL], ownQ[DL], ownP[DL];
                 load_vec<DL>(U + n * D + DL * p, acc);
-                PieceW<DL> qw, pw;
-                qw.load(QS + n * D + DL * p);
-                pw.load(PR + n * D + DL * p);
+                std::conditional_t<EX, PieceX<DL>, PieceW<DL>> qw, pw;
+                constexpr int WPR = EX ? 2 * D : D, WPL = EX ? 2 * DL : DL;   // 4-byte words per row / per lane piece
+                qw.load(QS + n * WPR + WPL * p);
+                pw.load(PR + n * WPR + WPL * p);
                 qw.first(ownQ);
                 pw.first(ownP);
                 // segments ending here: P[start] with own Q, adds e R[start]; then starting here
-                sweep_w<D, XP>(in_nbr + ib, i16, il, (int)n_pad, PR, p, ownQ, w2, b2, acc);
-                sweep_w<D, XP>(out_nbr + ob, i16, ol, (int)n_pad, QS, p, ownP, w2, b2, acc);
+                sweep_w<D, XP, EX>(in_nbr + ib, i16, il, (int)n_pad, PR, p, ownQ, w2, b2, acc);
+                sweep_w<D, XP, EX>(out_nbr + ob, i16, ol, (int)n_pad, QS, p, ownP, w2, b2, acc);
 #pragma unroll
                 for (int i = 0; i < DL; ++i) acc[i] = tanh_f(acc[i]);
                 store_vec<DL>(tr + i16 * B::tr_stride + DL * p, acc);
@@ -1768,8 +2006,16 @@ __global__ __launch_bounds__(1024) void k_iter_w(
             __syncthreads();                           // the team's 16 hits are in the scratch
             // hit update H' = tanh(W4 tanh(acc) + b4) (every wave of the team, 8 MFMAs) and this
             // wave's quarter of the record tiles of the next pass (model.py:94-98,125)
-            if (sl < s_end)
+            if constexpr (EX) {
+                // exact fp32: the team splits the tiles of hl = tanh(W4 q + b4) and meets again in th
+                float *th = scratch + (8 + team) * 16 * B::tr_stride;
+                if (sl < s_end) mfma_hidden_x<F, D, LAST>(smem, tr, th, lane, mem);
+                __syncthreads();
+                if (sl < s_end)
+                    mfma_tail_scratch_x<F, D, LAST, XP>(smem, tr, th, lane, (int64_t)sl * SLICE, PRn, QSn, U, Pc, Qc, mem, 4);
+            } else if (sl < s_end) {
                 mfma_tail_scratch<F, D, LAST, XP>(tb, tr, lane, (int64_t)sl * SLICE, PRn, QSn, U, Pc, Qc, mem, 4);
+            }
         }
     }
 }
@@ -2588,11 +2834,14 @@ Ws carve(char *b, int64_t n_pad, int table_floats, int D, int t16_words = 0)
 }
 
 template <int F, int D>
-constexpr int t16_words()
+constexpr int t16_words()      // fragment tables of the wide kernels: bf16 (BL) or exact fp32 (BX), one buffer
 {
-    if constexpr (D % 32 == 0 && F <= 8) return BL<F, D>::total;
+    if constexpr (D % 32 == 0 && F <= 4) return BL<F, D>::total > BX<F, D>::total ? BL<F, D>::total : BX<F, D>::total;
+    else if constexpr (D % 32 == 0 && F <= 8) return BL<F, D>::total;
     else return 0;
 }
+template <int F, int D>
+constexpr bool can_exact_wide() { return D % 32 == 0 && F <= 4; }
 
 template <int F, int D, bool XP>
 int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e_out, char *ws,
@@ -2613,6 +2862,16 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
     if (Np == 0 || G::pack_first)   // no hits (nothing for k_input4 to do), or a big table
         GNN_LAUNCH("k_pack", (k_pack<F, D, XP>), (L::total + 255) / 256, 256, s, *p, w.table, w.PRa, w.PRb,
                    w.QSa, w.QSb, w.U, w.Pc, w.Qc, Np);
+    // wide hidden layers in exact fp32 (the default): 16 lanes per hit over fp32 record rows, hit
+    // update on v_mfma_f32_16x16x4_f32 (BX).  k_pack32 runs after k_pack: its NULL rows use k_iter_w's
+    // row order and replace the general kernels'.
+    constexpr bool can_ex = can_exact_wide<F, D>() && G::pack_first;
+    const bool ex = can_ex && !bf && n_iters > 0 && Np > 0 && (uint64_t)(Np + 2) * D * 8 < (1ull << 32) &&
+                    !getenv("GNN_NO_WIDE_EXACT");
+    if constexpr (can_ex)
+        if (ex)
+            GNN_LAUNCH("k_pack32", (k_pack32<F, D>), 64, 256, s, *p, reinterpret_cast<float *>(w.t16), w.PRa, w.PRb,
+                       w.QSa, w.QSb, Np, XP ? 1 : 0);
     float *PR = w.PRa, *PRn = w.PRb, *QS = w.QSa, *QSn = w.QSb;
     if (Np > 0) {
         const int nt = (int)pl->n_tiles;
@@ -2679,6 +2938,19 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
                 input_done = true;
             }
         }
+        if constexpr (can_ex) {
+            if (ex) {
+                using B = BX<F, D>;
+                const size_t lds_in = (size_t)(B::template tm_words<false>() + 5 * D + 4 * 16 * B::tr_stride) * 4;
+                static DevOnce inx_attr;
+                if (inx_attr.need())
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_input4_x<F, D, false, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
+                const int64_t g_need = (Np * 4 + 255) / 256;
+                GNN_LAUNCH_SH("k_input4", (k_input4_x<F, D, false, XP>), (unsigned)(g_need < 512 ? g_need : 512), 256,
+                              lds_in, s, pl->X, w.table, reinterpret_cast<const float *>(w.t16), PR, QS, w.U, w.Pc, w.Qc, Np);
+                input_done = true;
+            }
+        }
         if (!fuse_first && !input_done) {
             const int64_t g_need = (Np * 4 + 255) / 256;
             const unsigned g = (unsigned)(g_need < 4096 ? g_need : 4096);   // 16 workgroups per CU, grid-stride
@@ -2729,6 +3001,31 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
                                       w.Pc, w.Qc, Np, tpx, nt);
                     else
                         GNN_LAUNCH_SH("k_iter_w", (k_iter_w<F, D, false, XP>), wgs, 1024,
+                                      (B::template lds_words<false>() + trw) * 4, s, pl->X, w.table, w.t16, pl->tiles,
+                                      pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PRh, QSh, w.U, PRn, QSn,
+                                      w.Pc, w.Qc, Np, tpx, nt);
+                    launched = true;
+                }
+            }
+            if constexpr (can_ex) {
+                if (ex) {           // the same kernel on fp32 record rows, exact fp32 matrix-core tail
+                    using B = BX<F, D>;
+                    static DevOnce ex_attr;
+                    if (ex_attr.need()) {
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter_w<F, D, true, XP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter_w<F, D, false, XP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
+                    }
+                    const int ncu = device_cus();
+                    const unsigned wgs = (unsigned)(((nt < ncu ? nt : ncu) + 7) / 8 * 8);
+                    const size_t trw = (size_t)(2 * 4 + 4) * 16 * B::tr_stride;   // double-buffered q scratch + hl scratch
+                    const unsigned *PRh = reinterpret_cast<const unsigned *>(PR), *QSh = reinterpret_cast<const unsigned *>(QS);
+                    if (t + 1 == n_iters)
+                        GNN_LAUNCH_SH("k_iter_w", (k_iter_w<F, D, true, XP, true>), wgs, 1024,
+                                      (B::template lds_words<true>() + trw) * 4, s, pl->X, w.table, w.t16, pl->tiles,
+                                      pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PRh, QSh, w.U, PRn, QSn,
+                                      w.Pc, w.Qc, Np, tpx, nt);
+                    else
+                        GNN_LAUNCH_SH("k_iter_w", (k_iter_w<F, D, false, XP, true>), wgs, 1024,
                                       (B::template lds_words<false>() + trw) * 4, s, pl->X, w.table, w.t16, pl->tiles,
                                       pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PRh, QSh, w.U, PRn, QSn,
                                       w.Pc, w.Qc, Np, tpx, nt);
