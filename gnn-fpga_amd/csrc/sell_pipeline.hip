@@ -30,10 +30,11 @@
 //
 // Kernels: k_iter2 (persistent phase-split iteration kernel: the fast path, see its comment; its
 // FIRST variant also runs the input network, so the fast path is T launches of k_iter2 + k_edge),
-// k_iter (general iteration kernel: any supported shape, global-gather tiles; with BF the hit
-// update runs on the matrix cores and the records travel as bf16, see mfma_tail), k_input4
-// (input network + first records where the first iteration cannot be fused), k_edge (final edge
-// pass), k_pack / k_pack16 (weight tables).  Activation scales are folded into the weights and an
+// k_iter_w (hidden_dim 32 / 64: 16 lanes per hit, hit update on the matrix cores - exact fp32 rows
+// and v_mfma_f32_16x16x4_f32 by default, bf16 rows and v_mfma_f32_16x16x32_bf16 with
+// GNN_FLAG_BF16_MLP), k_iter (general iteration kernel: any supported shape, global-gather tiles),
+// k_input4 / k_input4_x / k_input4_bf (input network + first records where the first iteration is
+// not fused), k_edge / k_edge_w (final edge pass), k_pack / k_pack16 / k_pack32 (weight tables).  Activation scales are folded into the weights and an
 // optional exp-product mode trades v_exp for a multiply (score4).
 //
 // LDS-staged windows: plan.py orders hits by (graph, topological level) and cuts them into
@@ -658,39 +659,8 @@ __device__ __forceinline__ void mfma_tail_scratch(const unsigned *tb, const floa
                                                   float *__restrict__ U, float *__restrict__ Pc,
                                                   float *__restrict__ Qc, int T0 = 0, int TS = 1);
 
-// Hit update + records of one slice on the matrix cores.  `tb`: LDS [T4 | Tm | b4 | bm] (BL);
-// `tr`: this wave's transpose scratch [16][D + 4]; acc / xv in the sweep's lane layout
-// (lane = hit * 4 + q holds dims [q d4, (q + 1) d4) of its hit).
-template <int F, int D, bool LAST, bool XP>
-__device__ __forceinline__ void mfma_tail(const unsigned *tb, float *tr, const float *acc,
-                                          const float *xv, int lane, int64_t n0,
-                                          float *__restrict__ PRn, float *__restrict__ QSn,
-                                          float *__restrict__ U, float *__restrict__ Pc,
-                                          float *__restrict__ Qc)
-{
-    using B = BL<F, D>;
-    constexpr int d4 = D / 4, NT1 = B::NT1, KS1 = B::KS1, KS2 = B::KS2;
-    constexpr int NT2 = LAST ? B::NT2L : B::NT2N;
-    typedef float f4v __attribute__((ext_vector_type(4)));
-    const bf16x8_t *T4 = reinterpret_cast<const bf16x8_t *>(tb);
-    const bf16x8_t *Tm = T4 + NT1 * KS1 * 64;
-    const float *b4 = reinterpret_cast<const float *>(tb + NT1 * KS1 * 256 + B::template tm_words<LAST>());
-    const float *bm = b4 + D;
-    // 1. q = tanh(acc) and X to the matrix-core lane layout, through the wave's own scratch
-    {
-        const int hit = lane >> 2, q = lane & 3;
-#pragma unroll
-        for (int i = 0; i < d4; i += 4)
-            *reinterpret_cast<f4v *>(tr + hit * B::tr_stride + q * d4 + i) =
-                f4v{tanh_f(acc[i]), tanh_f(acc[i + 1]), tanh_f(acc[i + 2]), tanh_f(acc[i + 3])};
-        if (q == 0)
-#pragma unroll
-            for (int k = 0; k < F; ++k) tr[hit * B::tr_stride + D + k] = xv[k];
-    }
-    mfma_tail_scratch<F, D, LAST, XP>(tb, tr, lane, n0, PRn, QSn, U, Pc, Qc);
-}
-
-// the same from a scratch the caller has filled: tr[hit][0 .. D) = tanh(acc), tr[hit][D .. D + F) = X;
+// Hit update + records of one slice on the matrix cores, from a scratch the caller has filled:
+// `tb`: LDS [T4 | Tm | b4 | bm] (BL); tr[hit][0 .. D) = tanh(acc), tr[hit][D .. D + F) = X;
 // record tiles T0, T0 + TS, ... only (several waves may share one slice's records)
 template <int F, int D, bool LAST, bool XP>
 __device__ __forceinline__ void mfma_tail_scratch(const unsigned *tb, const float *tr, int lane, int64_t n0,
@@ -1292,46 +1262,6 @@ struct Recs {
 __device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xFFFF0000u); }
 
-template <int D>
-struct Recs16 {
-    unsigned r[4][D / 4];
-    __device__ __forceinline__ void read(int cur, const unsigned *REC, int q)
-    {
-        constexpr int d4 = D / 4;
-        const int nb[4] = {quad_bcast_i<0>(cur), quad_bcast_i<1>(cur), quad_bcast_i<2>(cur),
-                           quad_bcast_i<3>(cur)};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(REC + (int64_t)nb[j] * D + q * d4);
-#pragma unroll
-            for (int v = 0; v < d4 / 4; ++v) {
-                const uint4 t = src[v];
-                r[j][4 * v] = t.x; r[j][4 * v + 1] = t.y; r[j][4 * v + 2] = t.z; r[j][4 * v + 3] = t.w;
-            }
-        }
-    }
-    // this lane's piece of record j as floats: [P(d4) | R(d4)]
-    __device__ __forceinline__ void unpack(float (*out)[2 * (D / 4)]) const
-    {
-        constexpr int d4 = D / 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int i = 0; i < d4; ++i) {
-                out[j][2 * i] = bf_lo(r[j][i]);
-                out[j][2 * i + 1] = bf_hi(r[j][i]);
-            }
-    }
-};
-
-// Score the 4 segments of a chunk and add their weighted R|S halves.
-//   part_j = sum over this lane's dims of w2'_i r(P_i + Q_i)       (4 partial sums per lane)
-//   a 4x4 transpose-add inside the quad leaves lane j with the full pre-activation of segment j,
-//   so each lane evaluates ONE sigmoid (not the same one four times); the scores come back with a
-//   DPP broadcast.  Steps past the list end (rem < 4) read the NULL record: they add e * 0.
-// XP (exp-product mode): records hold 2^P' / 2^Q' and 2^(P'+Q') is their product, so each hidden
-// unit costs fma + v_rcp instead of add + v_exp + add + v_rcp.  Only valid while |P'|, |Q'| <= 60
-// (no overflow / flush in either factor): the caller proves that bound, see GNN_FLAG_EXP_PRODUCT.
 template <int D4, bool XP>
 __device__ __forceinline__ void score4(const float (*rec)[2 * D4], const float *own,
                                        const float *w2, float b2, int q, float *acc)
@@ -1458,48 +1388,6 @@ __device__ __forceinline__ void sweep(const int *pre, const int32_t *__restrict_
     }
 }
 
-// the same walk over bf16 records, software-pipelined over the step groups
-template <int D, bool XP>
-__device__ __forceinline__ void sweep_r16(const int *pre, const int32_t *__restrict__ lst, int len,
-                                          int null_idx, const unsigned *REC, int q, const float *own,
-                                          const float *w2, float b2, float *acc)
-{
-    constexpr int d4 = D / 4;
-    if (len <= 0) return;
-    auto fix = [&](int cur, int rem) {
-        const int lim = rem < 4 ? rem : 4;
-        return (q < lim) ? cur : null_idx;
-    };
-    auto index_of = [&](int c) {                 // list entries of group c (4 steps)
-        int cur = 0;
-#pragma unroll
-        for (int i = 0; i < MAXC; ++i)
-            if (c == i) cur = pre[i];
-        if (c >= MAXC) cur = lst[4 * c * SLICE];
-        return fix(cur, len - 4 * c);
-    };
-    const int ng = (len + 3) >> 2;
-    Recs16<D> a, b;
-    a.read(index_of(0), REC, q);
-    for (int c = 0; c < ng; c += 2) {
-        if (c + 1 < ng) b.read(index_of(c + 1), REC, q);
-        {
-            float f[4][2 * d4];
-            a.unpack(f);
-            score4<d4, XP>(f, own, w2, b2, q, acc);
-        }
-        if (c + 1 < ng) {
-            if (c + 2 < ng) a.read(index_of(c + 2), REC, q);
-            float f[4][2 * d4];
-            b.unpack(f);
-            score4<d4, XP>(f, own, w2, b2, q, acc);
-        }
-    }
-}
-
-// Walk of a 16-bit packed list (plan.py _pack16): every register of c[] holds 8 steps for the quad
-// (lane q: steps 8sc+2q and 8sc+2q+1), the registers ROTATE through c[0] so this is a real loop.
-// Steps past the list end are NULL entries already (the packed lists are padded), so no fix-up.
 template <int D, int NC, bool XP, bool PIPE>
 __device__ __forceinline__ void sweep16(int (&c)[NC], const int32_t *__restrict__ nbr16,
                                         const int32_t *__restrict__ off16, int slice, int i16,
@@ -1584,7 +1472,7 @@ __device__ __forceinline__ void sweep16(int (&c)[NC], const int32_t *__restrict_
 
 // one message-passing iteration for one tile: edge scores + weighted aggregation + hit update
 // (+ records for the next pass).  One workgroup per tile; each wavefront takes 16-hit slices.
-template <int F, int D, bool LAST, bool XP, bool BF = false>
+template <int F, int D, bool LAST, bool XP>
 __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_iter(
     const float *__restrict__ X, const float *__restrict__ table,
     const int32_t *__restrict__ tiles, const int32_t *__restrict__ in_off,
@@ -1592,28 +1480,16 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_iter(
     const int32_t *__restrict__ out_nbr, const float *__restrict__ PR,
     const float *__restrict__ QS, float *__restrict__ U, float *__restrict__ PRn,
     float *__restrict__ QSn, float *__restrict__ Pc, float *__restrict__ Qc, int64_t n_pad,
-    int tiles_per_xcd, int n_tiles, int ablate, const unsigned *__restrict__ t16)
+    int tiles_per_xcd, int n_tiles, int ablate)
 {
     using L = TL<F, D>;
     using G = Cfg<F, D>;
     constexpr int d4 = L::d4, NT = G::NT;
     // dynamic LDS: [weight table | record windows]; sized by the host from the plan, so batches
     // of small graphs (small windows) get several workgroups per CU
-    // (BF: [bf16 A fragments + biases | per-wave transpose scratch], see mfma_tail)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *lds = smem, *win = smem + L::total;
-    if constexpr (BF) {
-        using B = BL<F, D>;
-        unsigned *tb = reinterpret_cast<unsigned *>(smem);
-        constexpr int n1 = B::NT1 * B::KS1 * 256, nm = B::template tm_words<LAST>();
-        for (int i = threadIdx.x; i < n1; i += NT) tb[i] = t16[B::o_t4 + i];
-        for (int i = threadIdx.x; i < nm; i += NT) tb[n1 + i] = t16[(LAST ? B::o_tml : B::o_tmn) + i];
-        for (int i = threadIdx.x; i < D; i += NT) tb[n1 + nm + i] = t16[B::o_b4 + i];
-        for (int i = threadIdx.x; i < (LAST ? 2 : 5) * D; i += NT)
-            tb[n1 + nm + D + i] = t16[(LAST ? B::o_bml : B::o_bmn) + i];
-    } else {
-        stage4<NT>(table, lds, L::total / 4);
-    }
+    stage4<NT>(table, lds, L::total / 4);
 
     // XCD-affine renumbering (matters for global-mode tiles only): blockIdx is dealt round-robin
     // over the 8 XCDs, so give each residue class a contiguous range of tiles.
@@ -1632,7 +1508,7 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_iter(
     struct Pre {
         int il, ol, ib, ob;          // list lengths and offsets: wave-uniform (SGPRs)
         int cin[MAXC], cout[MAXC];
-        AVec<BF ? d4 / 2 : d4> Pn, Qn;      // BF: bf16 pairs
+        AVec<d4> Pn, Qn;
         AVec<d4> acc;
         AVec<F> x;
     };
@@ -1656,13 +1532,8 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_iter(
 #undef GNN_PF
         static_assert(MAXC == 6, "prefetch is written out for 6 chunks");
         const int64_t n = (int64_t)slice * SLICE + i16;
-        if constexpr (BF) {                          // bf16 rows: D dwords per hit
-            p.Pn.load(PR + n * D + q * d4);
-            p.Qn.load(QS + n * D + q * d4);
-        } else {
-            p.Pn.load(PR + n * 2 * D + q * 2 * d4);  // own P chunk
-            p.Qn.load(QS + n * 2 * D + q * 2 * d4);  // own Q chunk
-        }
+        p.Pn.load(PR + n * 2 * D + q * 2 * d4);      // own P chunk
+        p.Qn.load(QS + n * 2 * D + q * 2 * d4);      // own Q chunk
         p.acc.load(U + n * D + q * d4);              // W3[:, 2C:] H_n + b3
         p.x.load(X + n * F);                         // skip concat input (model.py:154)
     };
@@ -1692,10 +1563,9 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_iter(
     __syncthreads();
     if (slice >= 0) arrive(cur);
     float w2[d4];
-    const float *w2src = BF ? table : lds;              // BF keeps no fp32 table in LDS
 #pragma unroll
-    for (int i = 0; i < d4; ++i) w2[i] = w2src[q * L::stride + L::o_w2 + i];
-    const float b2 = w2src[L::o_b2];                    // scaled output bias
+    for (int i = 0; i < d4; ++i) w2[i] = lds[q * L::stride + L::o_w2 + i];
+    const float b2 = lds[L::o_b2];                      // scaled output bias
 
     // While `cur` is processed (LDS-mode tiles issue no VMEM instruction there) the loads of
     // `nxt` stay in flight; arrive(nxt) waits for them a whole slice after issue, and this slice's
@@ -1716,23 +1586,8 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_iter(
             const float *wl = lds + woff;
             float acc[d4], Pn[d4], Qn[d4], xv[F];
             cur.acc.get(acc); cur.x.get(xv);
-            if constexpr (BF) {
-                float pp[d4 / 2], qq[d4 / 2];
-                cur.Pn.get(pp); cur.Qn.get(qq);
-#pragma unroll
-                for (int i = 0; i < d4 / 2; ++i) {
-                    Pn[2 * i] = bf_lo(__float_as_uint(pp[i])); Pn[2 * i + 1] = bf_hi(__float_as_uint(pp[i]));
-                    Qn[2 * i] = bf_lo(__float_as_uint(qq[i])); Qn[2 * i + 1] = bf_hi(__float_as_uint(qq[i]));
-                }
-            } else {
-                cur.Pn.get(Pn); cur.Qn.get(Qn);
-            }
+            cur.Pn.get(Pn); cur.Qn.get(Qn);
             if (ablate & 2) {
-            } else if constexpr (BF) {
-                sweep_r16<D, XP>(cur.cin, in_nbr + cur.ib + q * SLICE + i16, cur.il, (int)n_pad,
-                                 reinterpret_cast<const unsigned *>(PR), q, Qn, w2, b2, acc);
-                sweep_r16<D, XP>(cur.cout, out_nbr + cur.ob + q * SLICE + i16, cur.ol, (int)n_pad,
-                                 reinterpret_cast<const unsigned *>(QS), q, Pn, w2, b2, acc);
             } else if (G::it_rec > 0 && mode) {
                 // segments ending here: P[start] + Q[n], adds e * R[start]; then starting here
                 sweep<D, XP>(cur.cin, in_nbr + cur.ib + q * SLICE + i16, cur.il, in_cnt, winA, q, Qn, w2, b2, acc);
@@ -1742,30 +1597,22 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_iter(
                 sweep<D, XP>(cur.cout, out_nbr + cur.ob + q * SLICE + i16, cur.ol, (int)n_pad, QS, q, Pn, w2, b2, acc);
             }
             // hit update: H' = tanh(W4 tanh(acc) + b4)                  (model.py:94-98,125)
-            if constexpr (BF) {
-                using B = BL<F, D>;
-                float *tr = smem + B::template lds_words<LAST>() + (threadIdx.x >> 6) * 16 * B::tr_stride;
-                mfma_tail<F, D, LAST, XP>(reinterpret_cast<const unsigned *>(smem), tr, acc, xv, lane,
-                                          (int64_t)slice * SLICE, PRn, QSn, U, Pc, Qc);
-            } else {
-                float ql[d4], qa[D];
+            float ql[d4], qa[D];
 #pragma unroll
-                for (int i = 0; i < d4; ++i) ql[i] = tanh_f(acc[i]);
-                quad_allgather<d4>(ql, qa);
-                float hl[d4];
-                role_gemv<d4, D, 0>(wl + L::o_4, qa, qa, hl);
+            for (int i = 0; i < d4; ++i) ql[i] = tanh_f(acc[i]);
+            quad_allgather<d4>(ql, qa);
+            float hl[d4];
+            role_gemv<d4, D, 0>(wl + L::o_4, qa, qa, hl);
 #pragma unroll
-                for (int i = 0; i < d4; ++i) hl[i] = tanh_f(hl[i]);
-                float hn[D];
-                quad_allgather<d4>(hl, hn);
-                if (!(ablate & 4)) rec.compute(wl, hn, xv);
-            }
+            for (int i = 0; i < d4; ++i) hl[i] = tanh_f(hl[i]);
+            float hn[D];
+            quad_allgather<d4>(hl, hn);
+            if (!(ablate & 4)) rec.compute(wl, hn, xv);
         }
         if constexpr (G::pipelined)
             if (next >= 0) arrive(nxt);
         cur = nxt;
-        if constexpr (!BF)
-            if (slice >= 0 && !(ablate & 16)) rec.store(n, q, PRn, QSn, U, Pc, Qc);
+        if (slice >= 0 && !(ablate & 16)) rec.store(n, q, PRn, QSn, U, Pc, Qc);
         slice = next;
     }
 }
@@ -3036,11 +2883,11 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
             } else if (t + 1 == n_iters)
                 GNN_LAUNCH_SH("k_iter", (k_iter<F, D, true, XP>), 8 * tpx, G::NT, it_lds, s, pl->X, w.table,
                            pl->tiles, pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PR, QS, w.U,
-                           PRn, QSn, w.Pc, w.Qc, Np, tpx, nt, ablate, w.t16);
+                           PRn, QSn, w.Pc, w.Qc, Np, tpx, nt, ablate);
             else
                 GNN_LAUNCH_SH("k_iter", (k_iter<F, D, false, XP>), 8 * tpx, G::NT, it_lds, s, pl->X, w.table,
                            pl->tiles, pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PR, QS, w.U,
-                           PRn, QSn, w.Pc, w.Qc, Np, tpx, nt, ablate, w.t16);
+                           PRn, QSn, w.Pc, w.Qc, Np, tpx, nt, ablate);
             float *t1 = PR; PR = PRn; PRn = t1;
             float *t2 = QS; QS = QSn; QSn = t2;
         }
