@@ -997,9 +997,11 @@ __global__ __launch_bounds__(256) void k_input4_bf(const float *__restrict__ X,
     }
 }
 
-// the same with the exact fp32 products (BX / k_pack32)
+// the same with the exact fp32 products (BX / k_pack32).  1024 threads: the 88 KB of fragments allow one
+// workgroup per CU, and 4 waves per SIMD are needed to keep dependent MFMA chains apart (256 threads:
+// 0.257 ms at c5 x 8)
 template <int F, int D, bool LAST, bool XP>
-__global__ __launch_bounds__(256) void k_input4_x(const float *__restrict__ X,
+__global__ __launch_bounds__(1024) void k_input4_x(const float *__restrict__ X,
                                                   const float *__restrict__ table,
                                                   const float *__restrict__ tfg,
                                                   float *__restrict__ PRn, float *__restrict__ QSn,
@@ -1013,13 +1015,13 @@ __global__ __launch_bounds__(256) void k_input4_x(const float *__restrict__ X,
     typedef float f4v __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) float smem_inx[];
     float *tb = smem_inx;                                           // [Tm | bm]
-    for (int i = threadIdx.x; i < nm; i += 256) tb[i] = tfg[(LAST ? B::o_tml : B::o_tmn) + i];
-    for (int i = threadIdx.x; i < nb; i += 256) tb[nm + i] = tfg[(LAST ? B::o_bml : B::o_bmn) + i];
+    for (int i = threadIdx.x; i < nm; i += 1024) tb[i] = tfg[(LAST ? B::o_tml : B::o_tmn) + i];
+    for (int i = threadIdx.x; i < nb; i += 1024) tb[nm + i] = tfg[(LAST ? B::o_bml : B::o_bmn) + i];
     __syncthreads();
     float *tr = smem_inx + nm + nb + (threadIdx.x >> 6) * 16 * B::tr_stride;
     const int lane = threadIdx.x & 63, q = lane & 3;
-    for (int64_t n = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 2; n < n_pad;
-         n += (int64_t)gridDim.x * 64) {
+    for (int64_t n = ((int64_t)blockIdx.x * 1024 + threadIdx.x) >> 2; n < n_pad;
+         n += (int64_t)gridDim.x * 256) {
         float x[F], hl[d4];
 #pragma unroll
         for (int k = 0; k < F; ++k) x[k] = X[n * F + k];
@@ -2788,12 +2790,13 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
         if constexpr (can_ex) {
             if (ex) {
                 using B = BX<F, D>;
-                const size_t lds_in = (size_t)(B::template tm_words<false>() + 5 * D + 4 * 16 * B::tr_stride) * 4;
+                const size_t lds_in = (size_t)(B::template tm_words<false>() + 5 * D + 16 * 16 * B::tr_stride) * 4;
                 static DevOnce inx_attr;
                 if (inx_attr.need())
                     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_input4_x<F, D, false, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
-                const int64_t g_need = (Np * 4 + 255) / 256;
-                GNN_LAUNCH_SH("k_input4", (k_input4_x<F, D, false, XP>), (unsigned)(g_need < 512 ? g_need : 512), 256,
+                const int64_t g_need = (Np * 4 + 1023) / 1024;
+                const int64_t g_cap = device_cus();
+                GNN_LAUNCH_SH("k_input4", (k_input4_x<F, D, false, XP>), (unsigned)(g_need < g_cap ? g_need : g_cap), 1024,
                               lds_in, s, pl->X, w.table, reinterpret_cast<const float *>(w.t16), PR, QS, w.U, w.Pc, w.Qc, Np);
                 input_done = true;
             }
