@@ -738,7 +738,11 @@ def test_training_on_the_level_ordered_twin(hip):
     from gnn_fpga_amd.model import SegmentClassifier
     torch.manual_seed(6)
     graphs = [synth.layered_graph(10000, 100000, 3, seed=90 + s) for s in range(4)]
-    b = HitGraphBatch.from_graphs(graphs).cuda()
+    b = HitGraphBatch.from_graphs(graphs)
+    src, dst = b.src.numpy().copy(), b.dst.numpy().copy()
+    src[5::97] = -1                              # padded segments anywhere in the caller's order
+    dst[5::97] = -1
+    b = HitGraphBatch(b.X.numpy(), src, dst, y=b.y.numpy(), hit_ptr=b.hit_ptr, seg_ptr=b.seg_ptr).cuda()
     y = b.y.cuda()
     m = SegmentClassifier(input_dim=3, hidden_dim=8, n_iters=3).cuda().train()
 
@@ -752,7 +756,12 @@ def test_training_on_the_level_ordered_twin(hip):
 
     e0, l0, g0 = grads(False)
     twin = b.level_ordered(8)
-    assert twin is not b and twin.n_hits == b.n_hits and torch.equal(twin.X.sum(0), twin.X.sum(0))
+    assert twin is not b and twin.n_hits == b.n_hits
+    # the twin's segments are sorted by end hit, padded ones last; seg_order / seg_rank are inverse
+    td = twin.dst.long()
+    n_valid = int((td >= 0).sum())
+    assert bool((td[:n_valid] >= 0).all()) and bool((td[1:n_valid] >= td[:n_valid - 1]).all())
+    assert torch.equal(twin.seg_order[twin.seg_rank], torch.arange(b.n_segments, device="cuda"))
     e1, l1, g1 = grads(True)
     e2, l2, g2 = grads(True)
     assert (e0 - e1).abs().max().item() < 1e-6                       # scores stay in the caller's segment order
