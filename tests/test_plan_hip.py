@@ -2,7 +2,8 @@
 numpy specification plan.SellPlan: EVERY array and scalar equal (integer work: bit-exact), on layered
 detector batches, ragged / tiny graphs, padded segments, forced global-gather mode, wide hidden
 layers, one graph whose levels exceed a tile, muon-size graphs, graphs with cycles / self loops
-(the 64-sweep cap of the level relaxation), shuffled segment order, and BASELINE's c3 graph."""
+(the 64-sweep cap of the level relaxation), shuffled segment order (narrow and wide hit ranges per
+segment block), and BASELINE's c3 graph."""
 import numpy as np
 import pytest
 import torch
@@ -21,7 +22,7 @@ def _random_graph(n, e, F, seed):
 
 
 CASES = ["layered", "ragged", "padded", "global", "wide", "one_graph_big_levels", "muon", "cyclic",
-         "shuffled", "c3", "many_c3", "leading_pads", "tiny_tiles"]
+         "shuffled", "big_shuffled", "c3", "many_c3", "leading_pads", "tiny_tiles"]
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -59,6 +60,13 @@ def test_hip_builder_builds_the_same_plan(hip, case):
         g = synth.layered_graph(3000, 30000, 3, seed=5)
         o = np.random.default_rng(0).permutation(30000)
         graphs = [synth.HitGraph(g.X, g.src[o], g.dst[o], g.y[o]), synth.layered_graph(2000, 15000, 3, seed=6)]
+    elif case == "big_shuffled":
+        # a 16 k-segment block of pb_degrees spans > 16384 hits: its global-atomics path, next to a
+        # graph whose blocks stay narrow (LDS counts), and a block with padded segments only
+        g = synth.layered_graph(40000, 120000, 3, seed=7)
+        o = np.random.default_rng(1).permutation(120000)
+        graphs = [synth.HitGraph(g.X, g.src[o], g.dst[o], g.y[o]), synth.layered_graph(5000, 40000, 3, seed=8)]
+        pads = slice(120000 + 16384, 120000 + 2 * 16384)
     elif case == "c3":
         graphs = [synth.layered_graph(10000, 100000, 3, seed=0)]
     elif case == "many_c3":
