@@ -19,6 +19,11 @@
 //       k_agg_bwd_n  per hit:      gH_prev += sum_out e gmi[d] + sum_in e gmo[s]
 //   input         k_input_bwd per hit: g = gH0[:D] (1-H0^2);  gWin, gbin
 //
+// hidden_dim <= 16 takes the PULL FORM further down instead of the node / aggregation kernels above
+// (D-wide records [P | R | gp], [Q | S | gp]; a hit walks its two lists once per iteration): with the
+// forward's kept hidden layers (Q_all) on four lanes per hit - k_hit_bwd4, k_seg_bwd4, k_seg_fin -
+// else on one lane per hit - kb_prs, k_hit_bwd, k_seg_bwd.
+//
 // Weight gradients are sums of per-item outer products: a workgroup parks its 256 items' factors
 // in LDS, each thread then owns output elements and sums over the 256 items (fixed order) and adds
 // the result to ITS WORKGROUP'S OWN ROW of a partial-sum table (row = blockIdx.x; one writer per
