@@ -18,6 +18,7 @@ never touches the GPU) and relays rank 0's line.
 Rank 0 prints ONE JSON line with
   roofline      dominant kernel, HIP-event timed inside the library on the launch stream
   cpu_baseline  the oracle's dense-bmm port of the reference algorithm on this host (N=1 only)
+  train_c3      (N = 1, c3) one training step on 32 of the workload's graphs as one batch
   plan_ms       what the per-batch execution plan costs (outside the timed region), and the
                 rate of one forward on a FRESH batch, plan included (`value_incl_plan`)
   train_c4      BASELINE configs[3]: 512 muon graphs sharded r::N, HIP forward + fused BCE +
@@ -227,6 +228,55 @@ def train_c4(dev, rank, world, rehearse, steps=60, warmup=15, n_global=512):
     return rec
 
 
+def train_c3(dev, graphs, steps=30, warmup=8):
+    """Training at the headline workload's graph size (N = 1 only): 32 of the c3 graphs as one batch
+    (3.2 M segments), HIP forward that keeps e_t / H_t / Q_t + fused BCE + HIP backward + Adam.  The
+    batch trains on its level-ordered twin (hits in plan order, segments by end hit: built once)."""
+    import torch
+    from gnn_fpga_amd import HitGraphBatch, shard
+    from gnn_fpga_amd.loss import BCELoss
+    from gnn_fpga_amd.model import SegmentClassifier
+    graphs = graphs[:32]
+    batch = HitGraphBatch.from_graphs(graphs).to(dev)
+    y = batch.y.to(dev)
+    F = batch.X.shape[1]
+    torch.manual_seed(0)
+    m = SegmentClassifier(input_dim=F, hidden_dim=8, n_iters=3).to(dev).train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, fused=True)
+    bce = BCELoss()
+    bucket = shard.GradBucket(m.parameters())
+
+    def step():                              # the reference's loop (gnn/estimator.py:49-60)
+        opt.zero_grad(set_to_none=False)
+        loss = bce(m(batch), y)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def step_direct():                       # no autograd graph: the backward adds into the bucket's views
+        bucket.zero()
+        loss = bucket.step(m, batch, y)
+        opt.step()
+        return loss
+
+    sync = torch.cuda.synchronize
+    first = float(step().detach())
+    for _ in range(warmup):
+        step()
+    dt = time_steps(step, steps, sync)
+    for _ in range(warmup):
+        step_direct()
+    dd = time_steps(step_direct, steps, sync)
+    last = float(step().detach())
+    n_seg = batch.n_segments
+    return {"workload": "%d c3 graphs as one batch (%d hits, %d segments), F=%d, D=8, T=3, BCE, Adam"
+                        % (len(graphs), batch.n_hits, n_seg, F),
+            "ms_per_step": dt / steps * 1e3, "segments_per_s": n_seg * steps / dt,
+            "ms_per_step_direct": dd / steps * 1e3, "segments_per_s_direct": n_seg * steps / dd,
+            "direct": "GradBucket.step: same kernels, no autograd graph, loss in the twin's segment order",
+            "loss_first": first, "loss_last": last, "steps": steps}
+
+
 def run(args):
     import numpy as np  # noqa: F401
     import torch
@@ -363,6 +413,9 @@ def run(args):
         elapsed = float(tmax.item())
 
     train = None if args.no_train else train_c4(dev, rank, world, rehearse)
+    train3 = None
+    if not args.no_train and world == 1 and args.workload == "c3" and len(graphs) >= 32:
+        train3 = train_c3(dev, graphs)
 
     if rank == 0:
         per = {}
@@ -456,6 +509,8 @@ def run(args):
             out["pruned"] = pruned
         if train is not None:
             out["train_c4"] = train
+        if train3 is not None:
+            out["train_c3"] = train3
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, graphs[0], wl)
         print(json.dumps(out), flush=True)
