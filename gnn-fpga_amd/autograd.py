@@ -46,9 +46,19 @@ class _SegClf(torch.autograd.Function):
 
 def training_batch(model, batch, use_events):
     """The batch the training kernels run on: detector-size batches are renumbered in plan order once
-    (HitGraphBatch.level_ordered) so that the kernels' record gathers stay L2-local."""
-    if not getattr(model, "level_order_training", True) or batch.n_hits < 20000 or model.hidden_dim > 16:
+    (HitGraphBatch.level_ordered) so that the kernels' record gathers stay L2-local.
+    model.level_order_training: True (default: always), False (never), "auto" (from the second time
+    the same batch object is trained on)."""
+    policy = getattr(model, "level_order_training", True)
+    if not policy or batch.n_hits < 20000 or model.hidden_dim > 16:
         return batch
+    if policy == "auto" and getattr(batch, "_twin", None) is None:
+        # the twin costs a plan build and two sorts (10 ms at 3.2 M segments, ten steps' worth): it is
+        # built when a batch object comes back (epochs over cached batches, batch_generator), not for a
+        # batch that is seen once
+        batch._train_uses = getattr(batch, "_train_uses", 0) + 1
+        if batch._train_uses < 2:
+            return batch
     if use_events:
         lay = batch.event_layout()
         if lay is not None and _lib.events_supported(model.input_dim, model.hidden_dim, lay.max_hits, lay.max_segments):

@@ -240,6 +240,11 @@ class SegmentClassifier(nn.Module):
         self._workspace = None
         self.use_plan = True      # False: per-module CSR kernels instead of the fused pipeline
         self.use_events = True    # batches of small graphs: whole forward in one launch
+        # training on a batch's level-ordered twin (autograd.training_batch): True (default; the twin is
+        # built at the first step on a batch: a plan build and two sorts, ten steps' worth), False, or
+        # "auto" = only from the second time the same batch object is trained on (streams of batches
+        # that never repeat; the first and the later steps on a batch then sum in different orders)
+        self.level_order_training = True
         self.exp_product = True   # allow GNN_FLAG_EXP_PRODUCT when the bound check passes
         self.mlp_bf16 = False     # hidden_dim 32 / 64: hit update on the matrix cores (bf16 operands,
                                   # fp32 accumulate; scores move by ~1e-3 - opt-in, GNN_FLAG_BF16_MLP)

@@ -754,6 +754,13 @@ def test_training_on_the_level_ordered_twin(hip):
         loss.backward()
         return out.detach().clone(), loss.detach().clone(), [p.grad.detach().clone() for p in m.parameters()]
 
+    assert m.level_order_training is True
+    m.level_order_training = "auto"                  # opt-in: from the second use of a batch object
+    b2 = HitGraphBatch(b.X.cpu().numpy(), src, dst, y=b.y.cpu().numpy(), hit_ptr=b.hit_ptr, seg_ptr=b.seg_ptr).cuda()
+    m.zero_grad(); BCELoss()(m(b2), y).backward()
+    assert getattr(b2, "_twin", None) is None
+    m.zero_grad(); BCELoss()(m(b2), y).backward()
+    assert getattr(b2, "_twin", None) is not None and b2._twin is not b2
     e0, l0, g0 = grads(False)
     twin = b.level_ordered(8)
     assert twin is not b and twin.n_hits == b.n_hits
