@@ -841,6 +841,34 @@ def test_bf16_matrix_core_hit_update(hip, F, D, T):
         assert np.abs(eg - ref).max() < TOL_BF16
 
 
+@pytest.mark.parametrize("F,D,T", [(3, 64, 3), (2, 32, 4), (3, 32, 2)])
+def test_exact_wide_path_and_its_fallback(hip, F, D, T, monkeypatch):
+    """hidden_dim 32 / 64 in fp32: the 16-lanes-per-hit kernel with the hit update on
+    v_mfma_f32_16x16x4_f32 (a chain of fp32 fmas: nothing is rounded) is the default; the general
+    4-lanes-per-hit kernel stays as the fallback for tables beyond 32-bit record offsets
+    (GNN_NO_WIDE_EXACT forces it).  Both within the fp32 tolerance of the C oracle, both
+    deterministic, and really two different code paths (other summation orders)."""
+    from gnn_fpga_amd.model import SegmentClassifier
+    torch.manual_seed(3 * D + T)
+    graphs = [synth.layered_graph(900, 6000, F, seed=70 + i) for i in range(3)] + [synth.layered_graph(5, 4, F, n_layers=2, seed=9)]
+    m = SegmentClassifier(input_dim=F, hidden_dim=D, n_iters=T).cuda().eval()
+    m.use_events = False
+    params = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    batch = HitGraphBatch.from_graphs(graphs).cuda()
+    with torch.no_grad():
+        monkeypatch.delenv("GNN_NO_WIDE_EXACT", raising=False)
+        wide, wide_again = m(batch), m(batch)
+        monkeypatch.setenv("GNN_NO_WIDE_EXACT", "1")
+        general = m(batch)
+    torch.cuda.synchronize()
+    assert torch.equal(wide, wide_again)
+    assert not torch.equal(wide, general)
+    assert (wide - general).abs().max().item() < TOL
+    for g, ew, eg in zip(graphs, batch.split_scores(wide.cpu().numpy()), batch.split_scores(general.cpu().numpy())):
+        ref = index_c.segment_classifier(g.X, g.src, g.dst, params, T)
+        assert np.abs(ew - ref).max() < TOL and np.abs(eg - ref).max() < TOL
+
+
 @pytest.mark.parametrize("lim_over", [{}, {"iter_records": 0, "edge_records": 0}])
 def test_plan_built_on_the_gpu_equals_the_host_plan(hip, lim_over):
     """HitGraphBatch.build_plan on a CUDA batch runs plan_device.DeviceSellPlan (torch sorts and
