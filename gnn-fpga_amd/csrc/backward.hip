@@ -116,6 +116,51 @@ __device__ __forceinline__ void accum_outer(const float *L, const float *R, bool
     if constexpr (C0 + CH < NR) accum_outer<NL, NR, C0 + CH>(L, R, active, g, ldg, col0, gb, lds);
 }
 
+// The same sums on the matrix cores for wide left factors (NL = 32 / 64): the outer-product sum over
+// the workgroup's 256 items is a [NL x 256] . [256 x NR] product.  v_mfma_f32_16x16x4_f32 multiplies
+// and accumulates in fp32 in k (= item) order: nothing is rounded, the order is fixed.  Lane l supplies
+// A[row l & 15][item 4 s + (l >> 4)] and B[item 4 s + (l >> 4)][col l & 15] straight from the transposed
+// staging (stride 260: the 64 lanes hit 64 different banks) and receives rows 4 (l >> 4) .. + 3 of
+// column l & 15; the workgroup's 4 waves deal the 16 x 16 output tiles.  One thread per output was
+// 26 k LDS-bound instructions per thread at D = 64 (0.8 of k_seg_finW's 0.96 ms).
+template <int NL, int NR, int C0 = 0>
+__device__ __forceinline__ void accum_outer_mfma(const float *L, const float *R, bool active, float *g,
+                                                 int ldg, int col0, float *gb, float *lds)
+{
+    static_assert(NL % 16 == 0 && NL + 16 <= kOuterCap, "left factor: whole 16-row tiles");
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    constexpr bool ONES = (C0 == 0);
+    constexpr int ROOM = ((kOuterCap - NL) / 16) * 16 - (ONES ? 1 : 0);     // columns per chunk (tiles are whole)
+    constexpr int CH = (NR - C0 <= ROOM) ? NR - C0 : ROOM, RS = kOuterStride;
+    constexpr int COLS = CH + (ONES ? 1 : 0), CT = (COLS + 15) / 16, RT = NL / 16;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) lds[i * RS + threadIdx.x] = active ? L[i] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) lds[(NL + k) * RS + threadIdx.x] = active ? R[C0 + k] : 0.0f;
+    if constexpr (ONES) lds[(NL + CH) * RS + threadIdx.x] = active ? 1.0f : 0.0f;
+#pragma unroll
+    for (int k = COLS; k < 16 * CT; ++k) lds[(NL + k) * RS + threadIdx.x] = 0.0f;      // pad the last column tile
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r16 = lane & 15, g4 = lane >> 4;
+    for (int t = wv; t < RT * CT; t += kBlock / 64) {
+        const int it = t / CT, jt = t % CT;
+        const float *a = lds + (16 * it + r16) * RS + g4, *b = lds + (NL + 16 * jt + r16) * RS + g4;
+        f4v c = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 8
+        for (int st = 0; st < kBlock / 4; ++st) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * st], b[4 * st], c, 0, 0, 0);
+        const int col = 16 * jt + r16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * it + 4 * g4 + r;
+            const float v = r == 0 ? c.x : r == 1 ? c.y : r == 2 ? c.z : c.w;
+            if (col < CH) g[i * ldg + col0 + C0 + col] += v;                // own row: the only writer
+            else if (ONES && col == CH && gb) gb[i] += v;
+        }
+    }
+    __syncthreads();
+    if constexpr (C0 + CH < NR) accum_outer_mfma<NL, NR, C0 + CH>(L, R, active, g, ldg, col0, gb, lds);
+}
+
 // P/Q rows from H (same as the forward's k_pq; kept local to this file)
 template <int F, int D>
 __global__ __launch_bounds__(kBlock) void kb_pq(const float *__restrict__ H, int ldh,
@@ -992,6 +1037,280 @@ __global__ __launch_bounds__(kBlock) void k_seg_fin(
     accum_outer<D, C>(Gin, h, active, gW3, 3 * C, C, nullptr, lds);
 }
 
+// ---------------------------------------------------------------------------------------------
+// WIDE hidden layers (hidden_dim 32 / 64, the reference's toy / ACTS / mu200 models): the same pull
+// form with SIXTEEN lanes per hit in the list walk.  The per-pass kernels above keep C-wide rows in
+// one lane's registers (3C = 201 floats of M at D = 64) and ran 25x the inference forward.  Here lane p
+// of a hit's 16 owns dims [p DL, (p+1) DL), DL = D / 16; a record is stored [P(DL) R(DL)] x 16 | gp so
+// that a lane's share is contiguous and the 16 lanes read a row as whole lines; a segment's ge is
+// finished by the 4x4 transpose-add in the quad plus two row rotations (as k_iter_w's scores).
+//   k_hit_bwdW  per hit (1 lane): P R Q S from H, gp from the kept q -> A, B; gH_prev = W3c^T gp; gW3c, gb3, gW4, gb4
+//   k_seg_bwdW  per hit (16 lanes): both list walks -> G4 = [gP gQ Gout Gin] and the hit's W2 / b2 terms
+//   k_seg_finW  per hit (1 lane): gH_prev += W^T G4;  gW1, gb1, gW3a, gW3b, gW2, gb2
+template <int CTRL>
+__device__ __forceinline__ float dppf(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+template <int F, int D>
+__global__ __launch_bounds__(kBlock) void k_hit_bwdW(
+    const float *__restrict__ H, const float *__restrict__ Hn, const float *__restrict__ Qk, int ldh,
+    const float *__restrict__ W1, const float *__restrict__ b1, const float *__restrict__ W3,
+    const float *__restrict__ W4, const float *__restrict__ gHn, float *__restrict__ gH, float *__restrict__ A,
+    float *__restrict__ B, float *__restrict__ gW3, float *__restrict__ gb3, float *__restrict__ gW4,
+    float *__restrict__ gb4, int rep_stride, int64_t n_hits)
+{
+    gW3 = my_replica(gW3, rep_stride);
+    gb3 = my_replica(gb3, rep_stride);
+    gW4 = my_replica(gW4, rep_stride);
+    gb4 = my_replica(gb4, rep_stride);
+    constexpr int C = Shape<F, D>::C, LDH = Shape<F, D>::LDH, DL = D / 16;
+    __shared__ __attribute__((aligned(16))) float lds[outer_lds_floats<D, C>()];
+    const int64_t n = xcd_block() * kBlock + threadIdx.x;
+    const bool active = n < n_hits;
+    float h[C], q[D], gr[D], gp[D];
+#pragma unroll
+    for (int k = 0; k < C; ++k) h[k] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < D; ++i) q[i] = gr[i] = gp[i] = 0.0f;
+    if (active) {
+        {
+            float hp[LDH];
+            load_row4<LDH / 4>(H + n * ldh, hp);
+#pragma unroll
+            for (int k = 0; k < C; ++k) h[k] = hp[k];
+        }
+        load_row4<D / 4>(Qk + n * D, q);
+        {
+            float hn[D], gn[D];
+            load_row4<D / 4>(Hn + n * ldh, hn);
+            load_row4<D / 4>(gHn + n * ldh, gn);
+#pragma unroll
+            for (int i = 0; i < D; ++i) gr[i] = gn[i] * (1.0f - hn[i] * hn[i]);
+        }
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            float s = 0.0f;
+#pragma unroll
+            for (int i = 0; i < D; ++i) s = fmaf(W4[i * D + k], gr[i], s);
+            gp[k] = s * (1.0f - q[k] * q[k]);
+        }
+        {
+            float gh[LDH];
+#pragma unroll
+            for (int k = 0; k < LDH; ++k) gh[k] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < C; ++k) {
+                float s = 0.0f;
+#pragma unroll
+                for (int i = 0; i < D; ++i) s = fmaf(W3[i * 3 * C + 2 * C + k], gp[i], s);
+                gh[k] = s;
+            }
+            store_row4<LDH / 4>(gH + n * ldh, gh);                 // gHself initialises gH_prev
+        }
+        // records, one lane share [P(DL) R(DL)] / [Q(DL) S(DL)] at a time (stored as it is finished)
+        float *Ar = A + n * 3 * D, *Br = B + n * 3 * D;
+#pragma unroll 1
+        for (int pl = 0; pl < 16; ++pl) {
+            float a[2 * DL], b[2 * DL];
+#pragma unroll
+            for (int j = 0; j < DL; ++j) {
+                const int i = pl * DL + j;
+                float pp = b1[i], qq = 0.0f, rr = 0.0f, ss = 0.0f;
+#pragma unroll
+                for (int k = 0; k < C; ++k) {
+                    pp = fmaf(W1[i * 2 * C + k], h[k], pp);
+                    qq = fmaf(W1[i * 2 * C + C + k], h[k], qq);
+                    rr = fmaf(W3[i * 3 * C + k], h[k], rr);
+                    ss = fmaf(W3[i * 3 * C + C + k], h[k], ss);
+                }
+                a[j] = pp; a[DL + j] = rr; b[j] = qq; b[DL + j] = ss;
+            }
+            store_vec<2 * DL>(Ar + pl * 2 * DL, a);
+            store_vec<2 * DL>(Br + pl * 2 * DL, b);
+        }
+        store_row4<D / 4>(Ar + 2 * D, gp);
+        store_row4<D / 4>(Br + 2 * D, gp);
+    }
+    accum_outer_mfma<D, C>(gp, h, active, gW3, 3 * C, 2 * C, gb3, lds);
+    accum_outer_mfma<D, D>(gr, q, active, gW4, D, 0, gb4, lds);
+}
+
+// one direction of a hit's pull, 16 lanes per hit (see quad_walk for the roles of the arguments)
+template <int D, bool IN>
+__device__ __forceinline__ void row_walk(int beg, int end, int n, int p, const int32_t *__restrict__ nbr,
+                                         const int32_t *__restrict__ eid, const float *__restrict__ e,
+                                         const float *__restrict__ REC, const float *own_pq, const float *own_r,
+                                         const float *own_gp, const float *w2, float *gZ, float *G, float *sw2)
+{
+    constexpr int DL = D / 16;
+    const int q = p & 3;
+    for (int k = beg; k < end; k += 4) {
+        const int kk = k + q;
+        const bool ok = kk < end;
+        const int nb = ok ? nbr[kk] : n;                        // (a masked entry reads the own record with score 0)
+        const float ev = ok ? e[eid[kk]] : 0.0f;
+        float pr[4][2 * DL], gv[4][DL], part[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nbj = j == 0 ? quad_bcast<0>(nb) : j == 1 ? quad_bcast<1>(nb) : j == 2 ? quad_bcast<2>(nb) : quad_bcast<3>(nb);
+            const float *r = REC + (int64_t)nbj * 3 * D;
+            load_vec<2 * DL>(r + p * 2 * DL, pr[j]);
+            load_vec<DL>(r + 2 * D + p * DL, gv[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float x = 0.0f;
+#pragma unroll
+            for (int i = 0; i < DL; ++i) {
+                x = fmaf(gv[j][i], own_r[i], x);
+                x = fmaf(own_gp[i], pr[j][DL + i], x);
+            }
+            part[j] = x;
+        }
+        // lane q of every quad ends with the sum over the hit's 16 lanes of part[q]
+        const bool odd = q & 1, hi = q & 2;
+        const float s0 = odd ? part[0] : part[1], s1 = odd ? part[2] : part[3];
+        const float k0 = odd ? part[1] : part[0], k1 = odd ? part[3] : part[2];
+        const float t0 = k0 + dppf<0xB1>(s0), t1 = k1 + dppf<0xB1>(s1);
+        const float give = hi ? t0 : t1, keep = hi ? t1 : t0;
+        float ge = keep + dppf<0x4E>(give);
+        ge += dppf<0x124>(ge);                                 // row_ror:4
+        ge += dppf<0x128>(ge);                                 // row_ror:8
+        const float gu = ge * ev * (1.0f - ev);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float guj = j == 0 ? quad_bcast<0>(gu) : j == 1 ? quad_bcast<1>(gu) : j == 2 ? quad_bcast<2>(gu) : quad_bcast<3>(gu);
+            const float evj = j == 0 ? quad_bcast<0>(ev) : j == 1 ? quad_bcast<1>(ev) : j == 2 ? quad_bcast<2>(ev) : quad_bcast<3>(ev);
+#pragma unroll
+            for (int i = 0; i < DL; ++i) {
+                const float t = tanh_f(own_pq[i] + pr[j][i]);
+                gZ[i] = fmaf(guj * w2[i], 1.0f - t * t, gZ[i]);
+                G[i] = fmaf(evj, gv[j][i], G[i]);
+                if constexpr (IN) sw2[i] = fmaf(guj, t, sw2[i]);
+            }
+            if constexpr (IN) sw2[DL] += guj;
+        }
+    }
+}
+
+constexpr int kRowHits = kQuadBlock / 16;             // 64 hits per workgroup
+inline unsigned grid_rows(int64_t n)
+{
+    const unsigned g = (unsigned)((n + kRowHits - 1) / kRowHits);
+    return g > 8 ? (g + 7) & ~7u : g;
+}
+template <int D> constexpr int kSwStride = D + 4;    // per hit: gW2 terms [D] | gb2 term | pad
+
+template <int F, int D>
+__global__ __launch_bounds__(kQuadBlock) void k_seg_bwdW(
+    const float *__restrict__ A, const float *__restrict__ B, const float *__restrict__ e,
+    const int32_t *__restrict__ in_ptr, const int32_t *__restrict__ in_eid, const int32_t *__restrict__ in_nbr,
+    const int32_t *__restrict__ out_ptr, const int32_t *__restrict__ out_eid, const int32_t *__restrict__ out_nbr,
+    const float *__restrict__ W2, float *__restrict__ G4, float *__restrict__ SW, int64_t n_hits)
+{
+    constexpr int DL = D / 16;
+    const int p = threadIdx.x & 15;
+    const int64_t n = xcd_block() * kRowHits + (threadIdx.x >> 4);
+    if (n >= n_hits) return;                            // (whole 16-lane rows leave together)
+    float gP[DL], gQ[DL], Gout[DL], Gin[DL], sw2[DL + 1], w2[DL], a[2 * DL], b[2 * DL], gp[DL];
+#pragma unroll
+    for (int i = 0; i < DL; ++i) {
+        gP[i] = gQ[i] = Gout[i] = Gin[i] = sw2[i] = 0.0f;
+        w2[i] = W2[p * DL + i];
+    }
+    sw2[DL] = 0.0f;
+    load_vec<2 * DL>(A + n * 3 * D + p * 2 * DL, a);
+    load_vec<2 * DL>(B + n * 3 * D + p * 2 * DL, b);
+    load_vec<DL>(A + n * 3 * D + 2 * D + p * DL, gp);
+    // segments starting here (n -> d): [Q | S | gp] of the end hits; then ending here: [P | R | gp]
+    row_walk<D, false>(out_ptr[n], out_ptr[n + 1], (int)n, p, out_nbr, out_eid, e, B, a, a + DL, gp, w2, gP, Gout, sw2);
+    row_walk<D, true>(in_ptr[n], in_ptr[n + 1], (int)n, p, in_nbr, in_eid, e, A, b, b + DL, gp, w2, gQ, Gin, sw2);
+    float out[4 * DL];
+#pragma unroll
+    for (int i = 0; i < DL; ++i) {
+        out[i] = gP[i]; out[DL + i] = gQ[i]; out[2 * DL + i] = Gout[i]; out[3 * DL + i] = Gin[i];
+    }
+    store_vec<4 * DL>(G4 + n * 4 * D + p * 4 * DL, out);
+    store_vec<DL>(SW + n * kSwStride<D> + p * DL, sw2);
+    if (p == 0) SW[n * kSwStride<D> + D] = sw2[DL];
+}
+
+template <int F, int D>
+__global__ __launch_bounds__(kBlock) void k_seg_finW(
+    const float *__restrict__ H, int ldh, const float *__restrict__ G4, const float *__restrict__ SW,
+    const float *__restrict__ W1, const float *__restrict__ W3, float *__restrict__ gH, float *__restrict__ gW1,
+    float *__restrict__ gb1, float *__restrict__ gW2, float *__restrict__ gb2, float *__restrict__ gW3,
+    int rep_stride, int64_t n_hits)
+{
+    gW1 = my_replica(gW1, rep_stride);
+    gb1 = my_replica(gb1, rep_stride);
+    gW2 = my_replica(gW2, rep_stride);
+    gb2 = my_replica(gb2, rep_stride);
+    gW3 = my_replica(gW3, rep_stride);
+    constexpr int C = Shape<F, D>::C, LDH = Shape<F, D>::LDH, DL = D / 16;
+    __shared__ __attribute__((aligned(16))) float lds[outer_lds_floats<D, C>()];
+    const int64_t n = xcd_block() * kBlock + threadIdx.x;
+    const bool active = n < n_hits;
+    float h[C], gh[LDH];
+#pragma unroll
+    for (int k = 0; k < C; ++k) h[k] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < LDH; ++k) gh[k] = 0.0f;
+    if (active) {
+        float hp[LDH];
+        load_row4<LDH / 4>(H + n * ldh, hp);
+#pragma unroll
+        for (int k = 0; k < C; ++k) h[k] = hp[k];
+        load_row4<LDH / 4>(gH + n * ldh, gh);
+    }
+    // the four per-hit vectors one at a time: m = 0 gP (W1a, gb1), 1 gQ (W1b), 2 Gout (W3a), 3 Gin (W3b)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        float v[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) v[i] = 0.0f;
+        if (active) {
+#pragma unroll
+            for (int pl = 0; pl < 16; ++pl) load_vec<DL>(G4 + n * 4 * D + pl * 4 * DL + m * DL, v + pl * DL);
+            const float *W = m < 2 ? W1 : W3;
+            const int ld = m < 2 ? 2 * C : 3 * C, c0 = (m & 1) * C;
+#pragma unroll
+            for (int k = 0; k < C; ++k) {
+                float s = 0.0f;
+#pragma unroll
+                for (int i = 0; i < D; ++i) s = fmaf(W[i * ld + c0 + k], v[i], s);
+                gh[k] += s;
+            }
+        }
+        if (m == 0) accum_outer_mfma<D, C>(v, h, active, gW1, 2 * C, 0, gb1, lds);
+        else if (m == 1) accum_outer_mfma<D, C>(v, h, active, gW1, 2 * C, C, nullptr, lds);
+        else if (m == 2) accum_outer_mfma<D, C>(v, h, active, gW3, 3 * C, 0, nullptr, lds);
+        else accum_outer_mfma<D, C>(v, h, active, gW3, 3 * C, C, nullptr, lds);
+    }
+    if (active) store_row4<LDH / 4>(gH + n * ldh, gh);
+    {   // gW2[D] | gb2 from the hits' terms: wave sums, then one writer per element of this workgroup's row
+        constexpr int NW = kBlock / 64, NS = D + 1;
+        float *red = lds;
+        __syncthreads();
+#pragma unroll 4
+        for (int i = 0; i < NS; ++i) {
+            float x = active ? SW[n * kSwStride<D> + i] : 0.0f;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+            if ((threadIdx.x & 63) == 0) red[(threadIdx.x >> 6) * NS + i] = x;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x <= D) {
+            float x = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) x += red[w * NS + threadIdx.x];
+            *((int)threadIdx.x < D ? gW2 + threadIdx.x : gb2) += x;
+        }
+    }
+}
+
 // gradient w.r.t. the scores a node pass consumed: ge[j] = <gmi[d], H[s]> + <gmo[s], H[d]>, zero for
 // padded segments (the whole-model backward folds this into k_edge_bwd; the per-module entry point
 // gnn_node_bwd hands it to the caller)
@@ -1097,7 +1416,7 @@ inline int64_t bwd_rows(int64_t N, int64_t E)
 }
 
 struct BwdWs {
-    float *PQ, *gu, *gHa, *gHb, *gmio, *rep, *tmp, *A, *B, *G4;
+    float *PQ, *gu, *gHa, *gHb, *gmio, *rep, *tmp, *A, *B, *G4, *SW;
     char *rep_end;
     int64_t rows;
     size_t bytes;
@@ -1128,6 +1447,7 @@ BwdWs carve_bwd(char *b, int64_t N, int64_t E, int ldh, int C, int D)
     w.A = take((size_t)N * 3 * D);           // [P | R | gp], [Q | S | gp] of the pull-form kernels
     w.B = take((size_t)N * 3 * D);
     w.G4 = take((size_t)N * 4 * D);           // [gP gQ Gout Gin] between k_seg_bwd4 and k_seg_fin
+    w.SW = take(D >= 32 ? (size_t)N * (D + 4) : 0);   // wide shapes: a hit's gW2 / gb2 terms (k_seg_bwdW -> k_seg_finW)
     w.bytes = off;
     return w;
 }
@@ -1200,7 +1520,28 @@ int backward_t(const gnn_graph_t *g, const gnn_params_t *p, int T, const float *
             }
             break;
         }
-        // (wide hidden layers: the per-pass kernels) node pass t-1 backward: H_{t-1}, e_{t-1} -> H_t
+        if constexpr (D >= 32) {
+            // wide hidden layers with the forward's kept hidden layers: pull form, 16 lanes per hit
+            if (Q_all && !getenv("GNN_BWD_WIDE_PER_PASS")) {
+                for (int u = t; u >= 1; --u) {
+                    const float *Hu = H_all + (size_t)u * N * LDH;
+                    const float *Hp = H_all + (size_t)(u - 1) * N * LDH;
+                    const float *ep = e_all + (size_t)(u - 1) * E;
+                    if (N > 0) {
+                        GNN_LAUNCH("k_hit_bwdW", (k_hit_bwdW<F, D>), grid_for(N), kBlock, s, Hp, Hu,
+                                   Q_all + (size_t)(u - 1) * N * D, LDH, p->W1, p->b1, p->W3, p->W4, gH, gHprev, w.A, w.B,
+                                   rp + GL::oW3, rp + GL::ob3, rp + GL::oW4, rp + GL::ob4, RS, N);
+                        GNN_LAUNCH("k_seg_bwdW", (k_seg_bwdW<F, D>), grid_rows(N), kQuadBlock, s, w.A, w.B, ep, g->in_ptr,
+                                   g->in_eid, g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, p->W2, w.G4, w.SW, N);
+                        GNN_LAUNCH("k_seg_finW", (k_seg_finW<F, D>), grid_for(N), kBlock, s, Hp, LDH, w.G4, w.SW, p->W1, p->W3,
+                                   gHprev, rp + GL::oW1, rp + GL::ob1, rp + GL::oW2, rp + GL::ob2, rp + GL::oW3, RS, N);
+                    }
+                    float *tmp = gH; gH = gHprev; gHprev = tmp;
+                }
+                break;
+            }
+        }
+        // (wide hidden layers without Q_all: the per-pass kernels) node pass t-1 backward: H_{t-1}, e_{t-1} -> H_t
         const float *Hp = H_all + (size_t)(t - 1) * N * LDH;
         const float *ep = e_all + (size_t)(t - 1) * E;
         if (N > 0) {

@@ -841,6 +841,34 @@ def test_bf16_matrix_core_hit_update(hip, F, D, T):
         assert np.abs(eg - ref).max() < TOL_BF16
 
 
+@pytest.mark.parametrize("F,D,T", [(3, 64, 2), (2, 32, 3), (3, 32, 1)])
+def test_wide_backward_on_sixteen_lanes_per_hit(hip, F, D, T, monkeypatch):
+    """hidden_dim 32 / 64 (the reference's toy, ACTS and mu200 models): the pull-form backward with 16
+    lanes per hit in the list walks (k_hit_bwdW / k_seg_bwdW / k_seg_finW) against the per-pass kernels
+    it replaces (GNN_BWD_WIDE_PER_PASS) - all ten gradients within 1e-5 of the largest entry (other
+    summation orders), ragged lists, a tiny graph, padded segments; bit-reproducible."""
+    from gnn_fpga_amd.model import SegmentClassifier
+    torch.manual_seed(5 * D + T)
+    b = HitGraphBatch.from_graphs([synth.layered_graph(2500, 21000, F, seed=31), synth.layered_graph(9, 11, F, n_layers=3, seed=32)])
+    src, dst = b.src.numpy().copy(), b.dst.numpy().copy()
+    src[7::13] = -1
+    dst[7::13] = -1
+    b = HitGraphBatch(b.X.numpy(), src, dst, hit_ptr=b.hit_ptr, seg_ptr=b.seg_ptr).cuda()
+    m = SegmentClassifier(input_dim=F, hidden_dim=D, n_iters=T).cuda()
+    w = [t.detach().contiguous() for t in m.state_dict().values()]
+    e_all, H_all, Q_all = hip.segclf_forward_train(b, w, F, D, T)
+    go = torch.randn(b.n_segments, device="cuda") / b.n_segments
+    monkeypatch.delenv("GNN_BWD_WIDE_PER_PASS", raising=False)
+    wide = hip.segclf_backward(b, w, F, D, T, e_all, H_all, go, Q_all=Q_all)
+    again = hip.segclf_backward(b, w, F, D, T, e_all, H_all, go, Q_all=Q_all)
+    monkeypatch.setenv("GNN_BWD_WIDE_PER_PASS", "1")
+    per_pass = hip.segclf_backward(b, w, F, D, T, e_all, H_all, go, Q_all=Q_all)
+    for a, a2, c in zip(wide, again, per_pass):
+        assert torch.equal(a, a2)
+        assert float(c.abs().max()) > 0
+        assert (a - c).abs().max().item() <= 1e-9 + 1e-5 * c.abs().max().item()
+
+
 @pytest.mark.parametrize("F,D,T", [(3, 64, 3), (2, 32, 4), (3, 32, 2)])
 def test_exact_wide_path_and_its_fallback(hip, F, D, T, monkeypatch):
     """hidden_dim 32 / 64 in fp32: the 16-lanes-per-hit kernel with the hit update on
