@@ -1237,6 +1237,12 @@ __global__ __launch_bounds__(kQuadBlock) void k_seg_bwdW(
     if (p == 0) SW[n * kSwStride<D> + D] = sw2[DL];
 }
 
+// Everything dense in this kernel is a product over the workgroup's 256 hits and runs on the matrix
+// cores in exact fp32 from ONE transposed staging of the operands: the outer-product sums
+// [D x 256] . [256 x (C + 1)] (as accum_outer_mfma) and gH += W^T v as [C x D] . [D x 256] - one lane
+// per hit with scalar weight operands streamed 68 KB of weights per wave through the scalar cache
+// (0.96 ms per launch at D = 64).  Wave w keeps the gh tiles of hits 64 w .. 64 w + 63 in registers
+// over the four vectors.
 template <int F, int D>
 __global__ __launch_bounds__(kBlock) void k_seg_finW(
     const float *__restrict__ H, int ldh, const float *__restrict__ G4, const float *__restrict__ SW,
@@ -1249,47 +1255,89 @@ __global__ __launch_bounds__(kBlock) void k_seg_finW(
     gW2 = my_replica(gW2, rep_stride);
     gb2 = my_replica(gb2, rep_stride);
     gW3 = my_replica(gW3, rep_stride);
-    constexpr int C = Shape<F, D>::C, LDH = Shape<F, D>::LDH, DL = D / 16;
-    __shared__ __attribute__((aligned(16))) float lds[outer_lds_floats<D, C>()];
-    const int64_t n = xcd_block() * kBlock + threadIdx.x;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    constexpr int C = Shape<F, D>::C, LDH = Shape<F, D>::LDH, DL = D / 16, RS = kOuterStride;
+    constexpr int RT = D / 16, CT = (C + 1 + 15) / 16, KT = (LDH + 15) / 16, ROWS = D + 16 * CT;
+    __shared__ __attribute__((aligned(16))) float lds[ROWS * RS];   // [v (D rows) | h (C) | ones | zero pad] x 256 hits
+    const int64_t n0 = xcd_block() * kBlock, n = n0 + threadIdx.x;
     const bool active = n < n_hits;
-    float h[C], gh[LDH];
-#pragma unroll
-    for (int k = 0; k < C; ++k) h[k] = 0.0f;
-#pragma unroll
-    for (int k = 0; k < LDH; ++k) gh[k] = 0.0f;
-    if (active) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r16 = lane & 15, g4 = lane >> 4;
+    {
         float hp[LDH];
-        load_row4<LDH / 4>(H + n * ldh, hp);
 #pragma unroll
-        for (int k = 0; k < C; ++k) h[k] = hp[k];
-        load_row4<LDH / 4>(gH + n * ldh, gh);
+        for (int k = 0; k < LDH; ++k) hp[k] = 0.0f;
+        if (active) load_row4<LDH / 4>(H + n * ldh, hp);
+#pragma unroll
+        for (int k = 0; k < C; ++k) lds[(D + k) * RS + threadIdx.x] = hp[k];
+        lds[(D + C) * RS + threadIdx.x] = active ? 1.0f : 0.0f;
+#pragma unroll
+        for (int k = C + 1; k < 16 * CT; ++k) lds[(D + k) * RS + threadIdx.x] = 0.0f;
     }
+    f4v cg[KT][4];                                       // gh rows 16 kt + 4 g4 + r of hits 16 (4 wv + ht) + r16
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht) cg[kt][ht] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
     // the four per-hit vectors one at a time: m = 0 gP (W1a, gb1), 1 gQ (W1b), 2 Gout (W3a), 3 Gin (W3b)
-#pragma unroll
+#pragma unroll 1
     for (int m = 0; m < 4; ++m) {
-        float v[D];
+        __syncthreads();                                 // the previous vector's readers are done
+        {
+            float v[D];
 #pragma unroll
-        for (int i = 0; i < D; ++i) v[i] = 0.0f;
-        if (active) {
+            for (int i = 0; i < D; ++i) v[i] = 0.0f;
+            if (active) {
 #pragma unroll
-            for (int pl = 0; pl < 16; ++pl) load_vec<DL>(G4 + n * 4 * D + pl * 4 * DL + m * DL, v + pl * DL);
-            const float *W = m < 2 ? W1 : W3;
-            const int ld = m < 2 ? 2 * C : 3 * C, c0 = (m & 1) * C;
+                for (int pl = 0; pl < 16; ++pl) load_vec<DL>(G4 + n * 4 * D + pl * 4 * DL + m * DL, v + pl * DL);
+            }
 #pragma unroll
-            for (int k = 0; k < C; ++k) {
-                float s = 0.0f;
+            for (int i = 0; i < D; ++i) lds[i * RS + threadIdx.x] = v[i];
+        }
+        __syncthreads();
+        const float *W = m < 2 ? W1 : W3;
+        float *gW = m < 2 ? gW1 : gW3;
+        const int ld = m < 2 ? 2 * C : 3 * C, c0 = (m & 1) * C;
+        // outer-product sums over the 256 hits: [v] . [h | 1]
+        for (int t = wv; t < RT * CT; t += kBlock / 64) {
+            const int it = t / CT, jt = t % CT;
+            const float *a = lds + (16 * it + r16) * RS + g4, *b = lds + (D + 16 * jt + r16) * RS + g4;
+            f4v c = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 8
+            for (int st = 0; st < kBlock / 4; ++st) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * st], b[4 * st], c, 0, 0, 0);
+            const int col = 16 * jt + r16;
 #pragma unroll
-                for (int i = 0; i < D; ++i) s = fmaf(W[i * ld + c0 + k], v[i], s);
-                gh[k] += s;
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * it + 4 * g4 + r;
+                const float x = r == 0 ? c.x : r == 1 ? c.y : r == 2 ? c.z : c.w;
+                if (col < C) gW[i * ld + c0 + col] += x;               // own row: the only writer
+                else if (col == C && m == 0) gb1[i] += x;
             }
         }
-        if (m == 0) accum_outer_mfma<D, C>(v, h, active, gW1, 2 * C, 0, gb1, lds);
-        else if (m == 1) accum_outer_mfma<D, C>(v, h, active, gW1, 2 * C, C, nullptr, lds);
-        else if (m == 2) accum_outer_mfma<D, C>(v, h, active, gW3, 3 * C, 0, nullptr, lds);
-        else accum_outer_mfma<D, C>(v, h, active, gW3, 3 * C, C, nullptr, lds);
+        // gH += W^T v for this wave's 64 hits
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            const int k = 16 * kt + r16;
+#pragma unroll 4
+            for (int st = 0; st < D / 4; ++st) {
+                const float aw = k < C ? W[(4 * st + g4) * ld + c0 + k] : 0.0f;
+                const float *bv = lds + (4 * st + g4) * RS + 64 * wv + r16;
+#pragma unroll
+                for (int ht = 0; ht < 4; ++ht)
+                    cg[kt][ht] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw, bv[16 * ht], cg[kt][ht], 0, 0, 0);
+            }
+        }
     }
-    if (active) store_row4<LDH / 4>(gH + n * ldh, gh);
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht) {
+            const int64_t nn = n0 + 64 * wv + 16 * ht + r16;
+            const int k0 = 16 * kt + 4 * g4;
+            if (nn < n_hits && k0 < LDH) {
+                f4v *dst = reinterpret_cast<f4v *>(gH + nn * ldh + k0);
+                *dst = *dst + cg[kt][ht];
+            }
+        }
     {   // gW2[D] | gb2 from the hits' terms: wave sums, then one writer per element of this workgroup's row
         constexpr int NW = kBlock / 64, NS = D + 1;
         float *red = lds;
