@@ -1053,6 +1053,12 @@ __device__ __forceinline__ float dppf(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 
+// All of it as exact fp32 matrix-core products over the workgroup's 256 hits (thread = hit only for
+// loading and staging; lane l of a product holds rows 4 (l >> 4) .. + 3 of hit column l & 15):
+//   phase 1  LDS [gr | q 1]:  gW4, gb4 += gr (x) [q 1];   gp = (W4^T gr) (1 - q^2)   (this wave's 64 hits)
+//   phase 2  LDS [gp | h 1]:  gW3c, gb3 += gp (x) [h 1];  gH_prev = W3c^T gp;  records P R Q S = W h (+ b1)
+// One lane per hit with scalar weight operands streamed 100 KB of weights per wave through the scalar
+// cache (0.35 ms per launch at D = 64).
 template <int F, int D>
 __global__ __launch_bounds__(kBlock) void k_hit_bwdW(
     const float *__restrict__ H, const float *__restrict__ Hn, const float *__restrict__ Qk, int ldh,
@@ -1065,76 +1071,176 @@ __global__ __launch_bounds__(kBlock) void k_hit_bwdW(
     gb3 = my_replica(gb3, rep_stride);
     gW4 = my_replica(gW4, rep_stride);
     gb4 = my_replica(gb4, rep_stride);
-    constexpr int C = Shape<F, D>::C, LDH = Shape<F, D>::LDH, DL = D / 16;
-    __shared__ __attribute__((aligned(16))) float lds[outer_lds_floats<D, C>()];
-    const int64_t n = xcd_block() * kBlock + threadIdx.x;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    constexpr int C = Shape<F, D>::C, LDH = Shape<F, D>::LDH, DL = D / 16, RS = kOuterStride;
+    constexpr int RT = D / 16, CT = (C + 1 + 15) / 16, KT = (LDH + 15) / 16, YR = 16 * CT;
+    static_assert(D + 1 <= YR, "the [q | 1] block fits the [h | 1] rows");
+    __shared__ __attribute__((aligned(16))) float lds[(D + YR) * RS];
+    float *X = lds, *Y = lds + D * RS;
+    const int64_t n0 = xcd_block() * kBlock, n = n0 + threadIdx.x;
     const bool active = n < n_hits;
-    float h[C], q[D], gr[D], gp[D];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r16 = lane & 15, g4 = lane >> 4;
+    const int hcol = 64 * wv + r16;                      // + 16 ht: this lane's hit column of tile ht
+    // ---- phase 1 staging: X = gr, Y = [q | 1 | 0]
+    {
+        float qv[D], hn[D], gn[D];
 #pragma unroll
-    for (int k = 0; k < C; ++k) h[k] = 0.0f;
-#pragma unroll
-    for (int i = 0; i < D; ++i) q[i] = gr[i] = gp[i] = 0.0f;
-    if (active) {
-        {
-            float hp[LDH];
-            load_row4<LDH / 4>(H + n * ldh, hp);
-#pragma unroll
-            for (int k = 0; k < C; ++k) h[k] = hp[k];
-        }
-        load_row4<D / 4>(Qk + n * D, q);
-        {
-            float hn[D], gn[D];
+        for (int i = 0; i < D; ++i) qv[i] = hn[i] = gn[i] = 0.0f;
+        if (active) {
+            load_row4<D / 4>(Qk + n * D, qv);
             load_row4<D / 4>(Hn + n * ldh, hn);
             load_row4<D / 4>(gHn + n * ldh, gn);
-#pragma unroll
-            for (int i = 0; i < D; ++i) gr[i] = gn[i] * (1.0f - hn[i] * hn[i]);
         }
 #pragma unroll
-        for (int k = 0; k < D; ++k) {
-            float s = 0.0f;
-#pragma unroll
-            for (int i = 0; i < D; ++i) s = fmaf(W4[i * D + k], gr[i], s);
-            gp[k] = s * (1.0f - q[k] * q[k]);
+        for (int i = 0; i < D; ++i) {
+            X[i * RS + threadIdx.x] = gn[i] * (1.0f - hn[i] * hn[i]);
+            Y[i * RS + threadIdx.x] = qv[i];
         }
-        {
-            float gh[LDH];
+        Y[D * RS + threadIdx.x] = active ? 1.0f : 0.0f;
 #pragma unroll
-            for (int k = 0; k < LDH; ++k) gh[k] = 0.0f;
-#pragma unroll
-            for (int k = 0; k < C; ++k) {
-                float s = 0.0f;
-#pragma unroll
-                for (int i = 0; i < D; ++i) s = fmaf(W3[i * 3 * C + 2 * C + k], gp[i], s);
-                gh[k] = s;
-            }
-            store_row4<LDH / 4>(gH + n * ldh, gh);                 // gHself initialises gH_prev
-        }
-        // records, one lane share [P(DL) R(DL)] / [Q(DL) S(DL)] at a time (stored as it is finished)
-        float *Ar = A + n * 3 * D, *Br = B + n * 3 * D;
-#pragma unroll 1
-        for (int pl = 0; pl < 16; ++pl) {
-            float a[2 * DL], b[2 * DL];
-#pragma unroll
-            for (int j = 0; j < DL; ++j) {
-                const int i = pl * DL + j;
-                float pp = b1[i], qq = 0.0f, rr = 0.0f, ss = 0.0f;
-#pragma unroll
-                for (int k = 0; k < C; ++k) {
-                    pp = fmaf(W1[i * 2 * C + k], h[k], pp);
-                    qq = fmaf(W1[i * 2 * C + C + k], h[k], qq);
-                    rr = fmaf(W3[i * 3 * C + k], h[k], rr);
-                    ss = fmaf(W3[i * 3 * C + C + k], h[k], ss);
-                }
-                a[j] = pp; a[DL + j] = rr; b[j] = qq; b[DL + j] = ss;
-            }
-            store_vec<2 * DL>(Ar + pl * 2 * DL, a);
-            store_vec<2 * DL>(Br + pl * 2 * DL, b);
-        }
-        store_row4<D / 4>(Ar + 2 * D, gp);
-        store_row4<D / 4>(Br + 2 * D, gp);
+        for (int k = D + 1; k < YR; ++k) Y[k * RS + threadIdx.x] = 0.0f;
     }
-    accum_outer_mfma<D, C>(gp, h, active, gW3, 3 * C, 2 * C, gb3, lds);
-    accum_outer_mfma<D, D>(gr, q, active, gW4, D, 0, gb4, lds);
+    __syncthreads();
+    auto outer = [&](int ncol, float *g, int ldg, int col0, float *gb) {      // X (x) Y[0 .. ncol) | ones at ncol
+        const int ct = (ncol + 1 + 15) / 16;
+        for (int t = wv; t < RT * ct; t += kBlock / 64) {
+            const int it = t / ct, jt = t % ct;
+            const float *a = X + (16 * it + r16) * RS + g4, *b = Y + (16 * jt + r16) * RS + g4;
+            f4v c = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 8
+            for (int st = 0; st < kBlock / 4; ++st) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * st], b[4 * st], c, 0, 0, 0);
+            const int col = 16 * jt + r16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * it + 4 * g4 + r;
+                const float x = r == 0 ? c.x : r == 1 ? c.y : r == 2 ? c.z : c.w;
+                if (col < ncol) g[i * ldg + col0 + col] += x;               // own row: the only writer
+                else if (col == ncol) gb[i] += x;
+            }
+        }
+    };
+    outer(D, gW4, D, 0, gb4);
+    f4v gp[RT][4];                                       // gp rows 16 kt + 4 g4 + r of hits hcol + 16 ht
+#pragma unroll
+    for (int kt = 0; kt < RT; ++kt) {
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht) gp[kt][ht] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 4
+        for (int st = 0; st < D / 4; ++st) {
+            const float aw = W4[(4 * st + g4) * D + 16 * kt + r16];
+            const float *bv = X + (4 * st + g4) * RS + hcol;
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht) gp[kt][ht] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw, bv[16 * ht], gp[kt][ht], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht) {
+            const float *qy = Y + (16 * kt + 4 * g4) * RS + hcol + 16 * ht;
+            const float q0 = qy[0], q1 = qy[RS], q2 = qy[2 * RS], q3 = qy[3 * RS];
+            gp[kt][ht].x *= 1.0f - q0 * q0; gp[kt][ht].y *= 1.0f - q1 * q1;
+            gp[kt][ht].z *= 1.0f - q2 * q2; gp[kt][ht].w *= 1.0f - q3 * q3;
+        }
+    }
+    __syncthreads();                                     // everyone is done with gr and q
+    // ---- phase 2 staging: X = gp (from the product's layout), Y = [h | 1 | 0]
+#pragma unroll
+    for (int kt = 0; kt < RT; ++kt)
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht) {
+            float *x = X + (16 * kt + 4 * g4) * RS + hcol + 16 * ht;
+            x[0] = gp[kt][ht].x; x[RS] = gp[kt][ht].y; x[2 * RS] = gp[kt][ht].z; x[3 * RS] = gp[kt][ht].w;
+        }
+    {
+        float hp[LDH];
+#pragma unroll
+        for (int k = 0; k < LDH; ++k) hp[k] = 0.0f;
+        if (active) load_row4<LDH / 4>(H + n * ldh, hp);
+#pragma unroll
+        for (int k = 0; k < C; ++k) Y[k * RS + threadIdx.x] = hp[k];
+        Y[C * RS + threadIdx.x] = active ? 1.0f : 0.0f;
+#pragma unroll
+        for (int k = C + 1; k < YR; ++k) Y[k * RS + threadIdx.x] = 0.0f;
+    }
+    __syncthreads();
+    outer(C, gW3 + 2 * C, 3 * C, 0, gb3);
+    // gH_prev = W3c^T gp (initialises the row; k_seg_finW adds the segment terms)
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        f4v c[4];
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht) c[ht] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
+        const int k = 16 * kt + r16;
+#pragma unroll 4
+        for (int st = 0; st < D / 4; ++st) {
+            const float aw = k < C ? W3[(4 * st + g4) * 3 * C + 2 * C + k] : 0.0f;
+            const float *bv = X + (4 * st + g4) * RS + hcol;
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht) c[ht] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw, bv[16 * ht], c[ht], 0, 0, 0);
+        }
+        const int k0 = 16 * kt + 4 * g4;
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht) {
+            const int64_t nn = n0 + hcol + 16 * ht;
+            if (nn < n_hits && k0 < LDH) *reinterpret_cast<f4v *>(gH + nn * ldh + k0) = c[ht];
+        }
+    }
+    // records: [P R] -> A, [Q S] -> B (rows i of the products = dims; the ones row of Y carries b1 into P)
+    constexpr int KS = (C + 1 + 3) / 4;                  // k-steps over [h | 1]
+#pragma unroll 1
+    for (int it = 0; it < RT; ++it) {
+        const int i = 16 * it + r16;
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {           // 0: P, R (W1a, W3a) -> A;  1: Q, S (W1b, W3b) -> B
+            f4v c1[4], c3[4];
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht) c1[ht] = c3[ht] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 4
+            for (int st = 0; st < KS; ++st) {
+                const int kk = 4 * st + g4;
+                float a1 = 0.0f, a3 = 0.0f;
+                if (kk < C) {
+                    a1 = W1[i * 2 * C + half * C + kk];
+                    a3 = W3[i * 3 * C + half * C + kk];
+                } else if (kk == C && half == 0) {
+                    a1 = b1[i];
+                }
+                const float *bv = Y + kk * RS + hcol;
+#pragma unroll
+                for (int ht = 0; ht < 4; ++ht) {
+                    const float bb = bv[16 * ht];
+                    c1[ht] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bb, c1[ht], 0, 0, 0);
+                    c3[ht] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, bb, c3[ht], 0, 0, 0);
+                }
+            }
+            float *REC = half == 0 ? A : B;
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht) {
+                const int64_t nn = n0 + hcol + 16 * ht;
+                if (nn >= n_hits) continue;
+                float *rec = REC + nn * 3 * D;
+                // this lane holds dims i0 .. i0 + 3 (i0 = 16 it + 4 g4): lane share i0 / DL (+1 at DL = 2)
+                const int i0 = 16 * it + 4 * g4;
+                if constexpr (DL == 4) {
+                    *reinterpret_cast<f4v *>(rec + (i0 / 4) * 8) = c1[ht];
+                    *reinterpret_cast<f4v *>(rec + (i0 / 4) * 8 + 4) = c3[ht];
+                } else {
+                    static_assert(DL == 2 || DL == 4, "record shares of 2 or 4 dims");
+                    *reinterpret_cast<f4v *>(rec + (i0 / 2) * 4) = f4v{c1[ht].x, c1[ht].y, c3[ht].x, c3[ht].y};
+                    *reinterpret_cast<f4v *>(rec + (i0 / 2 + 1) * 4) = f4v{c1[ht].z, c1[ht].w, c3[ht].z, c3[ht].w};
+                }
+            }
+        }
+    }
+    // the gp field of both records (natural dim order)
+#pragma unroll
+    for (int kt = 0; kt < RT; ++kt)
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht) {
+            const int64_t nn = n0 + hcol + 16 * ht;
+            if (nn < n_hits) {
+                *reinterpret_cast<f4v *>(A + nn * 3 * D + 2 * D + 16 * kt + 4 * g4) = gp[kt][ht];
+                *reinterpret_cast<f4v *>(B + nn * 3 * D + 2 * D + 16 * kt + 4 * g4) = gp[kt][ht];
+            }
+        }
 }
 
 // one direction of a hit's pull, 16 lanes per hit (see quad_walk for the roles of the arguments)
