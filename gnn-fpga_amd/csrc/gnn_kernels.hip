@@ -262,6 +262,249 @@ __global__ __launch_bounds__(kBlock) void k_node(
 }
 
 // ---------------------------------------------------------------------------------------------
+// node pass for WIDE hidden layers (hidden_dim 32 / 64) at detector size, in two kernels
+// ---------------------------------------------------------------------------------------------
+// k_node keeps M = [mi | mo | h] (3C = 201 floats at D = 64) in one lane's registers and feeds the MLP
+// scalar weight operands: 100 KB of weights per wave through the scalar cache, 0.42 ms per pass at
+// 50 k hits.  Here (1) k_node_walkW: 16 lanes per hit walk the two lists (lane p gathers 16-byte
+// chunk p of a neighbour's row; list entries and scores one per lane, broadcast in the quad) and
+// store mi | mo; (2) k_node_mlpW: the MLP of 256 hits as exact fp32 matrix-core products
+// (v_mfma_f32_16x16x4_f32 accumulates in k order from the bias: the same fma chain as k_node's loops)
+// from transposed LDS stagings of mi, mo, h, then q, then [H' | x].
+template <int SEL>
+__device__ __forceinline__ int qb_i(int x) { return __builtin_amdgcn_mov_dpp(x, SEL * 0x55, 0xf, 0xf, true); }
+template <int SEL>
+__device__ __forceinline__ float qb_f(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), SEL * 0x55, 0xf, 0xf, true));
+}
+
+template <int LDH>
+__device__ __forceinline__ void row16_walk(int beg, int end, int n, int p, const int32_t *__restrict__ nbr,
+                                           const int32_t *__restrict__ eid, const float *__restrict__ e,
+                                           const float *__restrict__ H, int ldh, float (*acc)[4])
+{
+    constexpr int NCH = LDH / 4, CPL = (NCH + 15) / 16;
+    const int q = p & 3;
+    for (int k = beg; k < end; k += 4) {
+        const int kk = k + q;
+        const bool ok = kk < end;
+        const int nb = ok ? nbr[kk] : n;
+        const float ev = ok ? e[eid[kk]] : 0.0f;
+        float4 r[4][CPL];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nbj = j == 0 ? qb_i<0>(nb) : j == 1 ? qb_i<1>(nb) : j == 2 ? qb_i<2>(nb) : qb_i<3>(nb);
+            const float4 *row = reinterpret_cast<const float4 *>(H + (int64_t)nbj * ldh);
+#pragma unroll
+            for (int c = 0; c < CPL; ++c)
+                r[j][c] = (p + 16 * c < NCH) ? row[p + 16 * c] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float w = j == 0 ? qb_f<0>(ev) : j == 1 ? qb_f<1>(ev) : j == 2 ? qb_f<2>(ev) : qb_f<3>(ev);
+            if (k + j < end) {                              // (row-uniform; the sums are those of k_node)
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    acc[c][0] = fmaf(w, r[j][c].x, acc[c][0]);
+                    acc[c][1] = fmaf(w, r[j][c].y, acc[c][1]);
+                    acc[c][2] = fmaf(w, r[j][c].z, acc[c][2]);
+                    acc[c][3] = fmaf(w, r[j][c].w, acc[c][3]);
+                }
+            }
+        }
+    }
+}
+
+constexpr int kWalkBlock = 1024, kWalkHits = kWalkBlock / 16;
+constexpr int64_t kNodeWideMinHits = 2048;
+inline unsigned grid_walk(int64_t n)
+{
+    const unsigned g = (unsigned)((n + kWalkHits - 1) / kWalkHits);
+    return g > 8 ? (g + 7) & ~7u : g;
+}
+
+template <int F, int D>
+__global__ __launch_bounds__(kWalkBlock) void k_node_walkW(
+    const float *__restrict__ H, int ldh, const float *__restrict__ e,
+    const int32_t *__restrict__ in_ptr, const int32_t *__restrict__ in_eid, const int32_t *__restrict__ in_nbr,
+    const int32_t *__restrict__ out_ptr, const int32_t *__restrict__ out_eid, const int32_t *__restrict__ out_nbr,
+    float *__restrict__ M, int64_t n_hits)
+{
+    constexpr int LDH = Shape<F, D>::LDH, NCH = LDH / 4, CPL = (NCH + 15) / 16;
+    const int p = threadIdx.x & 15;
+    const int64_t n = xcd_block() * kWalkHits + (threadIdx.x >> 4);
+    if (n >= n_hits) return;                            // (whole 16-lane rows leave together)
+    float mi[CPL][4], mo[CPL][4];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mi[c][i] = mo[c][i] = 0.0f;
+    row16_walk<LDH>(in_ptr[n], in_ptr[n + 1], (int)n, p, in_nbr, in_eid, e, H, ldh, mi);       // model.py:117-118
+    row16_walk<LDH>(out_ptr[n], out_ptr[n + 1], (int)n, p, out_nbr, out_eid, e, H, ldh, mo);   // model.py:116,119
+    float4 *row = reinterpret_cast<float4 *>(M + n * 2 * LDH);
+#pragma unroll
+    for (int c = 0; c < CPL; ++c)
+        if (p + 16 * c < NCH) {
+            row[p + 16 * c] = make_float4(mi[c][0], mi[c][1], mi[c][2], mi[c][3]);
+            row[NCH + p + 16 * c] = make_float4(mo[c][0], mo[c][1], mo[c][2], mo[c][3]);
+        }
+}
+
+template <int F, int D>
+__global__ __launch_bounds__(kBlock) void k_node_mlpW(
+    const float *__restrict__ H, int ldh, const float *__restrict__ M, const float *__restrict__ W3,
+    const float *__restrict__ b3, const float *__restrict__ W4, const float *__restrict__ b4,
+    const float *__restrict__ W1, const float *__restrict__ b1, float *__restrict__ Hn, int ldhn,
+    float *__restrict__ PQ, float *__restrict__ Qkeep, int64_t n_hits)
+{
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    constexpr int C = Shape<F, D>::C, LDH = Shape<F, D>::LDH, RS = kBlock + 4;
+    constexpr int RT = D / 16, KS = (C + 3) / 4, ROWS = 4 * KS > D ? 4 * KS : D;
+    __shared__ __attribute__((aligned(16))) float lds[ROWS * RS];   // [k][hit]: one operand block at a time
+    const int64_t n0 = xcd_block() * kBlock, n = n0 + threadIdx.x;
+    const bool active = n < n_hits;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r16 = lane & 15, g4 = lane >> 4;
+    const int hcol = 64 * wv + r16;
+    float hp[LDH];
+#pragma unroll
+    for (int k = 0; k < LDH; ++k) hp[k] = 0.0f;
+    if (active) {
+        const float4 *row = reinterpret_cast<const float4 *>(H + n * ldh);
+#pragma unroll
+        for (int v = 0; v < LDH / 4; ++v) {
+            const float4 a = row[v];
+            hp[4 * v] = a.x; hp[4 * v + 1] = a.y; hp[4 * v + 2] = a.z; hp[4 * v + 3] = a.w;
+        }
+    }
+    // ---- q = tanh(W3 [mi | mo | h] + b3): three k-chunks of C rows            (model.py:120)
+    f4v cq[RT][4];
+#pragma unroll
+    for (int it = 0; it < RT; ++it) {
+        const f4v bias = *reinterpret_cast<const f4v *>(b3 + 16 * it + 4 * g4);
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht) cq[it][ht] = bias;
+    }
+#pragma unroll 1
+    for (int chunk = 0; chunk < 3; ++chunk) {
+        if (chunk) __syncthreads();
+        {
+            float v[LDH];
+            if (chunk < 2) {
+#pragma unroll
+                for (int k = 0; k < LDH; ++k) v[k] = 0.0f;
+                if (active) {
+                    const float4 *row = reinterpret_cast<const float4 *>(M + n * 2 * LDH + chunk * LDH);
+#pragma unroll
+                    for (int u = 0; u < LDH / 4; ++u) {
+                        const float4 a = row[u];
+                        v[4 * u] = a.x; v[4 * u + 1] = a.y; v[4 * u + 2] = a.z; v[4 * u + 3] = a.w;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < LDH; ++k) v[k] = hp[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 4 * KS; ++k) lds[k * RS + threadIdx.x] = k < C ? v[k < LDH ? k : 0] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < RT; ++it) {
+            const int i = 16 * it + r16;
+#pragma unroll 4
+            for (int st = 0; st < KS; ++st) {
+                const int kk = 4 * st + g4;
+                const float aw = kk < C ? W3[i * 3 * C + chunk * C + kk] : 0.0f;
+                const float *bv = lds + kk * RS + hcol;
+#pragma unroll
+                for (int ht = 0; ht < 4; ++ht) cq[it][ht] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw, bv[16 * ht], cq[it][ht], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < RT; ++it)
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht) {
+            const f4v q = {tanh_f(cq[it][ht].x), tanh_f(cq[it][ht].y), tanh_f(cq[it][ht].z), tanh_f(cq[it][ht].w)};
+            float *x = lds + (16 * it + 4 * g4) * RS + hcol + 16 * ht;
+            x[0] = q.x; x[RS] = q.y; x[2 * RS] = q.z; x[3 * RS] = q.w;
+            const int64_t nn = n0 + hcol + 16 * ht;
+            if (Qkeep && nn < n_hits) *reinterpret_cast<f4v *>(Qkeep + nn * D + 16 * it + 4 * g4) = q;
+        }
+    __syncthreads();
+    // ---- H' = tanh(W4 q + b4)                                                   (model.py:94-98)
+    f4v hn[RT][4];
+#pragma unroll
+    for (int it = 0; it < RT; ++it) {
+        const f4v bias = *reinterpret_cast<const f4v *>(b4 + 16 * it + 4 * g4);
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht) hn[it][ht] = bias;
+        const int i = 16 * it + r16;
+#pragma unroll 4
+        for (int st = 0; st < D / 4; ++st) {
+            const float aw = W4[i * D + 4 * st + g4];
+            const float *bv = lds + (4 * st + g4) * RS + hcol;
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht) hn[it][ht] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw, bv[16 * ht], hn[it][ht], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht) {
+            hn[it][ht] = f4v{tanh_f(hn[it][ht].x), tanh_f(hn[it][ht].y), tanh_f(hn[it][ht].z), tanh_f(hn[it][ht].w)};
+            const int64_t nn = n0 + hcol + 16 * ht;
+            if (nn < n_hits) *reinterpret_cast<f4v *>(Hn + nn * ldhn + 16 * it + 4 * g4) = hn[it][ht];
+        }
+    }
+    if (active) {                                        // skip concat of X (and the row's padding), model.py:154
+#pragma unroll
+        for (int v = D / 4; v < LDH / 4; ++v)
+            reinterpret_cast<float4 *>(Hn + n * ldhn)[v] = make_float4(hp[4 * v], hp[4 * v + 1], hp[4 * v + 2], hp[4 * v + 3]);
+    }
+    if (!PQ) return;                                     // (kernel-uniform)
+    // ---- P = W1a [H' | x] + b1, Q = W1b [H' | x] for the next edge pass
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < RT; ++it)
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht) {
+            float *x = lds + (16 * it + 4 * g4) * RS + hcol + 16 * ht;
+            x[0] = hn[it][ht].x; x[RS] = hn[it][ht].y; x[2 * RS] = hn[it][ht].z; x[3 * RS] = hn[it][ht].w;
+        }
+#pragma unroll
+    for (int k = D; k < 4 * KS; ++k) lds[k * RS + threadIdx.x] = k < C ? hp[k < LDH ? k : 0] : 0.0f;
+    __syncthreads();
+#pragma unroll 1
+    for (int it = 0; it < RT; ++it) {
+        const int i = 16 * it + r16;
+        f4v cp[4], cqq[4];
+        const f4v bias = *reinterpret_cast<const f4v *>(b1 + 16 * it + 4 * g4);
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht) { cp[ht] = bias; cqq[ht] = f4v{0.0f, 0.0f, 0.0f, 0.0f}; }
+#pragma unroll 4
+        for (int st = 0; st < KS; ++st) {
+            const int kk = 4 * st + g4;
+            const float ap = kk < C ? W1[i * 2 * C + kk] : 0.0f, aq = kk < C ? W1[i * 2 * C + C + kk] : 0.0f;
+            const float *bv = lds + kk * RS + hcol;
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht) {
+                const float bb = bv[16 * ht];
+                cp[ht] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap, bb, cp[ht], 0, 0, 0);
+                cqq[ht] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq, bb, cqq[ht], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht) {
+            const int64_t nn = n0 + hcol + 16 * ht;
+            if (nn < n_hits) {
+                *reinterpret_cast<f4v *>(PQ + nn * 2 * D + 16 * it + 4 * g4) = cp[ht];
+                *reinterpret_cast<f4v *>(PQ + nn * 2 * D + D + 16 * it + 4 * g4) = cqq[ht];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // small events: the WHOLE forward of one graph in one workgroup, one launch for the batch
 // ---------------------------------------------------------------------------------------------
 // The per-module kernels above cost one launch per pass (2T + 2 launches, ~5 us each on the
@@ -617,17 +860,27 @@ int run_edge(const int32_t *src, const int32_t *dst, const float *PQ, const floa
 template <int F, int D>
 int run_node(const float *H, int ldh, const float *e, const gnn_graph_t *g, const float *W3,
              const float *b3, const float *W4, const float *b4, const float *W1, const float *b1,
-             float *Hn, int ldhn, float *PQ, hipStream_t s, float *Qkeep = nullptr)
+             float *Hn, int ldhn, float *PQ, hipStream_t s, float *Qkeep = nullptr, float *Mbuf = nullptr)
 {
-    if (g->n_hits > 0)
-        GNN_LAUNCH("k_node", (k_node<F, D>), grid_for(g->n_hits), kBlock, s, H, ldh, e, g->in_ptr,
-                   g->in_eid, g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, W3, b3, W4, b4, W1, b1,
-                   Hn, ldhn, PQ, Qkeep, g->n_hits);
+    if (g->n_hits <= 0) return 0;
+    if constexpr (D >= 32) {
+        // wide hidden layers at detector size: 16-lane list walk + matrix-core MLP (Mbuf: [n_hits, 2 ldh] scratch)
+        if (Mbuf && g->n_hits >= kNodeWideMinHits && ldh == Shape<F, D>::LDH && !getenv("GNN_NODE_ONE_LANE")) {
+            GNN_LAUNCH("k_node_walkW", (k_node_walkW<F, D>), grid_walk(g->n_hits), kWalkBlock, s, H, ldh, e, g->in_ptr,
+                       g->in_eid, g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, Mbuf, g->n_hits);
+            GNN_LAUNCH("k_node_mlpW", (k_node_mlpW<F, D>), grid_for(g->n_hits), kBlock, s, H, ldh, Mbuf, W3, b3, W4, b4,
+                       W1, b1, Hn, ldhn, PQ, Qkeep, g->n_hits);
+            return 0;
+        }
+    }
+    GNN_LAUNCH("k_node", (k_node<F, D>), grid_for(g->n_hits), kBlock, s, H, ldh, e, g->in_ptr,
+               g->in_eid, g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, W3, b3, W4, b4, W1, b1,
+               Hn, ldhn, PQ, Qkeep, g->n_hits);
     return 0;
 }
 
 struct Workspace {
-    float *Ha, *Hb, *PQ, *e;
+    float *Ha, *Hb, *PQ, *e, *M;
     size_t bytes;
 };
 
@@ -641,6 +894,8 @@ Workspace carve(void *base, int64_t n_hits, int64_t n_seg, int ldh, int D)
     w.Hb = reinterpret_cast<float *>(b + off); off += hbytes;
     w.PQ = reinterpret_cast<float *>(b + off); off += align256((size_t)n_hits * 2 * D * sizeof(float));
     w.e = reinterpret_cast<float *>(b + off);  off += align256((size_t)n_seg * sizeof(float));
+    w.M = reinterpret_cast<float *>(b + off);             // wide shapes: [mi | mo] between k_node_walkW and k_node_mlpW
+    off += align256(D >= 32 ? (size_t)n_hits * 2 * ldh * sizeof(float) : 0);
     w.bytes = off;
     return w;
 }
@@ -675,7 +930,7 @@ int forward_impl(const gnn_graph_t *g, const gnn_params_t *p, int n_iters, float
             break;
         }
         rc = run_node<F, D>(H, LDH, e_t, g, p->W3, p->b3, p->W4, p->b4, p->W1, p->b1, Hn, LDH,
-                            w.PQ, s, Q_all ? Q_all + (size_t)t * N * D : nullptr);
+                            w.PQ, s, Q_all ? Q_all + (size_t)t * N * D : nullptr, w.M);
         if (rc) return rc;
         if (H_all) {
             H = Hn;

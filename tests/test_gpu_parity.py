@@ -842,6 +842,37 @@ def test_bf16_matrix_core_hit_update(hip, F, D, T):
 
 
 @pytest.mark.parametrize("F,D,T", [(3, 64, 2), (2, 32, 3), (3, 32, 1)])
+def test_wide_node_pass_walk_and_matrix_core_mlp(hip, F, D, T, monkeypatch):
+    """hidden_dim 32 / 64 at detector size: the node pass as a 16-lanes-per-hit list walk (k_node_walkW)
+    plus the MLP of 256 hits as exact fp32 matrix-core products (k_node_mlpW) against the one-lane
+    k_node it replaces (GNN_NODE_ONE_LANE): every kept tensor of the training forward within 1e-6
+    (k-ordered fp32 fma chains from the bias, like k_node's loops), scores within 1e-5 of the C oracle;
+    deterministic; ragged lists, hits without segments, padded segments, a tiny graph in the batch."""
+    from gnn_fpga_amd.model import SegmentClassifier
+    torch.manual_seed(7 * D + T)
+    graphs = [synth.layered_graph(2600, 22000, F, seed=41), synth.layered_graph(7, 6, F, n_layers=3, seed=42)]
+    b = HitGraphBatch.from_graphs(graphs)
+    src, dst = b.src.numpy().copy(), b.dst.numpy().copy()
+    src[3::17] = -1
+    dst[3::17] = -1
+    b = HitGraphBatch(b.X.numpy(), src, dst, hit_ptr=b.hit_ptr, seg_ptr=b.seg_ptr).cuda()
+    m = SegmentClassifier(input_dim=F, hidden_dim=D, n_iters=T).cuda()
+    params = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    w = [t.detach().contiguous() for t in m.state_dict().values()]
+    monkeypatch.delenv("GNN_NODE_ONE_LANE", raising=False)
+    wide = hip.segclf_forward_train(b, w, F, D, T)
+    again = hip.segclf_forward_train(b, w, F, D, T)
+    monkeypatch.setenv("GNN_NODE_ONE_LANE", "1")
+    one = hip.segclf_forward_train(b, w, F, D, T)
+    for a, a2, c in zip(wide, again, one):
+        assert torch.equal(a, a2)
+        assert (a - c).abs().max().item() < 1e-6
+    valid = src >= 0
+    ref = index_c.segment_classifier(b.X.cpu().numpy(), src[valid], dst[valid], params, T)
+    assert np.abs(wide[0][T].cpu().numpy()[valid] - ref).max() < TOL
+
+
+@pytest.mark.parametrize("F,D,T", [(3, 64, 2), (2, 32, 3), (3, 32, 1)])
 def test_wide_backward_on_sixteen_lanes_per_hit(hip, F, D, T, monkeypatch):
     """hidden_dim 32 / 64 (the reference's toy, ACTS and mu200 models): the pull-form backward with 16
     lanes per hit in the list walks (k_hit_bwdW / k_seg_bwdW / k_seg_finW) against the per-pass kernels
