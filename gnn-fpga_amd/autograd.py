@@ -50,7 +50,7 @@ def training_batch(model, batch, use_events):
     model.level_order_training: True (default: always), False (never), "auto" (from the second time
     the same batch object is trained on)."""
     policy = getattr(model, "level_order_training", True)
-    if not policy or batch.n_hits < 20000 or model.hidden_dim > 16:
+    if not policy or batch.n_hits < 20000:
         return batch
     if policy == "auto" and getattr(batch, "_twin", None) is None:
         # the twin costs a plan build and two sorts (10 ms at 3.2 M segments, ten steps' worth): it is

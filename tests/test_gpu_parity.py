@@ -730,21 +730,23 @@ def test_direct_training_step_equals_the_autograd_step(hip, kind):
     assert not any(p.grad.grad_fn is not None for p in m.parameters())
 
 
-def test_training_on_the_level_ordered_twin(hip):
+@pytest.mark.parametrize("D", [8, 32])
+def test_training_on_the_level_ordered_twin(hip, D):
     """Detector-size batches train on their level-ordered twin (hits renumbered in plan order: the
     gathers of the training kernels become L2-local): same loss and gradients as in the caller's
-    order (1e-4 of the largest entry: the sums run in another order), bit-reproducible."""
+    order (1e-4 of the largest entry: the sums run in another order), bit-reproducible.  D = 32: the
+    16-lanes-per-hit kernels of the wide shapes on the twin."""
     from gnn_fpga_amd.loss import BCELoss
     from gnn_fpga_amd.model import SegmentClassifier
     torch.manual_seed(6)
-    graphs = [synth.layered_graph(10000, 100000, 3, seed=90 + s) for s in range(4)]
+    graphs = [synth.layered_graph(10000, 100000, 3, seed=90 + s) for s in range(4 if D == 8 else 2)]
     b = HitGraphBatch.from_graphs(graphs)
     src, dst = b.src.numpy().copy(), b.dst.numpy().copy()
     src[5::97] = -1                              # padded segments anywhere in the caller's order
     dst[5::97] = -1
     b = HitGraphBatch(b.X.numpy(), src, dst, y=b.y.numpy(), hit_ptr=b.hit_ptr, seg_ptr=b.seg_ptr).cuda()
     y = b.y.cuda()
-    m = SegmentClassifier(input_dim=3, hidden_dim=8, n_iters=3).cuda().train()
+    m = SegmentClassifier(input_dim=3, hidden_dim=D, n_iters=3 if D == 8 else 2).cuda().train()
 
     def grads(level_order):
         m.level_order_training = level_order
@@ -762,7 +764,7 @@ def test_training_on_the_level_ordered_twin(hip):
     m.zero_grad(); BCELoss()(m(b2), y).backward()
     assert getattr(b2, "_twin", None) is not None and b2._twin is not b2
     e0, l0, g0 = grads(False)
-    twin = b.level_ordered(8)
+    twin = b.level_ordered(D)
     assert twin is not b and twin.n_hits == b.n_hits
     # the twin's segments are sorted by end hit, padded ones last; seg_order / seg_rank are inverse
     td = twin.dst.long()
