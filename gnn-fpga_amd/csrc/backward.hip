@@ -1053,6 +1053,26 @@ __device__ __forceinline__ float dppf(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 
+// Columns [col0, col0 + 4 K4) of rows n0 .. n0 + 255 of a row-major array (row stride `ld` floats, 16-byte
+// aligned pieces) -> LDS, transposed: dst[k * RS + hit].  Thread = hit reading its own row touches 64
+// different lines per load instruction (the L1's lookup rate bounded the dense kernels: 1.1e7 lookups per
+// launch in k_seg_finW); here consecutive threads read consecutive 16-byte pieces, a wave instruction
+// covers 64 / K4 rows as whole lines.  Rows beyond n_hits read as zeros.
+template <int K4>
+__device__ __forceinline__ void stage_cols_T(const float *__restrict__ src, int ld, int col0, int64_t n0,
+                                             int64_t n_hits, float *dst)
+{
+    constexpr int RS = kOuterStride;
+#pragma unroll 4
+    for (int j = threadIdx.x; j < kBlock * K4; j += kBlock) {
+        const int hit = j / K4, c = j % K4;
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (n0 + hit < n_hits) v = *reinterpret_cast<const float4 *>(src + (n0 + hit) * ld + col0 + 4 * c);
+        float *d = dst + (4 * c) * RS + hit;
+        d[0] = v.x; d[RS] = v.y; d[2 * RS] = v.z; d[3 * RS] = v.w;
+    }
+}
+
 // All of it as exact fp32 matrix-core products over the workgroup's 256 hits (thread = hit only for
 // loading and staging; lane l of a product holds rows 4 (l >> 4) .. + 3 of hit column l & 15):
 //   phase 1  LDS [gr | q 1]:  gW4, gb4 += gr (x) [q 1];   gp = (W4^T gr) (1 - q^2)   (this wave's 64 hits)
@@ -1333,12 +1353,12 @@ __global__ __launch_bounds__(kQuadBlock) void k_seg_bwdW(
     // segments starting here (n -> d): [Q | S | gp] of the end hits; then ending here: [P | R | gp]
     row_walk<D, false>(out_ptr[n], out_ptr[n + 1], (int)n, p, out_nbr, out_eid, e, B, a, a + DL, gp, w2, gP, Gout, sw2);
     row_walk<D, true>(in_ptr[n], in_ptr[n + 1], (int)n, p, in_nbr, in_eid, e, A, b, b + DL, gp, w2, gQ, Gin, sw2);
-    float out[4 * DL];
-#pragma unroll
-    for (int i = 0; i < DL; ++i) {
-        out[i] = gP[i]; out[DL + i] = gQ[i]; out[2 * DL + i] = Gout[i]; out[3 * DL + i] = Gin[i];
-    }
-    store_vec<4 * DL>(G4 + n * 4 * D + p * 4 * DL, out);
+    // G4 row = [gP(D) | gQ(D) | Gout(D) | Gin(D)], natural dim order: the 16 lanes write whole lines,
+    // and k_seg_finW reads one vector of 256 hits as 256-byte pieces (stage_cols_T)
+    store_vec<DL>(G4 + n * 4 * D + p * DL, gP);
+    store_vec<DL>(G4 + n * 4 * D + D + p * DL, gQ);
+    store_vec<DL>(G4 + n * 4 * D + 2 * D + p * DL, Gout);
+    store_vec<DL>(G4 + n * 4 * D + 3 * D + p * DL, Gin);
     store_vec<DL>(SW + n * kSwStride<D> + p * DL, sw2);
     if (p == 0) SW[n * kSwStride<D> + D] = sw2[DL];
 }
@@ -1368,17 +1388,11 @@ __global__ __launch_bounds__(kBlock) void k_seg_finW(
     const int64_t n0 = xcd_block() * kBlock, n = n0 + threadIdx.x;
     const bool active = n < n_hits;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r16 = lane & 15, g4 = lane >> 4;
-    {
-        float hp[LDH];
+    static_assert(LDH <= 16 * CT, "the padded h rows fit the column tiles");
+    stage_cols_T<LDH / 4>(H, ldh, 0, n0, n_hits, lds + D * RS);          // rows D .. D + LDH: h (and its padding)
+    __syncthreads();                                     // (the padding columns are overwritten next, by other threads)
 #pragma unroll
-        for (int k = 0; k < LDH; ++k) hp[k] = 0.0f;
-        if (active) load_row4<LDH / 4>(H + n * ldh, hp);
-#pragma unroll
-        for (int k = 0; k < C; ++k) lds[(D + k) * RS + threadIdx.x] = hp[k];
-        lds[(D + C) * RS + threadIdx.x] = active ? 1.0f : 0.0f;
-#pragma unroll
-        for (int k = C + 1; k < 16 * CT; ++k) lds[(D + k) * RS + threadIdx.x] = 0.0f;
-    }
+    for (int k = C; k < 16 * CT; ++k) lds[(D + k) * RS + threadIdx.x] = (k == C && active) ? 1.0f : 0.0f;   // ones row, zero pad
     f4v cg[KT][4];                                       // gh rows 16 kt + 4 g4 + r of hits 16 (4 wv + ht) + r16
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
@@ -1388,17 +1402,7 @@ __global__ __launch_bounds__(kBlock) void k_seg_finW(
 #pragma unroll 1
     for (int m = 0; m < 4; ++m) {
         __syncthreads();                                 // the previous vector's readers are done
-        {
-            float v[D];
-#pragma unroll
-            for (int i = 0; i < D; ++i) v[i] = 0.0f;
-            if (active) {
-#pragma unroll
-                for (int pl = 0; pl < 16; ++pl) load_vec<DL>(G4 + n * 4 * D + pl * 4 * DL + m * DL, v + pl * DL);
-            }
-#pragma unroll
-            for (int i = 0; i < D; ++i) lds[i * RS + threadIdx.x] = v[i];
-        }
+        stage_cols_T<D / 4>(G4, 4 * D, m * D, n0, n_hits, lds);
         __syncthreads();
         const float *W = m < 2 ? W1 : W3;
         float *gW = m < 2 ? gW1 : gW3;
@@ -1445,21 +1449,19 @@ __global__ __launch_bounds__(kBlock) void k_seg_finW(
             }
         }
     {   // gW2[D] | gb2 from the hits' terms: wave sums, then one writer per element of this workgroup's row
-        constexpr int NW = kBlock / 64, NS = D + 1;
-        float *red = lds;
+        // the hits' terms, transposed into LDS (rows = dims | gb2 term), then one thread per element adds
+        // its row of 256 in hit order
         __syncthreads();
-#pragma unroll 4
-        for (int i = 0; i < NS; ++i) {
-            float x = active ? SW[n * kSwStride<D> + i] : 0.0f;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-            if ((threadIdx.x & 63) == 0) red[(threadIdx.x >> 6) * NS + i] = x;
-        }
+        stage_cols_T<kSwStride<D> / 4>(SW, kSwStride<D>, 0, n0, n_hits, lds);
         __syncthreads();
         if ((int)threadIdx.x <= D) {
+            const float4 *row = reinterpret_cast<const float4 *>(lds + threadIdx.x * RS);
             float x = 0.0f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) x += red[w * NS + threadIdx.x];
+#pragma unroll 4
+            for (int t = 0; t < kBlock / 4; ++t) {
+                const float4 a = row[t];
+                x += a.x; x += a.y; x += a.z; x += a.w;
+            }
             *((int)threadIdx.x < D ? gW2 + threadIdx.x : gb2) += x;
         }
     }
