@@ -203,7 +203,7 @@ __global__ __launch_bounds__(kBlock) void k_edge_bwd(
     const float *__restrict__ e, const float *__restrict__ ge, const float *__restrict__ H,
     const float *__restrict__ gmio, float *__restrict__ gu_out,
     float *__restrict__ gW2, float *__restrict__ gb2, float *__restrict__ gb1, int rep_stride,
-    int64_t n_segments)
+    int64_t n_segments, int pad_only = 0)
 {
     constexpr int C = F + D, LDH = Shape<F, D>::LDH;
     gW2 = my_replica(gW2, rep_stride);
@@ -224,6 +224,7 @@ __global__ __launch_bounds__(kBlock) void k_edge_bwd(
     const int64_t lb = split ? blockIdx.x >> 3 : blockIdx.x, nlb = split ? gridDim.x >> 3 : gridDim.x;
     for (int64_t j = lo + lb * kBlock + threadIdx.x; j < hi; j += nlb * kBlock) {
         const int s = src[j], d = dst[j];
+        if (pad_only && s >= 0) continue;          // (wide pull form: the hits' walks cover the real segments)
         const float ev = e[j];
         float gej = 0.0f;
         if (ge) {
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(kBlock) void k_edge_bwd(
             sum[D + 1] += gu;
         }
         sum[D] += gu;
-        gu_out[j] = gu;
+        if (!pad_only) gu_out[j] = gu;
     }
     {
         constexpr int NW = kBlock / 64, N = D + 2;
@@ -1267,8 +1268,9 @@ __global__ __launch_bounds__(kBlock) void k_hit_bwdW(
 template <int D, bool IN>
 __device__ __forceinline__ void row_walk(int beg, int end, int n, int p, const int32_t *__restrict__ nbr,
                                          const int32_t *__restrict__ eid, const float *__restrict__ e,
-                                         const float *__restrict__ REC, const float *own_pq, const float *own_r,
-                                         const float *own_gp, const float *w2, float *gZ, float *G, float *sw2)
+                                         const float *__restrict__ ge_ext, const float *__restrict__ REC,
+                                         const float *own_pq, const float *own_r, const float *own_gp, const float *w2,
+                                         float *gZ, float *G, float *sw2)
 {
     constexpr int DL = D / 16;
     const int q = p & 3;
@@ -1276,7 +1278,9 @@ __device__ __forceinline__ void row_walk(int beg, int end, int n, int p, const i
         const int kk = k + q;
         const bool ok = kk < end;
         const int nb = ok ? nbr[kk] : n;                        // (a masked entry reads the own record with score 0)
-        const float ev = ok ? e[eid[kk]] : 0.0f;
+        const int se = ok ? eid[kk] : 0;
+        const float ev = ok ? e[se] : 0.0f;
+        const float gx = (ok && ge_ext) ? ge_ext[se] : 0.0f;    // final edge pass: the loss gradient of the scores
         float pr[4][2 * DL], gv[4][DL], part[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1304,6 +1308,7 @@ __device__ __forceinline__ void row_walk(int beg, int end, int n, int p, const i
         float ge = keep + dppf<0x4E>(give);
         ge += dppf<0x124>(ge);                                 // row_ror:4
         ge += dppf<0x128>(ge);                                 // row_ror:8
+        ge += gx;
         const float gu = ge * ev * (1.0f - ev);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1334,7 +1339,8 @@ __global__ __launch_bounds__(kQuadBlock) void k_seg_bwdW(
     const float *__restrict__ A, const float *__restrict__ B, const float *__restrict__ e,
     const int32_t *__restrict__ in_ptr, const int32_t *__restrict__ in_eid, const int32_t *__restrict__ in_nbr,
     const int32_t *__restrict__ out_ptr, const int32_t *__restrict__ out_eid, const int32_t *__restrict__ out_nbr,
-    const float *__restrict__ W2, float *__restrict__ G4, float *__restrict__ SW, int64_t n_hits)
+    const float *__restrict__ W2, float *__restrict__ G4, float *__restrict__ SW, int64_t n_hits,
+    const float *__restrict__ ge_ext)
 {
     constexpr int DL = D / 16;
     const int p = threadIdx.x & 15;
@@ -1351,8 +1357,8 @@ __global__ __launch_bounds__(kQuadBlock) void k_seg_bwdW(
     load_vec<2 * DL>(B + n * 3 * D + p * 2 * DL, b);
     load_vec<DL>(A + n * 3 * D + 2 * D + p * DL, gp);
     // segments starting here (n -> d): [Q | S | gp] of the end hits; then ending here: [P | R | gp]
-    row_walk<D, false>(out_ptr[n], out_ptr[n + 1], (int)n, p, out_nbr, out_eid, e, B, a, a + DL, gp, w2, gP, Gout, sw2);
-    row_walk<D, true>(in_ptr[n], in_ptr[n + 1], (int)n, p, in_nbr, in_eid, e, A, b, b + DL, gp, w2, gQ, Gin, sw2);
+    row_walk<D, false>(out_ptr[n], out_ptr[n + 1], (int)n, p, out_nbr, out_eid, e, ge_ext, B, a, a + DL, gp, w2, gP, Gout, sw2);
+    row_walk<D, true>(in_ptr[n], in_ptr[n + 1], (int)n, p, in_nbr, in_eid, e, ge_ext, A, b, b + DL, gp, w2, gQ, Gin, sw2);
     // G4 row = [gP(D) | gQ(D) | Gout(D) | Gin(D)], natural dim order: the 16 lanes write whole lines,
     // and k_seg_finW reads one vector of 256 hits as 256-byte pieces (stage_cols_T)
     store_vec<DL>(G4 + n * 4 * D + p * DL, gP);
@@ -1631,14 +1637,37 @@ int backward_t(const gnn_graph_t *g, const gnn_params_t *p, int T, const float *
         const float *Ht = H_all + (size_t)t * N * LDH;
         const float *et = e_all + (size_t)t * E;
         // edge pass t backward: adds into gH (gradient w.r.t. H_t)
-        if (N > 0) GNN_LAUNCH("kb_pq", (kb_pq<F, D>), grid_for(N), kBlock, s, Ht, LDH, p->W1, p->b1, w.PQ, N);
-        if (E > 0) {
+        bool edge_done = false;
+        if constexpr (D >= 32) {
+            // wide shapes, final pass (the only edge pass this loop still runs for them): the pull-form
+            // kernels with the loss gradient as ge - k_hit_bwdW on a zero gradient row builds the records
+            // ([P R 0], [Q S 0]), the walks rebuild gu at both ends, k_seg_finW adds W1^T (gP, gQ); the
+            // padded segments (in no hit's list) keep their own pass
+            if (Q_all && t == T && T > 0 && ge && !getenv("GNN_BWD_WIDE_PER_PASS")) {
+                if (N > 0) {
+                    GNN_LAUNCH("k_hit_bwdW", (k_hit_bwdW<F, D>), grid_for(N), kBlock, s, Ht, Ht, Q_all, LDH, p->W1, p->b1,
+                               p->W3, p->W4, gH, gHprev, w.A, w.B, rp + GL::oW3, rp + GL::ob3, rp + GL::oW4, rp + GL::ob4, RS, N);
+                    GNN_LAUNCH("k_seg_bwdW", (k_seg_bwdW<F, D>), grid_rows(N), kQuadBlock, s, w.A, w.B, et, g->in_ptr,
+                               g->in_eid, g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, p->W2, w.G4, w.SW, N, ge);
+                    GNN_LAUNCH("k_seg_finW", (k_seg_finW<F, D>), grid_for(N), kBlock, s, Ht, LDH, w.G4, w.SW, p->W1, p->W3,
+                               gH, rp + GL::oW1, rp + GL::ob1, rp + GL::oW2, rp + GL::ob2, rp + GL::oW3, RS, N);
+                }
+                if (E > 0) {
+                    const unsigned ge_grid = grid_for(E) < (unsigned)kSegGrid ? grid_for(E) : (unsigned)kSegGrid;
+                    GNN_LAUNCH("k_edge_bwd", (k_edge_bwd<F, D>), ge_grid, kBlock, s, g->src, g->dst, w.PQ, p->b1, p->W2, et,
+                               ge, Ht, w.gmio, w.gu, rp + GL::oW2, rp + GL::ob2, rp + GL::ob1, RS, E, 1);
+                }
+                edge_done = true;
+            }
+        }
+        if (!edge_done && N > 0) GNN_LAUNCH("kb_pq", (kb_pq<F, D>), grid_for(N), kBlock, s, Ht, LDH, p->W1, p->b1, w.PQ, N);
+        if (!edge_done && E > 0) {
             const unsigned ge_grid = grid_for(E) < (unsigned)kSegGrid ? grid_for(E) : (unsigned)kSegGrid;
             GNN_LAUNCH("k_edge_bwd", (k_edge_bwd<F, D>), ge_grid, kBlock, s, g->src, g->dst, w.PQ,
                        p->b1, p->W2, et, ge, Ht, w.gmio, w.gu, rp + GL::oW2, rp + GL::ob2, rp + GL::ob1,
                        RS, E);
         }
-        if (N > 0)
+        if (!edge_done && N > 0)
             GNN_LAUNCH("k_pq_bwd", (k_pq_bwd<F, D>), grid_for(N), kBlock, s, Ht, LDH, w.PQ, w.gu,
                        g->in_ptr, g->in_eid, g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, p->W1, p->W2,
                        gH, rp + GL::oW1, rp + GL::ob1, RS, N);
@@ -1688,7 +1717,8 @@ int backward_t(const gnn_graph_t *g, const gnn_params_t *p, int T, const float *
                                    Q_all + (size_t)(u - 1) * N * D, LDH, p->W1, p->b1, p->W3, p->W4, gH, gHprev, w.A, w.B,
                                    rp + GL::oW3, rp + GL::ob3, rp + GL::oW4, rp + GL::ob4, RS, N);
                         GNN_LAUNCH("k_seg_bwdW", (k_seg_bwdW<F, D>), grid_rows(N), kQuadBlock, s, w.A, w.B, ep, g->in_ptr,
-                                   g->in_eid, g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, p->W2, w.G4, w.SW, N);
+                                   g->in_eid, g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, p->W2, w.G4, w.SW, N,
+                                   (const float *)nullptr);
                         GNN_LAUNCH("k_seg_finW", (k_seg_finW<F, D>), grid_for(N), kBlock, s, Hp, LDH, w.G4, w.SW, p->W1, p->W3,
                                    gHprev, rp + GL::oW1, rp + GL::ob1, rp + GL::oW2, rp + GL::ob2, rp + GL::oW3, RS, N);
                     }
