@@ -1054,18 +1054,20 @@ __device__ __forceinline__ float dppf(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 
+// the dense wide kernels run 512 threads for their 256 hits: eight waves share the tiles, two per SIMD instead of one
+constexpr int kFinThreads = 512;
 // Columns [col0, col0 + 4 K4) of rows n0 .. n0 + 255 of a row-major array (row stride `ld` floats, 16-byte
 // aligned pieces) -> LDS, transposed: dst[k * RS + hit].  Thread = hit reading its own row touches 64
 // different lines per load instruction (the L1's lookup rate bounded the dense kernels: 1.1e7 lookups per
 // launch in k_seg_finW); here consecutive threads read consecutive 16-byte pieces, a wave instruction
 // covers 64 / K4 rows as whole lines.  Rows beyond n_hits read as zeros.
-template <int K4>
+template <int K4, int NTH = kBlock>
 __device__ __forceinline__ void stage_cols_T(const float *__restrict__ src, int ld, int col0, int64_t n0,
                                              int64_t n_hits, float *dst)
 {
     constexpr int RS = kOuterStride;
 #pragma unroll 4
-    for (int j = threadIdx.x; j < kBlock * K4; j += kBlock) {
+    for (int j = threadIdx.x; j < kBlock * K4; j += NTH) {
         const int hit = j / K4, c = j % K4;
         float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (n0 + hit < n_hits) v = *reinterpret_cast<const float4 *>(src + (n0 + hit) * ld + col0 + 4 * c);
@@ -1081,7 +1083,7 @@ __device__ __forceinline__ void stage_cols_T(const float *__restrict__ src, int 
 // One lane per hit with scalar weight operands streamed 100 KB of weights per wave through the scalar
 // cache (0.35 ms per launch at D = 64).
 template <int F, int D>
-__global__ __launch_bounds__(kBlock) void k_hit_bwdW(
+__global__ __launch_bounds__(kFinThreads) void k_hit_bwdW(
     const float *__restrict__ H, const float *__restrict__ Hn, const float *__restrict__ Qk, int ldh,
     const float *__restrict__ W1, const float *__restrict__ b1, const float *__restrict__ W3,
     const float *__restrict__ W4, const float *__restrict__ gHn, float *__restrict__ gH, float *__restrict__ A,
@@ -1095,15 +1097,16 @@ __global__ __launch_bounds__(kBlock) void k_hit_bwdW(
     typedef float f4v __attribute__((ext_vector_type(4)));
     constexpr int C = Shape<F, D>::C, LDH = Shape<F, D>::LDH, DL = D / 16, RS = kOuterStride;
     constexpr int RT = D / 16, CT = (C + 1 + 15) / 16, KT = (LDH + 15) / 16, YR = 16 * CT;
-    static_assert(D + 1 <= YR, "the [q | 1] block fits the [h | 1] rows");
+    static_assert(D + 1 <= YR && LDH <= YR, "the [q | 1] block and the padded h rows fit the [h | 1] rows");
     __shared__ __attribute__((aligned(16))) float lds[(D + YR) * RS];
     float *X = lds, *Y = lds + D * RS;
+    constexpr int NT = kFinThreads, NW = NT / 64, HW = kBlock / NW, HT = HW / 16;    // 512 threads for 256 hits
     const int64_t n0 = xcd_block() * kBlock, n = n0 + threadIdx.x;
-    const bool active = n < n_hits;
+    const bool is_hit = threadIdx.x < kBlock, active = is_hit && n < n_hits;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r16 = lane & 15, g4 = lane >> 4;
-    const int hcol = 64 * wv + r16;                      // + 16 ht: this lane's hit column of tile ht
+    const int hcol = HW * wv + r16;                      // + 16 ht: this lane's hit column of tile ht
     // ---- phase 1 staging: X = gr, Y = [q | 1 | 0]
-    {
+    if (is_hit) {
         float qv[D], hn[D], gn[D];
 #pragma unroll
         for (int i = 0; i < D; ++i) qv[i] = hn[i] = gn[i] = 0.0f;
@@ -1124,7 +1127,7 @@ __global__ __launch_bounds__(kBlock) void k_hit_bwdW(
     __syncthreads();
     auto outer = [&](int ncol, float *g, int ldg, int col0, float *gb) {      // X (x) Y[0 .. ncol) | ones at ncol
         const int ct = (ncol + 1 + 15) / 16;
-        for (int t = wv; t < RT * ct; t += kBlock / 64) {
+        for (int t = wv; t < RT * ct; t += NW) {
             const int it = t / ct, jt = t % ct;
             const float *a = X + (16 * it + r16) * RS + g4, *b = Y + (16 * jt + r16) * RS + g4;
             f4v c = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -1141,20 +1144,20 @@ __global__ __launch_bounds__(kBlock) void k_hit_bwdW(
         }
     };
     outer(D, gW4, D, 0, gb4);
-    f4v gp[RT][4];                                       // gp rows 16 kt + 4 g4 + r of hits hcol + 16 ht
+    f4v gp[RT][HT];                                       // gp rows 16 kt + 4 g4 + r of hits hcol + 16 ht
 #pragma unroll
     for (int kt = 0; kt < RT; ++kt) {
 #pragma unroll
-        for (int ht = 0; ht < 4; ++ht) gp[kt][ht] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int ht = 0; ht < HT; ++ht) gp[kt][ht] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll 4
         for (int st = 0; st < D / 4; ++st) {
             const float aw = W4[(4 * st + g4) * D + 16 * kt + r16];
             const float *bv = X + (4 * st + g4) * RS + hcol;
 #pragma unroll
-            for (int ht = 0; ht < 4; ++ht) gp[kt][ht] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw, bv[16 * ht], gp[kt][ht], 0, 0, 0);
+            for (int ht = 0; ht < HT; ++ht) gp[kt][ht] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw, bv[16 * ht], gp[kt][ht], 0, 0, 0);
         }
 #pragma unroll
-        for (int ht = 0; ht < 4; ++ht) {
+        for (int ht = 0; ht < HT; ++ht) {
             const float *qy = Y + (16 * kt + 4 * g4) * RS + hcol + 16 * ht;
             const float q0 = qy[0], q1 = qy[RS], q2 = qy[2 * RS], q3 = qy[3 * RS];
             gp[kt][ht].x *= 1.0f - q0 * q0; gp[kt][ht].y *= 1.0f - q1 * q1;
@@ -1166,40 +1169,35 @@ __global__ __launch_bounds__(kBlock) void k_hit_bwdW(
 #pragma unroll
     for (int kt = 0; kt < RT; ++kt)
 #pragma unroll
-        for (int ht = 0; ht < 4; ++ht) {
+        for (int ht = 0; ht < HT; ++ht) {
             float *x = X + (16 * kt + 4 * g4) * RS + hcol + 16 * ht;
             x[0] = gp[kt][ht].x; x[RS] = gp[kt][ht].y; x[2 * RS] = gp[kt][ht].z; x[3 * RS] = gp[kt][ht].w;
         }
-    {
-        float hp[LDH];
+    stage_cols_T<LDH / 4, NT>(H, ldh, 0, n0, n_hits, Y);             // h (and its padding columns)
+    __syncthreads();
+    if (is_hit) {
 #pragma unroll
-        for (int k = 0; k < LDH; ++k) hp[k] = 0.0f;
-        if (active) load_row4<LDH / 4>(H + n * ldh, hp);
-#pragma unroll
-        for (int k = 0; k < C; ++k) Y[k * RS + threadIdx.x] = hp[k];
-        Y[C * RS + threadIdx.x] = active ? 1.0f : 0.0f;
-#pragma unroll
-        for (int k = C + 1; k < YR; ++k) Y[k * RS + threadIdx.x] = 0.0f;
+        for (int k = C; k < YR; ++k) Y[k * RS + threadIdx.x] = (k == C && active) ? 1.0f : 0.0f;    // ones row, zero pad
     }
     __syncthreads();
     outer(C, gW3 + 2 * C, 3 * C, 0, gb3);
     // gH_prev = W3c^T gp (initialises the row; k_seg_finW adds the segment terms)
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
-        f4v c[4];
+        f4v c[HT];
 #pragma unroll
-        for (int ht = 0; ht < 4; ++ht) c[ht] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int ht = 0; ht < HT; ++ht) c[ht] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
         const int k = 16 * kt + r16;
 #pragma unroll 4
         for (int st = 0; st < D / 4; ++st) {
             const float aw = k < C ? W3[(4 * st + g4) * 3 * C + 2 * C + k] : 0.0f;
             const float *bv = X + (4 * st + g4) * RS + hcol;
 #pragma unroll
-            for (int ht = 0; ht < 4; ++ht) c[ht] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw, bv[16 * ht], c[ht], 0, 0, 0);
+            for (int ht = 0; ht < HT; ++ht) c[ht] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw, bv[16 * ht], c[ht], 0, 0, 0);
         }
         const int k0 = 16 * kt + 4 * g4;
 #pragma unroll
-        for (int ht = 0; ht < 4; ++ht) {
+        for (int ht = 0; ht < HT; ++ht) {
             const int64_t nn = n0 + hcol + 16 * ht;
             if (nn < n_hits && k0 < LDH) *reinterpret_cast<f4v *>(gH + nn * ldh + k0) = c[ht];
         }
@@ -1211,9 +1209,9 @@ __global__ __launch_bounds__(kBlock) void k_hit_bwdW(
         const int i = 16 * it + r16;
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {           // 0: P, R (W1a, W3a) -> A;  1: Q, S (W1b, W3b) -> B
-            f4v c1[4], c3[4];
+            f4v c1[HT], c3[HT];
 #pragma unroll
-            for (int ht = 0; ht < 4; ++ht) c1[ht] = c3[ht] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
+            for (int ht = 0; ht < HT; ++ht) c1[ht] = c3[ht] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll 4
             for (int st = 0; st < KS; ++st) {
                 const int kk = 4 * st + g4;
@@ -1226,7 +1224,7 @@ __global__ __launch_bounds__(kBlock) void k_hit_bwdW(
                 }
                 const float *bv = Y + kk * RS + hcol;
 #pragma unroll
-                for (int ht = 0; ht < 4; ++ht) {
+                for (int ht = 0; ht < HT; ++ht) {
                     const float bb = bv[16 * ht];
                     c1[ht] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bb, c1[ht], 0, 0, 0);
                     c3[ht] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, bb, c3[ht], 0, 0, 0);
@@ -1234,7 +1232,7 @@ __global__ __launch_bounds__(kBlock) void k_hit_bwdW(
             }
             float *REC = half == 0 ? A : B;
 #pragma unroll
-            for (int ht = 0; ht < 4; ++ht) {
+            for (int ht = 0; ht < HT; ++ht) {
                 const int64_t nn = n0 + hcol + 16 * ht;
                 if (nn >= n_hits) continue;
                 float *rec = REC + nn * 3 * D;
@@ -1255,7 +1253,7 @@ __global__ __launch_bounds__(kBlock) void k_hit_bwdW(
 #pragma unroll
     for (int kt = 0; kt < RT; ++kt)
 #pragma unroll
-        for (int ht = 0; ht < 4; ++ht) {
+        for (int ht = 0; ht < HT; ++ht) {
             const int64_t nn = n0 + hcol + 16 * ht;
             if (nn < n_hits) {
                 *reinterpret_cast<f4v *>(A + nn * 3 * D + 2 * D + 16 * kt + 4 * g4) = gp[kt][ht];
@@ -1376,7 +1374,7 @@ __global__ __launch_bounds__(kQuadBlock) void k_seg_bwdW(
 // (0.96 ms per launch at D = 64).  Wave w keeps the gh tiles of hits 64 w .. 64 w + 63 in registers
 // over the four vectors.
 template <int F, int D>
-__global__ __launch_bounds__(kBlock) void k_seg_finW(
+__global__ __launch_bounds__(kFinThreads) void k_seg_finW(
     const float *__restrict__ H, int ldh, const float *__restrict__ G4, const float *__restrict__ SW,
     const float *__restrict__ W1, const float *__restrict__ W3, float *__restrict__ gH, float *__restrict__ gW1,
     float *__restrict__ gb1, float *__restrict__ gW2, float *__restrict__ gb2, float *__restrict__ gW3,
@@ -1391,30 +1389,33 @@ __global__ __launch_bounds__(kBlock) void k_seg_finW(
     constexpr int C = Shape<F, D>::C, LDH = Shape<F, D>::LDH, DL = D / 16, RS = kOuterStride;
     constexpr int RT = D / 16, CT = (C + 1 + 15) / 16, KT = (LDH + 15) / 16, ROWS = D + 16 * CT;
     __shared__ __attribute__((aligned(16))) float lds[ROWS * RS];   // [v (D rows) | h (C) | ones | zero pad] x 256 hits
+    constexpr int NT = kFinThreads, NW = NT / 64, HW = kBlock / NW, HT = HW / 16;    // hits (hit tiles) per wave
     const int64_t n0 = xcd_block() * kBlock, n = n0 + threadIdx.x;
-    const bool active = n < n_hits;
+    const bool is_hit = threadIdx.x < kBlock, active = is_hit && n < n_hits;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r16 = lane & 15, g4 = lane >> 4;
     static_assert(LDH <= 16 * CT, "the padded h rows fit the column tiles");
-    stage_cols_T<LDH / 4>(H, ldh, 0, n0, n_hits, lds + D * RS);          // rows D .. D + LDH: h (and its padding)
+    stage_cols_T<LDH / 4, NT>(H, ldh, 0, n0, n_hits, lds + D * RS);      // rows D .. D + LDH: h (and its padding)
     __syncthreads();                                     // (the padding columns are overwritten next, by other threads)
+    if (is_hit) {
 #pragma unroll
-    for (int k = C; k < 16 * CT; ++k) lds[(D + k) * RS + threadIdx.x] = (k == C && active) ? 1.0f : 0.0f;   // ones row, zero pad
-    f4v cg[KT][4];                                       // gh rows 16 kt + 4 g4 + r of hits 16 (4 wv + ht) + r16
+        for (int k = C; k < 16 * CT; ++k) lds[(D + k) * RS + threadIdx.x] = (k == C && active) ? 1.0f : 0.0f;   // ones row, zero pad
+    }
+    f4v cg[KT][HT];                                      // gh rows 16 kt + 4 g4 + r of hits HW wv + 16 ht + r16
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int ht = 0; ht < 4; ++ht) cg[kt][ht] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int ht = 0; ht < HT; ++ht) cg[kt][ht] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
     // the four per-hit vectors one at a time: m = 0 gP (W1a, gb1), 1 gQ (W1b), 2 Gout (W3a), 3 Gin (W3b)
 #pragma unroll 1
     for (int m = 0; m < 4; ++m) {
         __syncthreads();                                 // the previous vector's readers are done
-        stage_cols_T<D / 4>(G4, 4 * D, m * D, n0, n_hits, lds);
+        stage_cols_T<D / 4, NT>(G4, 4 * D, m * D, n0, n_hits, lds);
         __syncthreads();
         const float *W = m < 2 ? W1 : W3;
         float *gW = m < 2 ? gW1 : gW3;
         const int ld = m < 2 ? 2 * C : 3 * C, c0 = (m & 1) * C;
         // outer-product sums over the 256 hits: [v] . [h | 1]
-        for (int t = wv; t < RT * CT; t += kBlock / 64) {
+        for (int t = wv; t < RT * CT; t += NW) {
             const int it = t / CT, jt = t % CT;
             const float *a = lds + (16 * it + r16) * RS + g4, *b = lds + (D + 16 * jt + r16) * RS + g4;
             f4v c = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -1436,9 +1437,9 @@ __global__ __launch_bounds__(kBlock) void k_seg_finW(
 #pragma unroll 4
             for (int st = 0; st < D / 4; ++st) {
                 const float aw = k < C ? W[(4 * st + g4) * ld + c0 + k] : 0.0f;
-                const float *bv = lds + (4 * st + g4) * RS + 64 * wv + r16;
+                const float *bv = lds + (4 * st + g4) * RS + HW * wv + r16;
 #pragma unroll
-                for (int ht = 0; ht < 4; ++ht)
+                for (int ht = 0; ht < HT; ++ht)
                     cg[kt][ht] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw, bv[16 * ht], cg[kt][ht], 0, 0, 0);
             }
         }
@@ -1446,8 +1447,8 @@ __global__ __launch_bounds__(kBlock) void k_seg_finW(
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int ht = 0; ht < 4; ++ht) {
-            const int64_t nn = n0 + 64 * wv + 16 * ht + r16;
+        for (int ht = 0; ht < HT; ++ht) {
+            const int64_t nn = n0 + HW * wv + 16 * ht + r16;
             const int k0 = 16 * kt + 4 * g4;
             if (nn < n_hits && k0 < LDH) {
                 f4v *dst = reinterpret_cast<f4v *>(gH + nn * ldh + k0);
@@ -1458,7 +1459,7 @@ __global__ __launch_bounds__(kBlock) void k_seg_finW(
         // the hits' terms, transposed into LDS (rows = dims | gb2 term), then one thread per element adds
         // its row of 256 in hit order
         __syncthreads();
-        stage_cols_T<kSwStride<D> / 4>(SW, kSwStride<D>, 0, n0, n_hits, lds);
+        stage_cols_T<kSwStride<D> / 4, NT>(SW, kSwStride<D>, 0, n0, n_hits, lds);
         __syncthreads();
         if ((int)threadIdx.x <= D) {
             const float4 *row = reinterpret_cast<const float4 *>(lds + threadIdx.x * RS);
@@ -1645,11 +1646,11 @@ int backward_t(const gnn_graph_t *g, const gnn_params_t *p, int T, const float *
             // padded segments (in no hit's list) keep their own pass
             if (Q_all && t == T && T > 0 && ge && !getenv("GNN_BWD_WIDE_PER_PASS")) {
                 if (N > 0) {
-                    GNN_LAUNCH("k_hit_bwdW", (k_hit_bwdW<F, D>), grid_for(N), kBlock, s, Ht, Ht, Q_all, LDH, p->W1, p->b1,
+                    GNN_LAUNCH("k_hit_bwdW", (k_hit_bwdW<F, D>), grid_for(N), kFinThreads, s, Ht, Ht, Q_all, LDH, p->W1, p->b1,
                                p->W3, p->W4, gH, gHprev, w.A, w.B, rp + GL::oW3, rp + GL::ob3, rp + GL::oW4, rp + GL::ob4, RS, N);
                     GNN_LAUNCH("k_seg_bwdW", (k_seg_bwdW<F, D>), grid_rows(N), kQuadBlock, s, w.A, w.B, et, g->in_ptr,
                                g->in_eid, g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, p->W2, w.G4, w.SW, N, ge);
-                    GNN_LAUNCH("k_seg_finW", (k_seg_finW<F, D>), grid_for(N), kBlock, s, Ht, LDH, w.G4, w.SW, p->W1, p->W3,
+                    GNN_LAUNCH("k_seg_finW", (k_seg_finW<F, D>), grid_for(N), kFinThreads, s, Ht, LDH, w.G4, w.SW, p->W1, p->W3,
                                gH, rp + GL::oW1, rp + GL::ob1, rp + GL::oW2, rp + GL::ob2, rp + GL::oW3, RS, N);
                 }
                 if (E > 0) {
@@ -1713,13 +1714,13 @@ int backward_t(const gnn_graph_t *g, const gnn_params_t *p, int T, const float *
                     const float *Hp = H_all + (size_t)(u - 1) * N * LDH;
                     const float *ep = e_all + (size_t)(u - 1) * E;
                     if (N > 0) {
-                        GNN_LAUNCH("k_hit_bwdW", (k_hit_bwdW<F, D>), grid_for(N), kBlock, s, Hp, Hu,
+                        GNN_LAUNCH("k_hit_bwdW", (k_hit_bwdW<F, D>), grid_for(N), kFinThreads, s, Hp, Hu,
                                    Q_all + (size_t)(u - 1) * N * D, LDH, p->W1, p->b1, p->W3, p->W4, gH, gHprev, w.A, w.B,
                                    rp + GL::oW3, rp + GL::ob3, rp + GL::oW4, rp + GL::ob4, RS, N);
                         GNN_LAUNCH("k_seg_bwdW", (k_seg_bwdW<F, D>), grid_rows(N), kQuadBlock, s, w.A, w.B, ep, g->in_ptr,
                                    g->in_eid, g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, p->W2, w.G4, w.SW, N,
                                    (const float *)nullptr);
-                        GNN_LAUNCH("k_seg_finW", (k_seg_finW<F, D>), grid_for(N), kBlock, s, Hp, LDH, w.G4, w.SW, p->W1, p->W3,
+                        GNN_LAUNCH("k_seg_finW", (k_seg_finW<F, D>), grid_for(N), kFinThreads, s, Hp, LDH, w.G4, w.SW, p->W1, p->W3,
                                    gHprev, rp + GL::oW1, rp + GL::ob1, rp + GL::oW2, rp + GL::ob2, rp + GL::oW3, RS, N);
                     }
                     float *tmp = gH; gH = gHprev; gHprev = tmp;
