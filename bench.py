@@ -228,20 +228,21 @@ def train_c4(dev, rank, world, rehearse, steps=60, warmup=15, n_global=512):
     return rec
 
 
-def train_c3(dev, graphs, steps=30, warmup=8):
-    """Training at the headline workload's graph size (N = 1 only): 32 of the c3 graphs as one batch
-    (3.2 M segments), HIP forward that keeps e_t / H_t / Q_t + fused BCE + HIP backward + Adam.  The
-    batch trains on its level-ordered twin (hits in plan order, segments by end hit: built once)."""
+def train_c3(dev, graphs, steps=30, warmup=8, hidden_dim=8, n_iters=3, n_graphs=32):
+    """Training at the workload's graph size (N = 1 only): c3 - 32 of the graphs as one batch (3.2 M
+    segments, D = 8, T = 3); c5 - one mu200-size graph with the model gnn/MPNN_Seg_ACTS_mu200.ipynb
+    trains (D = 64, T = 6).  HIP forward that keeps e_t / H_t / Q_t + fused BCE + HIP backward + Adam,
+    on the batch's level-ordered twin (hits in plan order, segments by end hit: built once)."""
     import torch
     from gnn_fpga_amd import HitGraphBatch, shard
     from gnn_fpga_amd.loss import BCELoss
     from gnn_fpga_amd.model import SegmentClassifier
-    graphs = graphs[:32]
+    graphs = graphs[:n_graphs]
     batch = HitGraphBatch.from_graphs(graphs).to(dev)
     y = batch.y.to(dev)
     F = batch.X.shape[1]
     torch.manual_seed(0)
-    m = SegmentClassifier(input_dim=F, hidden_dim=8, n_iters=3).to(dev).train()
+    m = SegmentClassifier(input_dim=F, hidden_dim=hidden_dim, n_iters=n_iters).to(dev).train()
     opt = torch.optim.Adam(m.parameters(), lr=1e-3, fused=True)
     bce = BCELoss()
     bucket = shard.GradBucket(m.parameters())
@@ -269,8 +270,8 @@ def train_c3(dev, graphs, steps=30, warmup=8):
     dd = time_steps(step_direct, steps, sync)
     last = float(step().detach())
     n_seg = batch.n_segments
-    return {"workload": "%d c3 graphs as one batch (%d hits, %d segments), F=%d, D=8, T=3, BCE, Adam"
-                        % (len(graphs), batch.n_hits, n_seg, F),
+    return {"workload": "%d graph(s) of the workload as one batch (%d hits, %d segments), F=%d, D=%d, T=%d, BCE, Adam"
+                        % (len(graphs), batch.n_hits, n_seg, F, hidden_dim, n_iters),
             "ms_per_step": dt / steps * 1e3, "segments_per_s": n_seg * steps / dt,
             "ms_per_step_direct": dd / steps * 1e3, "segments_per_s_direct": n_seg * steps / dd,
             "direct": "GradBucket.step: same kernels, no autograd graph, loss in the twin's segment order",
@@ -413,9 +414,11 @@ def run(args):
         elapsed = float(tmax.item())
 
     train = None if args.no_train else train_c4(dev, rank, world, rehearse)
-    train3 = None
+    train3 = train5 = None
     if not args.no_train and world == 1 and args.workload == "c3" and len(graphs) >= 32:
         train3 = train_c3(dev, graphs)
+    if not args.no_train and world == 1 and args.workload == "c5":
+        train5 = train_c3(dev, graphs, steps=15, warmup=4, hidden_dim=D, n_iters=T, n_graphs=1)
 
     if rank == 0:
         per = {}
@@ -511,6 +514,8 @@ def run(args):
             out["train_c4"] = train
         if train3 is not None:
             out["train_c3"] = train3
+        if train5 is not None:
+            out["train_c5"] = train5
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, graphs[0], wl)
         print(json.dumps(out), flush=True)
