@@ -337,6 +337,22 @@ def events_supported(F, D, max_hits, max_segments):
     return bool(load().gnn_events_supported(F, D, max_hits, max_segments))
 
 
+# Beyond this many segments per graph the one-workgroup-per-graph kernels lose to the tiled pipeline /
+# per-pass kernels even when a graph fits their LDS (tools/cliff_probe.py: 256 x (300 hits, 2000 segments)
+# 0.119 ms against 0.069; 256 x (150, 1000) 0.050 against 0.066)
+EVENTS_MAX_SEGMENTS = 1200
+
+
+def events_preferred(F, D, layout, backward=False):
+    """Should a batch with this event layout take the one-launch kernels?  (They must be able to - LDS -
+    and the graphs must be small enough to be worth a workgroup each.)"""
+    if layout is None or layout.max_segments > EVENTS_MAX_SEGMENTS:
+        return False
+    if not events_supported(F, D, layout.max_hits, layout.max_segments):
+        return False
+    return (not backward) or events_backward_supported(F, D, layout.max_hits, layout.max_segments)
+
+
 def segclf_forward_events(batch, layout, weights, F, D, n_iters, out=None, params=None):
     """Whole forward in one launch, one workgroup per graph (small events); `layout` is
     `batch.event_layout()`.  Returns scores [n_segments], bit-identical to segclf_forward."""

@@ -18,11 +18,10 @@ class _SegClf(torch.autograd.Function):
         # small graphs (the reference's muon events): the whole forward in one launch
         lay = batch.event_layout() if (use_events and batch.n_graphs > 0) else None
         # (only when the backward has its one-launch form too: the per-pass backward wants Q_all)
-        if lay is not None and not (_lib.events_supported(F, D, lay.max_hits, lay.max_segments) and
-                                    _lib.events_backward_supported(F, D, lay.max_hits, lay.max_segments)):
+        if not _lib.events_preferred(F, D, lay, backward=True):
             lay = None
         e_all, H_all, Q_all = _lib.segclf_forward_train(batch, w, F, D, n_iters, layout=lay)
-        ctx.batch, ctx.F, ctx.D, ctx.n_iters, ctx.use_events = batch, F, D, n_iters, use_events
+        ctx.batch, ctx.F, ctx.D, ctx.n_iters, ctx.use_events = batch, F, D, n_iters, lay is not None
         ctx.save_for_backward(e_all, H_all, Q_all, *w)
         rank = getattr(batch, "seg_rank", None)          # level-ordered twin: back to the caller's segment order
         return e_all[n_iters].clone() if rank is None else e_all[n_iters].index_select(0, rank)
@@ -36,8 +35,8 @@ class _SegClf(torch.autograd.Function):
         if order is not None:
             go = go.index_select(0, order)
         # small graphs (the reference's muon events): the whole backward in one launch
-        lay = b.event_layout() if (ctx.use_events and b.n_graphs > 0) else None
-        if lay is not None and _lib.events_backward_supported(ctx.F, ctx.D, lay.max_hits, lay.max_segments):
+        lay = b.event_layout() if ctx.use_events else None          # (the forward's decision)
+        if lay is not None:
             grads = _lib.segclf_backward_events(b, lay, list(w), ctx.F, ctx.D, ctx.n_iters, e_all, H_all, go)
         else:
             grads = _lib.segclf_backward(b, list(w), ctx.F, ctx.D, ctx.n_iters, e_all, H_all, go, Q_all=Q_all)
@@ -61,7 +60,7 @@ def training_batch(model, batch, use_events):
             return batch
     if use_events:
         lay = batch.event_layout()
-        if lay is not None and _lib.events_supported(model.input_dim, model.hidden_dim, lay.max_hits, lay.max_segments):
+        if _lib.events_preferred(model.input_dim, model.hidden_dim, lay, backward=True):
             return batch                       # small graphs: the one-launch kernels
     return batch.level_ordered(model.hidden_dim)
 

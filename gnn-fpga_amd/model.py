@@ -335,7 +335,7 @@ class SegmentClassifier(nn.Module):
         # (up to ~1k graphs: beyond that the tiled pipeline's throughput wins, tools/latency_probe.py)
         lay = batch.event_layout() if (self.use_events and not trace and batch.n_graphs <= 1024 and
                                        _lib.shape_supported(F, D)) else None
-        if lay is not None and _lib.events_supported(F, D, lay.max_hits, lay.max_segments):
+        if _lib.events_preferred(F, D, lay):
             e = _lib.segclf_forward_events(batch, lay, weights, F, D, self.n_iters, params=pstruct)
             if batch.dense_shape:
                 e = e.view(batch.dense_shape[0], batch.dense_shape[2])

@@ -119,8 +119,7 @@ class GradBucket:
             self.flat.zero_()
             use_events = bool(getattr(model, "use_events", True)) and 0 < batch.n_graphs <= 1024
             lay = batch.event_layout() if use_events else None
-            if lay is not None and not (_lib.events_supported(F, D, lay.max_hits, lay.max_segments) and
-                                        _lib.events_backward_supported(F, D, lay.max_hits, lay.max_segments)):
+            if not _lib.events_preferred(F, D, lay, backward=True):
                 lay = None
             if lay is None:
                 from .autograd import training_batch
