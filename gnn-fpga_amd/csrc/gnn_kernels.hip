@@ -504,6 +504,60 @@ __global__ __launch_bounds__(kBlock) void k_node_mlpW(
     }
 }
 
+// P / Q rows of 256 hits from their H rows, wide hidden layers: the same products as k_node_mlpW's last
+// stage (exact fp32, k ascending from the bias), H staged transposed with coalesced loads.  k_input /
+// k_pq feed these products scalar weight operands: 0.13 ms for 50 k hits at D = 64.
+template <int F, int D>
+__global__ __launch_bounds__(kBlock) void k_pq_mlpW(const float *__restrict__ H, int ldh, const float *__restrict__ W1,
+                                                    const float *__restrict__ b1, float *__restrict__ PQ, int64_t n_hits)
+{
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    constexpr int C = Shape<F, D>::C, LDH = Shape<F, D>::LDH, RS = kBlock + 4;
+    constexpr int RT = D / 16, KS = (C + 3) / 4;
+    static_assert(LDH == 4 * KS, "a padded H row is the k-steps of the products");
+    __shared__ __attribute__((aligned(16))) float lds[LDH * RS];
+    const int64_t n0 = xcd_block() * kBlock;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r16 = lane & 15, g4 = lane >> 4;
+    const int hcol = 64 * wv + r16;
+#pragma unroll 4
+    for (int j = threadIdx.x; j < kBlock * (LDH / 4); j += kBlock) {      // consecutive threads, consecutive 16-byte pieces
+        const int hit = j / (LDH / 4), c = j % (LDH / 4);
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (n0 + hit < n_hits) v = *reinterpret_cast<const float4 *>(H + (n0 + hit) * ldh + 4 * c);
+        float *d = lds + (4 * c) * RS + hit;
+        d[0] = v.x; d[RS] = v.y; d[2 * RS] = v.z; d[3 * RS] = v.w;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int it = 0; it < RT; ++it) {
+        const int i = 16 * it + r16;
+        f4v cp[4], cq[4];
+        const f4v bias = *reinterpret_cast<const f4v *>(b1 + 16 * it + 4 * g4);
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht) { cp[ht] = bias; cq[ht] = f4v{0.0f, 0.0f, 0.0f, 0.0f}; }
+#pragma unroll 4
+        for (int st = 0; st < KS; ++st) {
+            const int kk = 4 * st + g4;
+            const float ap = kk < C ? W1[i * 2 * C + kk] : 0.0f, aq = kk < C ? W1[i * 2 * C + C + kk] : 0.0f;
+            const float *bv = lds + kk * RS + hcol;
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht) {
+                const float bb = bv[16 * ht];
+                cp[ht] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap, bb, cp[ht], 0, 0, 0);
+                cq[ht] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq, bb, cq[ht], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht) {
+            const int64_t nn = n0 + hcol + 16 * ht;
+            if (nn < n_hits) {
+                *reinterpret_cast<f4v *>(PQ + nn * 2 * D + 16 * it + 4 * g4) = cp[ht];
+                *reinterpret_cast<f4v *>(PQ + nn * 2 * D + D + 16 * it + 4 * g4) = cq[ht];
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // small events: the WHOLE forward of one graph in one workgroup, one launch for the batch
 // ---------------------------------------------------------------------------------------------
@@ -833,9 +887,18 @@ template <int F, int D>
 int run_input(const float *X, const float *Win, const float *bin, const float *W1,
               const float *b1, float *H, int ldh, float *PQ, int64_t n, hipStream_t s)
 {
-    if (n > 0)
-        GNN_LAUNCH("k_input", (k_input<F, D>), grid_for(n), kBlock, s, X, Win, bin, W1, b1, H, ldh,
-                   PQ, n);
+    if (n <= 0) return 0;
+    if constexpr (D >= 32) {
+        // wide hidden layers at detector size: the P / Q products on the matrix cores
+        if (PQ && n >= kNodeWideMinHits && ldh == Shape<F, D>::LDH && !getenv("GNN_NODE_ONE_LANE")) {
+            GNN_LAUNCH("k_input", (k_input<F, D>), grid_for(n), kBlock, s, X, Win, bin, W1, b1, H, ldh,
+                       (float *)nullptr, n);
+            GNN_LAUNCH("k_pq_mlpW", (k_pq_mlpW<F, D>), grid_for(n), kBlock, s, H, ldh, W1, b1, PQ, n);
+            return 0;
+        }
+    }
+    GNN_LAUNCH("k_input", (k_input<F, D>), grid_for(n), kBlock, s, X, Win, bin, W1, b1, H, ldh,
+               PQ, n);
     return 0;
 }
 
