@@ -346,8 +346,8 @@ EVENTS_MAX_SEGMENTS = 1200
 def events_preferred(F, D, layout, backward=False):
     """Should a batch with this event layout take the one-launch kernels?  (They must be able to - LDS -
     and the graphs must be small enough to be worth a workgroup each.)"""
-    if layout is None or layout.max_segments > EVENTS_MAX_SEGMENTS:
-        return False
+    if layout is None or layout.max_segments > EVENTS_MAX_SEGMENTS or D > 16:
+        return False                 # (wide hidden layers: one toy graph 0.123 ms in one workgroup, 0.089 ms tiled)
     if not events_supported(F, D, layout.max_hits, layout.max_segments):
         return False
     return (not backward) or events_backward_supported(F, D, layout.max_hits, layout.max_segments)
