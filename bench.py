@@ -16,7 +16,13 @@ and no torchrun environment starts the N ranks itself (child processes of a pare
 never touches the GPU) and relays rank 0's line.
 
 Rank 0 prints ONE JSON line with
-  roofline      dominant kernel, HIP-event timed inside the library on the launch stream
+  roofline      dominant kernel, HIP-event timed inside the library on the launch stream: a pass of
+                >= 3 x K forwards, the first third dropped, MEDIAN per launch position; the sum of the
+                medians must not exceed 1.05 x ms_per_step (`consistent`)
+  value_exact_exp  the same forward with the exp-product mode off (what trained weights outside
+                its proven range run)
+  c5            (N = 1, c3) BASELINE configs[4]: 8 x (50k hits, 500k segments), D=64, T=6, exact fp32
+                and bf16 records, with the dominant kernel's HBM fraction and committed counters
   cpu_baseline  the oracle's dense-bmm port of the reference algorithm on this host (N=1 only)
   train_c3      (N = 1, c3) one training step on 32 of the workload's graphs as one batch
   plan_ms       what the per-batch execution plan costs (outside the timed region), and the
@@ -107,6 +113,133 @@ def cpu_baseline(model, graph, wl):
                       "formulation of gnn/model.py restated in oracle/dense_torch.py, "
                       "torch CPU %d threads, 1 run (%.1f s)" % (cores, t_dense),
             "index_form_value": e / t_index, "index_form_sample": idx_sample}
+
+
+def event_medians(step, steps):
+    """Per-launch kernel times of one step: HIP events recorded by the library around every launch, on
+    the launch stream, in a pass of its own (events perturb a timed region).  The pass runs n >= 3 x
+    `steps` (>= 30) steps; the first third is dropped (event creation idles the GPU: the clocks ramp
+    again) and every launch POSITION of a step gets the MEDIAN of the rest.
+    -> [(kernel_name, median_ms), ...] in launch order."""
+    from gnn_fpga_amd import _lib
+    n = min(max(3 * steps, 30), 600)
+    with _lib.profile(capacity=40 * n) as prof:
+        for _ in range(n):
+            step()
+    lps = len(prof.records) // n
+    if lps == 0 or lps * n != len(prof.records):
+        return []
+    out = []
+    for i in range(lps):
+        v = sorted(prof.records[k * lps + i][1] for k in range(n // 3, n))
+        out.append((prof.records[i][0], v[len(v) // 2]))
+    return out
+
+
+def pmc_section(path, key):
+    """Committed counter record of one workload (profiles/pmc_traffic.json, written by
+    tools/make_pmc_traffic.py from separate rocprofv3 --pmc passes), or None."""
+    if not (path and os.path.exists(path)):
+        return None
+    with open(path) as f:
+        pj = json.load(f)
+    sec = pj if key == "c3" and "kernels" in pj else pj.get(key)
+    return sec if sec and "kernels" in sec else None
+
+
+def kernel_traffic(sec, kernel):
+    """Launch-weighted HBM bytes per launch over the template variants of `kernel`."""
+    vs = [v for k, v in sec["kernels"].items() if k.split("<")[0] == kernel]
+    if not vs:
+        return None
+    return (sum(v["hbm_bytes_per_launch"] * v.get("launches", 1) for v in vs) /
+            sum(v.get("launches", 1) for v in vs))
+
+
+def c5_record(dev, steps, pmc_path, G=8):
+    """BASELINE configs[4] inside the default line (N = 1): G x (50k hits, 500k segments), D = 64,
+    T = 6 (gnn/MPNN_Seg_ACTS_mu200.ipynb cells 15, 19), exact fp32 records (the default wide path)
+    and bf16 records / bf16 matrix-core products (BASELINE's dtype for this config; scores within
+    2e-3, not 1e-5).  The bound reported is the one the kernels are actually against: HBM bytes of the
+    dominant kernel (`k_iter_w`) - algorithmic, and measured (`traffic`, committed PMC passes) - with
+    the vector-ALU busy fraction beside it; the per-segment-contraction MFMA figure of earlier rounds
+    was nominal (the kernels run the per-hit form, 10x fewer multiply-adds) and is gone."""
+    import torch
+    from gnn_fpga_amd import HitGraphBatch, synth
+    from gnn_fpga_amd.model import SegmentClassifier
+    wl = WORKLOADS["c5"]
+    n, e, F, D, T = wl["n"], wl["e"], wl["F"], wl["D"], wl["T"]
+    graphs = [synth.layered_graph(n, e, F, seed=1000 + i) for i in range(G)]
+    batch = HitGraphBatch.from_graphs(graphs).to(dev)
+    torch.manual_seed(0)
+    model = SegmentClassifier(input_dim=F, hidden_dim=D, n_iters=T).to(dev).eval()
+    model.use_events = False
+    K = max(steps // 2, 10)
+    rec = {"workload": wl["text"] % G, "steps": K}
+    with torch.no_grad():
+        for bf16 in (False, True):
+            model.mlp_bf16 = bf16
+            step = lambda: model(batch)          # noqa: E731
+            for _ in range(10):
+                step()
+            dt = time_steps(step, K, torch.cuda.synchronize) / K
+            seq = event_medians(step, K)
+            tag = "bf16" if bf16 else "f32"
+            sub = {"ms_per_step": dt * 1e3, "value": batch.n_segments / dt, "unit": "edges/s"}
+            per = {}
+            for name, ms in seq:
+                per.setdefault(name, []).append(ms)
+            if per:
+                dom = max(per, key=lambda k: sum(per[k]))
+                alg = algorithmic(batch.n_hits, batch.n_segments, F, D, T, w=2 if bf16 else 4)
+                t_dom = sum(per[dom]) / len(per[dom]) * 1e-3
+                ab = alg["bytes"].get(dom, alg["bytes"]["k_iter_w"])
+                sub.update({"kernel": dom, "avg_launch_ms": t_dom * 1e3,
+                            "launches_per_step": len(per[dom]),
+                            "algorithmic_bytes_per_launch": ab,
+                            "hbm_achieved_GBps": ab / t_dom / 1e9,
+                            "hbm_frac": ab / t_dom / 1e9 / HBM_PEAK_GBS,
+                            "sum_kernel_ms": sum(ms for _, ms in seq),
+                            "consistent": sum(ms for _, ms in seq) <= 1.05 * dt * 1e3,
+                            "forward_frac": alg["bytes"]["forward"] / dt / 1e9 / HBM_PEAK_GBS})
+                sec = pmc_section(pmc_path, "c5_" + tag)
+                if sec:
+                    tr = kernel_traffic(sec, dom)
+                    sub["traffic"] = tr
+                    sub["traffic_over_algorithmic"] = tr / ab if tr else None
+                    sub["valu_busy"] = sec.get("valu_busy", {}).get(dom)
+                    sub["counters_source"] = sec.get("source")
+            rec[tag] = sub
+    rec["bound"] = "hbm"
+    rec["note"] = ("k_iter_w: one launch per iteration; hbm_frac = SURVEY 8(d) B_edge + B_node of the "
+                   "launch / its median time / 8 TB/s; traffic = FETCH_SIZE x 2 + WRITE_SIZE of a committed "
+                   "rocprofv3 --pmc pass; valu_busy = SQ_ACTIVE_INST_VALU x 4 / SQ_BUSY_CU_CYCLES there")
+    return rec
+
+
+def fresh_single_graph(dev, model, graph, D, reps=5):
+    """What the reference's trigger-style use pays (gnn/Inference.ipynb cell 3: one graph in, scores
+    out): a NEVER-SEEN single graph already on the device -> plan -> forward -> scores ready, wall
+    clock with a synchronize, best of `reps` fresh batch objects (code objects and allocator warm)."""
+    import torch
+    from gnn_fpga_amd import HitGraphBatch
+    best = (float("inf"), 0.0, 0.0)
+    with torch.no_grad():
+        for _ in range(reps + 1):
+            b = HitGraphBatch.from_graphs([graph]).to(dev)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            b.build_plan(D)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            model(b)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            if t2 - t0 < best[0]:
+                best = (t2 - t0, t1 - t0, t2 - t1)
+    return {"ms": best[0] * 1e3, "plan_ms": best[1] * 1e3, "forward_ms": best[2] * 1e3,
+            "what": "one never-seen graph of the workload, resident on the device: plan build + forward, "
+                    "synchronised wall clock, best of %d" % reps}
 
 
 def free_port():
@@ -207,25 +340,42 @@ def train_c4(dev, rank, world, rehearse, steps=60, warmup=15, n_global=512):
                              if world > 1 else "none (single rank)")),
            "rccl_ranks": int(ones.item()), "loss_first": first, "loss_last": last,
            "mode": "eager; us_per_step = the reference-style loop (forward, loss.backward(), bucket all-reduce, Adam)"}
-    if world == 1:
-        # the whole step as ONE captured HIP graph (the library launches on the capturing stream and
-        # allocates nothing; Adam capturable)
-        opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True, fused=True)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                step()
-        torch.cuda.current_stream().wait_stream(side)
-        cg = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(cg):
-            step()
-        for _ in range(warmup):
-            cg.replay()
-        dg = time_steps(cg.replay, steps, sync_all)
-        rec["us_per_step_hip_graph"] = dg / steps * 1e6
-        rec["segments_per_s_hip_graph"] = n_seg * steps / dg
-    return rec
+    # the whole step as ONE captured HIP graph (the library launches on the capturing stream and
+    # allocates nothing; Adam capturable).  With world > 1 the RCCL all-reduce sits INSIDE the capture
+    # (the eager 8-rank step is host-launch-bound, not collective-bound); gloo (rehearsal) cannot be
+    # captured.  A capture that raises falls back to the eager numbers above and says so.
+    def capture():
+        nonlocal opt
+        try:
+            opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True, fused=True)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    step_direct()
+            torch.cuda.current_stream().wait_stream(side)
+            sync_all()
+            cg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cg):
+                step_direct()
+            for _ in range(warmup):
+                cg.replay()
+            dg = time_steps(cg.replay, steps, sync_all)
+            if world > 1:
+                t = torch.tensor([dg], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dg = float(t.item())
+            rec["us_per_step_hip_graph"] = dg / steps * 1e6
+            rec["segments_per_s_hip_graph"] = n_seg * steps / dg
+            rec["hip_graph"] = ("GradBucket.step + Adam captured once and replayed%s"
+                                % (", the RCCL all-reduce inside the capture" if world > 1 else ""))
+        except Exception as ex:       # noqa: BLE001  (capture refused: the eager numbers stand)
+            rec["hip_graph"] = "capture refused (%s: %s) - eager numbers only" % (type(ex).__name__, str(ex)[:120])
+
+    if world > 1 and rehearse:
+        rec["hip_graph"] = "gloo rehearsal: not capturable"
+        return rec, None
+    return rec, capture
 
 
 def train_c3(dev, graphs, steps=30, warmup=8, hidden_dim=8, n_iters=3, n_graphs=32):
@@ -286,6 +436,18 @@ def run(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.dry_run:
+        # the launch path alone (tests/test_bench_host.py, no GPU): rendezvous on 127.0.0.1, one
+        # all-reduce over gloo, rank 0 prints a line, every rank leaves with code 0
+        ones = torch.ones(1)
+        if world > 1:
+            dist.init_process_group("gloo")
+            dist.all_reduce(ones)
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "ranks": int(ones.item()), "n_gpus": world}), flush=True)
+        return
     # GNN_BENCH_REHEARSE=1: rehearsal of the N > 1 code path on a box with fewer GPUs than ranks
     # (ranks share devices, gloo instead of RCCL); the numbers of such a run mean nothing
     rehearse = os.environ.get("GNN_BENCH_REHEARSE") == "1"
@@ -342,18 +504,25 @@ def run(args):
             step = cg.replay
             step()
         elapsed = time_steps(step, args.steps, sync_all)
-        # per-kernel durations: HIP events recorded by the library around every launch,
-        # on the launch stream, in a separate pass (events perturb the timed region)
-        with _lib.profile(capacity=32 * args.steps) as prof:
-            for _ in range(args.steps):
-                model(batch)
-        other = None
+        # per-kernel durations (see event_medians): a pass of its own, first third dropped, medians
+        seq = event_medians(lambda: model(batch), args.steps)
+        other = exact = None
         if args.workload == "c5":           # the other arithmetic beside it
             model.mlp_bf16 = not bf16
             for _ in range(2):
                 model(batch)
             other = time_steps(step, max(args.steps // 4, 2), sync_all) / max(args.steps // 4, 2)
             model.mlp_bf16 = bf16
+        elif not args.graph:
+            # the exact-exp rate beside `value`: exp-product mode is only legal inside its proven range
+            # (include/gnn_hip.h, GNN_FLAG_EXP_PRODUCT); weights outside it run this path
+            model.exp_product = False
+            ke = max(args.steps // 2, 10)
+            for _ in range(5):
+                model(batch)
+            exact = time_steps(step, ke, sync_all) / ke
+            model.exp_product = True
+            model(batch)
         # the per-batch plan on the record: a second, fresh batch of the same graphs (code objects
         # and allocator warm), then one forward on it - what a stream of never-repeated batches pays
         e_tot_local = batch.n_segments
@@ -409,34 +578,40 @@ def run(args):
                       "speedup": times[False] / times[True], "value": e_tot_local / times[True]}
         del fresh
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed, exact or 0.0], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        elapsed = float(tmax[0].item())
+        exact = float(tmax[1].item()) or None
 
-    train = None if args.no_train else train_c4(dev, rank, world, rehearse)
+    train, train_capture = (None, None) if args.no_train else train_c4(dev, rank, world, rehearse)
+    if train_capture is not None and world == 1:
+        train_capture()
     train3 = train5 = None
     if not args.no_train and world == 1 and args.workload == "c3" and len(graphs) >= 32:
         train3 = train_c3(dev, graphs)
     if not args.no_train and world == 1 and args.workload == "c5":
         train5 = train_c3(dev, graphs, steps=15, warmup=4, hidden_dim=D, n_iters=T, n_graphs=1)
 
+    c5 = single = None
+    if world == 1 and args.workload == "c3" and not args.no_c5 and not args.graph:
+        c5 = c5_record(dev, args.steps, args.pmc_traffic)
+    if world == 1 and not args.graph:
+        with torch.no_grad():
+            single = fresh_single_graph(dev, model, graphs[0], D)
+
     if rank == 0:
         per = {}
-        for name, ms in prof.records:
+        for name, ms in seq:
             per.setdefault(name, []).append(ms)
         tot = {k: sum(v) for k, v in per.items()}
         dom = max(tot, key=tot.get)
         avg_ms = {k: sum(v) / len(v) for k, v in per.items()}
-        # the same, by position in the launch sequence of one step (first / middle / last iteration)
-        lps = len(prof.records) // args.steps
-        seq_ms = [[prof.records[i][0], round(sum(prof.records[j][1] for j in range(i, len(prof.records), lps))
-                                             / args.steps, 4)] for i in range(lps)] if lps else []
         n_tot, e_tot = batch.n_hits, batch.n_segments
         alg = algorithmic(n_tot, e_tot, F, D, T, w=2 if bf16 else 4)
         ab, af = alg["bytes"], alg["flops"]
         # algorithmic bytes of the dominant kernel's launches in one step; when the input network
         # is fused into the first iteration launch (no k_input4 launch), its bytes ride along
-        n_dom = len(per[dom]) // args.steps
+        n_dom = len(per[dom])
         ab_dom_step, af_dom_step = n_dom * ab[dom], n_dom * af[dom]
         if dom == "k_iter2" and "k_input4" not in per:
             ab_dom_step += ab["k_input4"]
@@ -447,42 +622,45 @@ def run(args):
         tfs = af_dom / t_dom / 1e12
         ms_step = elapsed / args.steps * 1e3
         traffic = traffic_source = None
-        if args.pmc_traffic and os.path.exists(args.pmc_traffic) and G == 256 and args.workload == "c3":
-            with open(args.pmc_traffic) as f:
-                pj = json.load(f)
-            pk = pj["kernels"]
+        sec = pmc_section(args.pmc_traffic, args.workload if args.workload == "c3" else
+                          "c5_" + ("bf16" if bf16 else "f32"))
+        if sec and G == wl["G"]:
             # the dominant kernel has template variants (first / middle / last iteration move
             # different amounts): launch-weighted mean over the profiled run
-            vs = [v for k, v in pk.items() if k.startswith(dom + "<")]
-            if vs:
-                traffic = (sum(v["hbm_bytes_per_launch"] * v.get("launches", 1) for v in vs) /
-                           sum(v.get("launches", 1) for v in vs))
+            traffic = kernel_traffic(sec, dom)
+            if traffic:
                 traffic_source = ("%s (%s): rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of this "
                                   "command, committed - not measured in this run"
-                                  % (os.path.relpath(args.pmc_traffic, REPO), pj.get("source", "?")))
+                                  % (os.path.relpath(args.pmc_traffic, REPO), sec.get("source", "?")))
         value = world * e_tot * args.steps / elapsed
+        sum_k = sum(ms for _, ms in seq)
+        dom_pos = per[dom]
         roof = {"kernel": dom, "algorithmic_bytes_per_launch": ab_dom,
                 "algorithmic_flops_per_launch": af_dom, "avg_launch_ms": avg_ms[dom],
+                # flat scalars (nested objects do not survive the driver's parse): the dominant
+                # kernel by launch position, everything else in one number, and the cross-check
+                "launches_per_step": n_dom,
+                "launch_ms_first": dom_pos[0], "launch_ms_middle": dom_pos[len(dom_pos) // 2],
+                "launch_ms_last": dom_pos[-1],
+                "other_kernels_ms": sum_k - sum(dom_pos),
+                "sum_kernel_ms": sum_k, "ms_per_step": ms_step,
+                "consistent": bool(sum_k <= 1.05 * ms_step),
+                "timing": "HIP events on the launch stream, %d-step pass after the timed loop, first third "
+                          "dropped, median per launch position" % min(max(3 * args.steps, 30), 600),
                 "traffic": traffic, "traffic_source": traffic_source,
                 "kernel_ms": {k: round(v, 4) for k, v in avg_ms.items()},
-                "launches_per_step": {k: len(v) // args.steps for k, v in per.items()},
-                "launch_sequence_ms": seq_ms,
+                "launch_sequence_ms": [[k, round(v, 4)] for k, v in seq],
                 "forward_algorithmic_GBps": ab["forward"] / (ms_step * 1e-3) / 1e9,
                 "forward_frac": ab["forward"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        # (c5 too: the kernels execute the per-hit P/Q form, E/N = 10x fewer multiply-adds than the
+        # reference's per-segment contraction, so its nominal MFMA figure bounds nothing - the
+        # bytes do; the algorithmic flop rate stays in the record for reference)
+        roof = dict({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": gbs / HBM_PEAK_GBS}, **roof)
         if args.workload == "c5":
-            # c5's dense contractions make the matrix cores the bounding roofline of the
-            # reference's formulation; report the MFMA fraction AND the HBM fraction
-            peak = BF16_PEAK_TFLOPS if bf16 else F32_MATRIX_TFLOPS
-            roof = dict({"bound": "mfma", "achieved": tfs, "peak": peak, "unit": "TFLOP/s",
-                         "frac": tfs / peak, "hbm_achieved_GBps": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
-                         "forward_algorithmic_TFLOPs": af["forward"] / (ms_step * 1e-3) / 1e12,
-                         "forward_mfma_frac": af["forward"] / (ms_step * 1e-3) / 1e12 / peak,
-                         "note": "algorithmic flops = the reference's per-segment contraction (SURVEY 8(d)); "
-                                 "the kernels execute the per-hit P/Q form, E/N = 10x fewer multiply-adds"},
-                        **roof)
-        else:
-            roof = dict({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs / HBM_PEAK_GBS}, **roof)
+            roof["algorithmic_TFLOPs"] = tfs
+            if sec:
+                roof["valu_busy"] = sec.get("valu_busy", {}).get(dom)
         out = {
             "metric": "edges/sec (EdgeNet+NodeNet fwd) on 100k-edge TrackML graphs; % HBM roofline",
             "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
@@ -505,6 +683,14 @@ def run(args):
             "value_incl_plan_note": "one forward on a never-seen batch: warm plan build + first forward; "
                                     "`value` replays one resident batch (plan amortised)",
         }
+        if exact is not None:
+            out["value_exact_exp"] = world * e_tot / exact
+            out["ms_per_step_exact_exp"] = exact * 1e3
+        if single is not None:
+            out["fresh_single_graph_ms"] = single["ms"]
+            out["fresh_single_graph"] = single
+        if c5 is not None:
+            out["c5"] = c5
         if other is not None:
             out["other_dtype"] = {"dtype": "f32" if bf16 else "bf16", "ms_per_step": other * 1e3,
                                   "value": e_tot / other}
@@ -518,6 +704,24 @@ def run(args):
             out["train_c5"] = train5
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, graphs[0], wl)
+    if train_capture is not None and world > 1:
+        # LAST, behind a watchdog: a capture with a collective inside cannot be rehearsed on a one-GPU
+        # box; if it does not come back, rank 0 still prints the line (eager numbers) and every rank
+        # leaves with code 0
+        import threading
+
+        def bail():
+            if rank == 0:
+                out["train_c4"]["hip_graph"] = "capture / replay did not finish within 180 s - eager numbers only"
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        timer = threading.Timer(180.0, bail)
+        timer.daemon = True
+        timer.start()
+        train_capture()
+        timer.cancel()
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -535,6 +739,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the train_c4 sub-record")
     ap.add_argument("--no-pruned", action="store_true", help="skip the pruned-model sub-record (c3, N=1)")
+    ap.add_argument("--no-c5", action="store_true", help="skip the c5 sub-record (c3, N=1)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="start the ranks, rendezvous over gloo, print {dry_run, ranks} and leave (no GPU)")
     ap.add_argument("--graph", action="store_true",
                     help="experiment: replay the forward from a captured HIP graph")
     ap.add_argument("--global-gather", action="store_true",

@@ -237,7 +237,18 @@ def cached_graph_struct(batch):
 def params_struct(weights, F, D, flags=0):
     """weights: the ten effective (masked) tensors in state_dict order."""
     p = GnnParams()
-    for name, w in zip(("Win", "bin", "W1", "b1", "W2", "b2", "W3", "b3", "W4", "b4"), weights):
+    C = F + D
+    shapes = ((D, F), (D,), (D, 2 * C), (D,), (1, D), (1,), (D, 3 * C), (D,), (D, D), (D,))
+    if len(weights) != 10:
+        raise GnnHipError("expected the ten weight tensors in state_dict order, got %d" % len(weights))
+    for name, w, shp in zip(("Win", "bin", "W1", "b1", "W2", "b2", "W3", "b3", "W4", "b4"), weights, shapes):
+        n = 1
+        for d in shp:
+            n *= d
+        if torch.is_tensor(w) and w.numel() != n:
+            # the kernels index the tensors as [D, ...] rows of (F, D): a mismatch is an out-of-bounds read
+            raise GnnHipError("%s has %d elements, but input_dim=%d hidden_dim=%d needs shape %s"
+                              % (name, w.numel(), F, D, shp))
         setattr(p, name, _dev(w, torch.float32, name))
     p.F, p.D, p.flags = F, D, flags
     devs = {w.device for w in weights}

@@ -46,9 +46,9 @@ class _SegClf(torch.autograd.Function):
 def training_batch(model, batch, use_events):
     """The batch the training kernels run on: detector-size batches are renumbered in plan order once
     (HitGraphBatch.level_ordered) so that the kernels' record gathers stay L2-local.
-    model.level_order_training: True (default: always), False (never), "auto" (from the second time
-    the same batch object is trained on)."""
-    policy = getattr(model, "level_order_training", True)
+    model.level_order_training: "auto" (default: from the second time the same batch object is trained
+    on), True (always), False (never)."""
+    policy = getattr(model, "level_order_training", "auto")
     if not policy or batch.n_hits < 20000:
         return batch
     if policy == "auto" and getattr(batch, "_twin", None) is None:

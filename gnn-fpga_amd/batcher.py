@@ -57,24 +57,41 @@ def merge_graphs(graphs, layout="padded"):
     return b, (None if b.y is None else b.y.view(b.dense_shape[0], b.dense_shape[2]).clone())
 
 
-def batch_generator(graphs, n_samples=1, batch_size=1, train=True, device=None, layout="padded"):
+def _batch_bytes(b, y):
+    """Bytes a cached batch pins at most: its own arrays, its two CSRs and the level-ordered twin the
+    training path may add (a second copy of all of them), plus the two execution plans (about the size
+    of the segment lists again)."""
+    own = b.X.numel() * 4 + 2 * b.n_segments * 4 + (0 if y is None else y.numel() * 4)
+    csr = 2 * (b.n_hits + 1) * 4 + 4 * b.n_segments * 4
+    plan = 6 * b.n_segments * 4 + 64 * b.n_hits
+    return 2 * (own + csr + plan)
+
+
+def batch_generator(graphs, n_samples=1, batch_size=1, train=True, device=None, layout="padded",
+                    cache=True, max_cached_bytes=8 << 30):
     """Endless generator of `(HitGraphBatch, y)` in the reference's order
     (gnn/trainSegmentClassifier.py:97-111).  `train` is accepted for signature compatibility (the
-    reference uses it for the long-gone `volatile` flag only).  Batches are built once and reused
-    over epochs (their execution plans and CSRs with them) unless `n_samples` is large; `device`
-    moves them (and y) there."""
+    reference uses it for the long-gone `volatile` flag only).  `device` moves the batches (and y)
+    there.  With `cache=True` batches are built once and reused over epochs - their CSRs, execution
+    plans and level-ordered twins with them - while the estimated bytes they pin (`_batch_bytes`: twin
+    and plans included) stay under `max_cached_bytes` (default 8 GiB of the 288); what does not fit is
+    rebuilt each epoch and holds nothing between uses, like every batch of the reference's generator
+    (`cache=False`)."""
     del train
     idxs = np.arange(0, n_samples, batch_size)
-    cache = {}
+    kept, kept_bytes = {}, 0
     while True:
         for j in idxs:
-            item = cache.get(int(j))
+            item = kept.get(int(j))
             if item is None:
                 b, y = merge_graphs(graphs[j:j + batch_size], layout)
                 if device is not None:
                     b = b.to(device)
                     y = None if y is None else y.to(device)
                 item = (b, y)
-                if len(cache) < 4096:
-                    cache[int(j)] = item
+                if cache:
+                    need = _batch_bytes(b, y)
+                    if kept_bytes + need <= max_cached_bytes:
+                        kept[int(j)] = item
+                        kept_bytes += need
             yield item

@@ -50,7 +50,8 @@ enum Hdr {
     H_NVALID, H_NUNITS, H_NTILES, H_NPAD, H_TILEMAX, H_NSCHED, H_NRUNS, H_NMARKS, H_NCHUNKS, H_STATUS,
     H_LDSREC, H_NLDSTILES, H_LDSIN, H_LDSOUT, H_EDGEROWS, H_NLDSCHUNKS, H_MAXSTEPS, H_MAXLEVEL, H_COUNT = 32
 };
-enum Status { ST_OK = 0, ST_DEGREE = 1, ST_TILES = 2, ST_PAD = 4, ST_CHUNKS = 8, ST_SLICES = 16, ST_I32 = 32 };
+enum Status { ST_OK = 0, ST_DEGREE = 1, ST_TILES = 2, ST_PAD = 4, ST_CHUNKS = 8, ST_SLICES = 16, ST_I32 = 32,
+              ST_ENDPOINT = 64 };   // ST_ENDPOINT: a segment end outside [0, n_hits), or exactly one end negative
 
 struct I2 { int a, b; };
 struct I4 { int a, b, c, d; };
@@ -175,22 +176,26 @@ __device__ __forceinline__ void hdr_add(int64_t *hdr, int slot, long long v)
 // thousand global atomics per workgroup instead of 32 k.  Wide ranges (shuffled input) count in global
 // memory as before.
 constexpr int kDegSegs = 16384, kDegRange = 16384;
-__global__ __launch_bounds__(1024) void pb_degrees(const int *__restrict__ src, const int *__restrict__ dst, int64_t E,
+// The builder does not trust its endpoints: a segment is VALID when both ends lie in [0, n); a padded
+// segment has both ends negative; anything else (an end >= n, one end negative) sets ST_ENDPOINT and
+// is skipped by every kernel that indexes per-hit arrays before the caller reads the status back.
+__device__ __forceinline__ bool seg_ok(int s, int d, int n) { return (unsigned)s < (unsigned)n && (unsigned)d < (unsigned)n; }
+
+__global__ __launch_bounds__(1024) void pb_degrees(const int *__restrict__ src, const int *__restrict__ dst, int64_t E, int n,
                                                   int *deg_in, int *deg_out, int64_t *hdr)
 {
     __shared__ int cin[kDegRange], cout[kDegRange];
     __shared__ int red[2 * 16];
-    int cnt = 0;
+    int cnt = 0, bad = 0;
     for (int64_t b0 = (int64_t)blockIdx.x * kDegSegs; b0 < E; b0 += (int64_t)gridDim.x * kDegSegs) {
         const int64_t b1 = b0 + kDegSegs < E ? b0 + kDegSegs : E;
         int mn = 0x7FFFFFFF, mx = -1;
         for (int64_t j = b0 + threadIdx.x; j < b1; j += 1024) {
-            const int s = src[j];
-            if (s >= 0) {
-                const int d = dst[j];
+            const int s = src[j], d = dst[j];
+            if (seg_ok(s, d, n)) {
                 mn = s < mn ? s : mn; mn = d < mn ? d : mn;
                 mx = s > mx ? s : mx; mx = d > mx ? d : mx;
-            }
+            } else if (s >= 0 || d >= 0) bad = 1;
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -212,9 +217,8 @@ __global__ __launch_bounds__(1024) void pb_degrees(const int *__restrict__ src, 
             for (int i = threadIdx.x; i <= hi - lo; i += 1024) cin[i] = cout[i] = 0;
         __syncthreads();
         for (int64_t j = b0 + threadIdx.x; j < b1; j += 1024) {
-            const int s = src[j];
-            if (s >= 0) {
-                const int d = dst[j];
+            const int s = src[j], d = dst[j];
+            if (seg_ok(s, d, n)) {
                 if (local) {
                     atomicAdd(&cout[s - lo], 1);
                     atomicAdd(&cin[d - lo], 1);
@@ -237,6 +241,7 @@ __global__ __launch_bounds__(1024) void pb_degrees(const int *__restrict__ src, 
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
     if ((threadIdx.x & 63) == 0 && cnt) hdr_add(hdr, H_NVALID, cnt);
+    if (__any(bad) && (threadIdx.x & 63) == 0) set_status(hdr, ST_ENDPOINT);
 }
 
 // gid[i] = number of interior graph boundaries hit_ptr[1..G-1] that are <= i   (plan.py: add.at + cumsum)
@@ -263,16 +268,16 @@ __global__ __launch_bounds__(TB) void pb_gid(const int64_t *__restrict__ hit_ptr
 // Levels are swept as BYTES (the iterate never exceeds kMaxLevelIters = 64): 2.5 MB for the 2.56 M hits of
 // c3 x 256, which every XCD's 4 MB L2 holds, where the int32 table's 10 MB lived in the MALL - the
 // sweep is one random level[src] read per segment and nothing else.  pb_widen hands int32 levels on.
-__global__ __launch_bounds__(TB) void pb_level_sweep(const int *__restrict__ src, const int *__restrict__ dst, int64_t E,
+__global__ __launch_bounds__(TB) void pb_level_sweep(const int *__restrict__ src, const int *__restrict__ dst, int64_t E, int n,
                                                      unsigned char *level, int *chg, int t)
 {
     if (t > 1 && chg[t - 1] == 0) return;
     int any = 0;
     GS_LOOP(j, E) {
-        const int s = src[j];
-        if (s < 0) continue;
+        const int s = src[j], d = dst[j];
+        if (!seg_ok(s, d, n)) continue;
         if ((int)level[s] >= t - 1) {
-            level[dst[j]] = (unsigned char)t;
+            level[d] = (unsigned char)t;
             any = 1;
         }
     }
@@ -293,15 +298,15 @@ __global__ __launch_bounds__(TB) void pb_widen(const unsigned char *__restrict__
 // would cost more than the sweeps themselves.
 constexpr int kSweepRound = 12;
 constexpr int64_t kSmallSweepSegments = 1 << 15;   // (100 k segments: 0.69 ms in one workgroup, 0.41 ms as 64 launches)
-__global__ __launch_bounds__(1024) void pb_levels_small(const int *__restrict__ src, const int *__restrict__ dst, int E,
+__global__ __launch_bounds__(1024) void pb_levels_small(const int *__restrict__ src, const int *__restrict__ dst, int E, int n,
                                                         int *level)
 {
     for (int t = 1; t <= kMaxLevelIters; ++t) {
         int any = 0;
         for (int j = threadIdx.x; j < E; j += 1024) {
-            const int s = src[j];
-            if (s >= 0 && level[s] >= t - 1) {
-                level[dst[j]] = t;
+            const int s = src[j], d = dst[j];
+            if (seg_ok(s, d, n) && level[s] >= t - 1) {
+                level[d] = t;
                 any = 1;
             }
         }
@@ -312,12 +317,12 @@ __global__ __launch_bounds__(1024) void pb_levels_small(const int *__restrict__ 
 __global__ __launch_bounds__(TB) void pb_fill_i32(int *a, int64_t n, int v) { GS_LOOP(i, n) a[i] = v; }
 
 // (only hits without incoming segments use it: one segment in ten of a layered graph)
-__global__ __launch_bounds__(TB) void pb_down(const int *__restrict__ src, const int *__restrict__ dst, int64_t E,
+__global__ __launch_bounds__(TB) void pb_down(const int *__restrict__ src, const int *__restrict__ dst, int64_t E, int n,
                                               const int *__restrict__ level, const int *__restrict__ deg_in, int *down)
 {
     GS_LOOP(j, E) {
-        const int s = src[j];
-        if (s >= 0 && deg_in[s] == 0) atomicMin(&down[s], level[dst[j]]);
+        const int s = src[j], d = dst[j];
+        if (seg_ok(s, d, n) && deg_in[s] == 0) atomicMin(&down[s], level[d]);
     }
 }
 
@@ -609,12 +614,12 @@ __global__ __launch_bounds__(TB) void pb_valid_idx(const int *__restrict__ src, 
 
 // run starts of the (graph, start level) key; padded segments join the run before them: k[j] = key of
 // the last valid segment at or before j (or of segment 0 when there is none)
-__global__ __launch_bounds__(TB) void pb_run_flags(const int *__restrict__ src, int64_t E, const int *__restrict__ idx,
+__global__ __launch_bounds__(TB) void pb_run_flags(const int *__restrict__ src, int64_t E, int n, const int *__restrict__ idx,
                                                    const int *__restrict__ gid, const int *__restrict__ level, int *flag)
 {
     auto key_at = [&](int j) {
         const int s = src[j];
-        return s >= 0 ? (long long)gid[s] * 128 + level[s] : -1ll;
+        return (unsigned)s < (unsigned)n ? (long long)gid[s] * 128 + level[s] : -1ll;   // (>= n: ST_ENDPOINT is set)
     };
     GS_LOOP(j, E + 1) {
         int f = 0;
@@ -1003,20 +1008,20 @@ int gnn_plan_build_sizes(const int32_t *src, const int32_t *dst, const int64_t *
     HIP_OK(hipMemsetAsync(w.degn, 0, (size_t)(b.np_max + 1) * sizeof(I2), s), "memset");
     {
         const int64_t nb = (E + kDegSegs - 1) / kDegSegs;
-        GNN_LAUNCH("pb_degrees", pb_degrees, (unsigned)(nb < 2048 ? nb : 2048), 1024, s, src, dst, E, w.deg_in, w.deg_out,
-                   w.hdr);
+        GNN_LAUNCH("pb_degrees", pb_degrees, (unsigned)(nb < 2048 ? nb : 2048), 1024, s, src, dst, E, (int)n, w.deg_in,
+                   w.deg_out, w.hdr);
     }
     GNN_LAUNCH("pb_gid", pb_gid, gs(n), TB, s, hit_ptr, G, n, w.gid);
     int *level = w.lvA;
     if (E <= kSmallSweepSegments)
-        GNN_LAUNCH("pb_levels_small", pb_levels_small, 1, 1024, s, src, dst, (int)E, level);
+        GNN_LAUNCH("pb_levels_small", pb_levels_small, 1, 1024, s, src, dst, (int)E, (int)n, level);
     else
         // in rounds of 12 sweeps (a 10-layer detector graph is done after 11); one 4-byte read-back per
         // round costs ~15 us, the 52 launches it usually saves cost 0.3 ms
     {
         unsigned char *lv8 = reinterpret_cast<unsigned char *>(w.lvB);   // (zeroed with the header)
         for (int t = 1; t <= kMaxLevelIters; ++t) {
-            GNN_LAUNCH("pb_level_sweep", pb_level_sweep, gs(E), TB, s, src, dst, E, lv8, w.chg, t);
+            GNN_LAUNCH("pb_level_sweep", pb_level_sweep, gs(E), TB, s, src, dst, E, (int)n, lv8, w.chg, t);
             if (t % kSweepRound == 0 && t < kMaxLevelIters) {
                 int raised = 1;
                 HIP_OK(hipMemcpyAsync(&raised, w.chg + t, sizeof(int), hipMemcpyDeviceToHost, s), "sweep flag read-back");
@@ -1027,7 +1032,7 @@ int gnn_plan_build_sizes(const int32_t *src, const int32_t *dst, const int64_t *
         GNN_LAUNCH("pb_widen", pb_widen, gs(n), TB, s, lv8, level, n);
     }
     GNN_LAUNCH("pb_fill_i32", pb_fill_i32, gs(n), TB, s, w.down, n, 0x7FFFFFFF);
-    GNN_LAUNCH("pb_down", pb_down, gs(E), TB, s, src, dst, E, level, w.deg_in, w.down);
+    GNN_LAUNCH("pb_down", pb_down, gs(E), TB, s, src, dst, E, (int)n, level, w.deg_in, w.down);
     GNN_LAUNCH("pb_key1", pb_key1, gs(n), TB, s, n, w.deg_in, w.deg_out, w.gid, level, w.down, w.k64a, w.iota, w.hdr);
     size_t tb = w.temp_bytes;
     HIP_OK(rocprim::radix_sort_pairs(w.temp, tb, (const unsigned long long *)w.k64a, w.k64b, (const int *)w.iota, w.base,
@@ -1068,7 +1073,7 @@ int gnn_plan_build_sizes(const int32_t *src, const int32_t *dst, const int64_t *
     tb = w.temp_bytes;
     HIP_OK(rocprim::inclusive_scan(w.temp, tb, (const int *)w.kscr, w.rb, (size_t)E, rocprim::maximum<int>(), s, false),
            "valid-index scan");
-    GNN_LAUNCH("pb_run_flags", pb_run_flags, gs(E + 1), TB, s, src, E, w.rb, w.gid, level, w.mscan);
+    GNN_LAUNCH("pb_run_flags", pb_run_flags, gs(E + 1), TB, s, src, E, (int)n, w.rb, w.gid, level, w.mscan);
     tb = w.temp_bytes;
     HIP_OK(rocprim::exclusive_scan(w.temp, tb, (const int *)w.mscan, w.c_scan, 0, (size_t)E + 1, rocprim::plus<int>(), s, false),
            "run scan");

@@ -240,11 +240,12 @@ class SegmentClassifier(nn.Module):
         self._workspace = None
         self.use_plan = True      # False: per-module CSR kernels instead of the fused pipeline
         self.use_events = True    # batches of small graphs: whole forward in one launch
-        # training on a batch's level-ordered twin (autograd.training_batch): True (default; the twin is
-        # built at the first step on a batch: a plan build and two sorts, ten steps' worth), False, or
-        # "auto" = only from the second time the same batch object is trained on (streams of batches
-        # that never repeat; the first and the later steps on a batch then sum in different orders)
-        self.level_order_training = True
+        # training on a batch's level-ordered twin (autograd.training_batch): "auto" (default) = from the
+        # second time the same batch object is trained on - a stream of never-repeated batches (the
+        # unchanged estimator.py loop hands over fresh dense matrices every step) never pays the twin's
+        # plan build and two sorts, ten steps' worth; the first and the later steps on a batch sum in
+        # different orders.  True = at the first step already, False = never.
+        self.level_order_training = "auto"
         self.exp_product = True   # allow GNN_FLAG_EXP_PRODUCT when the bound check passes
         self.mlp_bf16 = False     # hidden_dim 32 / 64: hit update on the matrix cores (bf16 operands,
                                   # fp32 accumulate; scores move by ~1e-3 - opt-in, GNN_FLAG_BF16_MLP)
@@ -306,7 +307,9 @@ class SegmentClassifier(nn.Module):
         key = self._param_key()
         cached = getattr(plan, "_xp", None)
         if cached is None or cached[0] is not self or cached[1] != key:
-            bound = _lib.exp_product_bound(weights, self.input_dim, self.hidden_dim, plan.x_absmax)
+            # the width the kernels RUN at: `weights` are the compacted tensors when masks have killed
+            # whole units (W1' is [D_run, 2 (F + D_run)]), not the module's hidden_dim
+            bound = _lib.exp_product_bound(weights, self.input_dim, int(weights[2].shape[0]), plan.x_absmax)
             cached = plan._xp = (self, key, _lib.GNN_FLAG_EXP_PRODUCT if bound <= 60.0 else 0)
         self._xp_cache = (key, cached[2])       # last decision taken (tests / diagnostics)
         return cached[2]

@@ -44,6 +44,9 @@ class HipSellPlan(SellPlan):
         ws = torch.empty(_lib.plan_build_workspace_bytes(n, E, CH), dtype=torch.uint8, device=dev)
         sz = _lib.plan_build_sizes(src, dst, hit_ptr, n, E, G, tile_hits, int(limits["iter_records"]), CH,
                                    int(limits["edge_records"]), ws)
+        if sz.status & 64:      # ST_ENDPOINT: the numpy builder's ValueError, not a fallback
+            raise ValueError("segment endpoint out of range, or a segment with exactly one padded end "
+                             "(a padded segment must have src = dst = -1)")
         if sz.status:
             raise PlanBuilderUnsupported("plan builder status %d" % sz.status)
         if max(sz.in_total, sz.out_total) + 64 >= 2 ** 31:

@@ -130,11 +130,12 @@ class GradBucket:
             if order is not None:
                 # targets in the twin's order, kept with the twin while the caller's tensor is unchanged
                 # (a 4-byte gather over every segment is 35 us at 3.2 M segments)
-                key = (y.data_ptr(), y._version, tuple(y.shape))
+                # (the entry holds `y` itself: an address-and-version key would also match a NEW tensor
+                # the allocator placed at a freed one's address - stale labels, silently)
                 kept = getattr(batch, "_y_sorted", None)
-                if kept is None or kept[0] != key:
-                    kept = batch._y_sorted = (key, yv.index_select(0, order))
-                yv = kept[1]
+                if kept is None or kept[0] is not y or kept[1] != y._version:
+                    kept = batch._y_sorted = (y, y._version, yv.index_select(0, order))
+                yv = kept[2]
             loss_sum, ge = _lib.bce_loss(e_all[T], yv, 1.0)
             into = [p.grad for p in self.params]
             if lay is not None:

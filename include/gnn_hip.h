@@ -269,7 +269,9 @@ int gnn_node_bwd(const float *H, int32_t ldh, const float *e, const float *Hnext
  * boundaries, non-decreasing); tile_hits / iter_records / chunk_segments / edge_records as
  * gnn_plan_limits gives them (after the caller's small-batch adjustments, plan.py).  sizes.status
  * != 0: this batch is outside the builder's static bounds (degree >= 65536, > n/16 + 1024 tiles,
- * ...) - build the plan with plan.py / plan_device.py instead.  n_hits, n_segments > 0. */
+ * ...) - build the plan with plan.py / plan_device.py instead; bit 64 of status: a segment end
+ * outside [0, n_hits) or a segment with exactly one negative end (malformed batch: the kernels
+ * skip such segments, the caller must raise).  n_hits, n_segments > 0. */
 typedef struct gnn_plan_sizes {
     int64_t n_pad, n_tiles, n_slices, n_chunks;
     int64_t in_total, out_total;        /* entries of in_nbr / out_nbr before their 64 zero entries */

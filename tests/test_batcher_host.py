@@ -96,6 +96,23 @@ def test_batch_generator_yields_the_reference_batches(name, layout):
     assert seen[:nb] == seen[nb:]                 # epochs reuse the batches (plans / CSRs with them)
 
 
+def test_batch_generator_cache_is_bounded_by_bytes():
+    """The generator keeps batches (and what hangs off them: CSRs, plans, level-ordered twins) only
+    while their estimated bytes fit `max_cached_bytes`; beyond that, and with cache=False, it holds
+    nothing between uses - like the reference's generator (gnn/trainSegmentClassifier.py:97-111)."""
+    from gnn_fpga_amd.batcher import _batch_bytes, merge_graphs
+    graphs = [synth.layered_graph(200, 900, 3, seed=s) for s in range(6)]
+    one = _batch_bytes(*merge_graphs(graphs[:2]))
+    assert one > 2 * (2 * 900 * 8 + 2 * 200 * 12)               # twin and plans are counted
+    for kw, reused in (({}, [True, True, True]), ({"cache": False}, [False] * 3),
+                       ({"max_cached_bytes": int(2.5 * one)}, [True, True, False])):
+        gen = gnn_fpga_amd.batch_generator(graphs, n_samples=6, batch_size=2, **kw)
+        first = [next(gen)[0] for _ in range(3)]
+        second = [next(gen)[0] for _ in range(3)]
+        assert [a is b for a, b in zip(first, second)] == reused, kw
+        assert all(np.array_equal(a.src.numpy(), b.src.numpy()) for a, b in zip(first, second))
+
+
 def test_padded_batch_from_hit_graphs_matches_the_dense_adapter():
     graphs = [synth.muon_graph(s) for s in (3, 4, 5, 6)]
     b = HitGraphBatch.from_graphs(graphs, pad_segments=True)

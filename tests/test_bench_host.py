@@ -51,3 +51,27 @@ def test_wrong_world_size_is_refused(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4"])
     with pytest.raises(SystemExit):
         bench.main()
+
+
+def test_gpus_2_dry_run_starts_two_ranks_that_meet_over_gloo():
+    """`python bench.py --gpus 2 --dry-run` as the driver would start it without torchrun: the parent
+    spawns torch.distributed.run, the two child ranks rendezvous on 127.0.0.1 and all-reduce over
+    gloo, rank 0's JSON line is relayed, the exit code is the children's."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR",
+                                                              "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-run"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec == {"dry_run": True, "ranks": 2, "n_gpus": 2}
+    # and under a torchrun environment (the driver's form) the same file is a rank, not a parent
+    port = bench.free_port()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "bench.py"),
+                        "--gpus", "2", "--dry-run"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")] == [rec]

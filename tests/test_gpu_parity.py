@@ -756,8 +756,7 @@ def test_training_on_the_level_ordered_twin(hip, D):
         loss.backward()
         return out.detach().clone(), loss.detach().clone(), [p.grad.detach().clone() for p in m.parameters()]
 
-    assert m.level_order_training is True
-    m.level_order_training = "auto"                  # opt-in: from the second use of a batch object
+    assert m.level_order_training == "auto"          # the default: from the second use of a batch object
     b2 = HitGraphBatch(b.X.cpu().numpy(), src, dst, y=b.y.cpu().numpy(), hit_ptr=b.hit_ptr, seg_ptr=b.seg_ptr).cuda()
     m.zero_grad(); BCELoss()(m(b2), y).backward()
     assert getattr(b2, "_twin", None) is None

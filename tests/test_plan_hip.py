@@ -108,6 +108,27 @@ def test_hip_builder_is_the_default_and_declines_what_it_cannot_hold(hip, monkey
         HipSellPlan(HitGraphBatch.from_graphs([hub]).cuda(), hip.plan_limits(3, 8))
 
 
+def test_hip_builder_refuses_malformed_endpoints(hip):
+    """A malformed index-form batch on the device (an endpoint >= n_hits, a segment with exactly one
+    padded end) must come back as the ValueError the numpy builder's path gives - not as out-of-range
+    global atomics / stores of the builder kernels (status bit ST_ENDPOINT, set by pb_degrees; every
+    kernel that indexes per-hit arrays before the status read-back skips such segments)."""
+    from gnn_fpga_amd.plan_hip import HipSellPlan
+    g = synth.layered_graph(5000, 40000, 3, seed=2)
+    for bad_src, bad_dst in (((123, 5000 + 7), None), (None, (40, 2 ** 30)), ((77, -1), None), (None, (9, -5))):
+        b = HitGraphBatch.from_graphs([g]).cuda()
+        src, dst = b.src.clone(), b.dst.clone()            # corrupt the DEVICE arrays: no host check sees them
+        if bad_src:
+            src[bad_src[0]] = bad_src[1]
+        if bad_dst:
+            dst[bad_dst[0]] = bad_dst[1]
+        b.src, b.dst = src, dst
+        with pytest.raises(ValueError):
+            HipSellPlan(b, hip.plan_limits(3, 8))
+    ok = HitGraphBatch.from_graphs([g]).cuda()
+    HipSellPlan(ok, hip.plan_limits(3, 8))                  # the device is still healthy
+
+
 def test_forward_on_a_hip_built_plan_matches_the_oracle(hip):
     from gnn_fpga_amd.model import SegmentClassifier
     from gnn_fpga_amd.plan_hip import HipSellPlan

@@ -87,3 +87,60 @@ def test_pruned_model_runs_the_narrower_kernels(hip, name, route):
     for k, p in m.named_parameters():
         if k in fx.masks:
             assert np.all(p.grad.cpu().numpy()[fx.masks[k] == 0] == 0)
+
+
+def test_params_struct_rejects_tensors_of_another_width():
+    """The kernels index the ten tensors as (F, D) says: handing over tensors compacted to another
+    width (W1' [8, 22] read as [16, 38]) must raise before any pointer reaches a kernel."""
+    from gnn_fpga_amd import _lib
+    fx = Fixture("pruned_units_d16_s0")
+    eff = fx.effective_params()
+    w, Dn, _ = compact_dead_units([torch.from_numpy(eff[k]) for k in KEYS], fx.F, fx.D, [4, 8])
+    with pytest.raises(_lib.GnnHipError, match="hidden_dim=%d needs shape" % fx.D):
+        _lib.params_struct(w, fx.F, fx.D)                   # compacted tensors, full-width D
+    with pytest.raises(_lib.GnnHipError, match="ten weight tensors"):
+        _lib.params_struct(w[:9], fx.F, Dn)
+
+
+@pytest.mark.gpu
+def test_exp_product_bound_is_taken_at_the_width_the_kernels_run(hip):
+    """The exp-product decision of a pruned model is made on the compacted weights at THEIR width: the
+    bound equals the formula 2 log2(e) max_row(sum |W1 row| (1 or max|X_k|) + |b1_row|) evaluated in
+    numpy on the tensors the kernels consume.  A dead edge unit with a large bias (W1 row masked,
+    b1 = 30) is folded into b2 by the compaction: the narrower network's bound stays <= 60 (flag on)
+    while the full-width network's exceeds it (flag off) - and both score like the oracle."""
+    from gnn_fpga_amd import _lib
+    fx = Fixture("pruned_units_d16_s0")
+    m = _masked_model(fx).cuda().eval()
+    m.use_events = False
+    dead = int(np.flatnonzero(~fx.masks["edge_network.network.0.weight"].any(axis=1))[0])
+    with torch.no_grad():
+        m.edge_network.network[0].bias[dead] = 30.0
+    params = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    for k, msk in fx.masks.items():
+        params[k] = params[k] * msk
+    ref = index_c.segment_classifier(fx.graph.X, fx.graph.src, fx.graph.dst, params, fx.n_iters)
+
+    def bound_np(w, F):
+        W1, b1 = w[2].cpu().numpy().astype(np.float64), w[3].cpu().numpy().astype(np.float64)
+        D = W1.shape[0]
+        C = F + D
+        xmax = np.abs(fx.graph.X).max(axis=0)
+        scale = np.concatenate([np.ones(D), xmax])
+        p = np.abs(W1[:, :C]) @ scale + np.abs(b1)
+        q = np.abs(W1[:, C:]) @ scale
+        return 2.8853900817779268 * max(p.max(), q.max())
+
+    for prune, want_flag in ((True, _lib.GNN_FLAG_EXP_PRODUCT), (False, 0)):
+        m.prune_dead_units = prune
+        m.invalidate()
+        b = HitGraphBatch.from_graphs([fx.graph]).cuda()
+        with torch.no_grad():
+            e = m(b)
+        w, _, D_run = m._cached_weights()
+        assert D_run == (8 if prune else fx.D) and w[2].shape[0] == D_run
+        got = _lib.exp_product_bound(w, fx.F, D_run, b.plan.x_absmax)
+        assert abs(got - bound_np(w, fx.F)) < 1e-3 * max(1.0, got)
+        assert (got <= 60.0) == bool(want_flag)
+        assert m._xp_cache[1] == want_flag
+        assert np.abs(e.cpu().numpy() - ref).max() < TOL
