@@ -14,6 +14,15 @@ namespace gnn {
 int fail(int code, const char *fmt, ...);
 void prof_pre(const char *name, hipStream_t s);
 void prof_post(hipStream_t s);
+// gnn_profile_begin/end: the launches of ONE library call are timed from one event per kernel boundary
+// (see Profiler::chain); put one at the top of an entry point that launches several kernels
+struct ProfChain {
+    bool prev;
+    ProfChain();
+    ~ProfChain();
+    ProfChain(const ProfChain &) = delete;
+    ProfChain &operator=(const ProfChain &) = delete;
+};
 
 #define GNN_LAUNCH(NAME, KERNEL, GRID, BLOCK, STREAM, ...)                                       \
     do {                                                                                         \

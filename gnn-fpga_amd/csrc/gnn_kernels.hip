@@ -40,7 +40,14 @@ struct Profiler {
     int cap = 0;
     std::vector<hipEvent_t> ev;     // 2 per record
     std::vector<const char *> name;
+    std::vector<int> start;         // index of the event a record starts at
     int n = 0;
+    // Inside one library call that launches several kernels back to back (ProfChain), a kernel's
+    // interval starts at the event recorded behind the previous kernel: ONE event per kernel
+    // boundary, so the intervals of a call tile its time exactly - each is the kernel plus the
+    // boundary to the next launch, as in an unprofiled run - instead of two event packets per
+    // kernel, whose processing time (~10 us per pair) ended up inside every interval.
+    bool chain = false, have_prev = false;
 };
 Profiler g_prof;
 
@@ -48,7 +55,12 @@ void prof_pre(const char *name, hipStream_t s)
 {
     if (g_prof.on && g_prof.n < g_prof.cap) {
         g_prof.name[g_prof.n] = name;
-        (void)hipEventRecord(g_prof.ev[2 * g_prof.n], s);
+        if (g_prof.chain && g_prof.have_prev && g_prof.n > 0) {
+            g_prof.start[g_prof.n] = 2 * (g_prof.n - 1) + 1;
+        } else {
+            g_prof.start[g_prof.n] = 2 * g_prof.n;
+            (void)hipEventRecord(g_prof.ev[2 * g_prof.n], s);
+        }
     }
 }
 void prof_post(hipStream_t s)
@@ -56,7 +68,16 @@ void prof_post(hipStream_t s)
     if (g_prof.on && g_prof.n < g_prof.cap) {
         (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], s);
         g_prof.n++;
+        g_prof.have_prev = true;
     }
+}
+ProfChain::ProfChain() : prev(g_prof.chain)
+{
+    if (!prev) { g_prof.chain = true; g_prof.have_prev = false; }
+}
+ProfChain::~ProfChain()
+{
+    if (!prev) g_prof.chain = g_prof.have_prev = false;
 }
 
 }  // namespace gnn
@@ -1114,6 +1135,7 @@ int gnn_segclf_forward(const gnn_graph_t *g, const gnn_params_t *p, int32_t n_it
                        float *e_trace, float *H_trace, void *workspace, size_t workspace_bytes,
                        void *stream)
 {
+    gnn::ProfChain chain_;
     if (!g || !p || n_iters < 0 || g->n_hits < 0 || g->n_segments < 0)
         return fail(GNN_ERR_BADARG, "gnn_segclf_forward: bad argument");
     if (g->n_segments > 0 && (!e_out || !g->src || !g->dst))
@@ -1140,6 +1162,7 @@ int gnn_segclf_forward_train(const gnn_graph_t *g, const gnn_params_t *p, int32_
                              float *e_all, float *H_all, float *Q_all, void *workspace,
                              size_t workspace_bytes, void *stream)
 {
+    gnn::ProfChain chain_;
     if (!g || !p || n_iters < 0 || g->n_hits < 0 || g->n_segments < 0)
         return fail(GNN_ERR_BADARG, "gnn_segclf_forward_train: bad argument");
     if ((g->n_segments > 0 && (!e_all || !g->src || !g->dst)) || (g->n_hits > 0 && (!H_all || !g->X || !g->in_ptr || !g->out_ptr)))
@@ -1170,6 +1193,7 @@ int gnn_segclf_backward(const gnn_graph_t *g, const gnn_params_t *p, int32_t n_i
                         const float *grad_out, const gnn_grads_t *gr, void *workspace,
                         size_t workspace_bytes, void *stream)
 {
+    gnn::ProfChain chain_;
     if (!g || !p || !gr || n_iters < 0 || g->n_hits < 0 || g->n_segments < 0 || !workspace)
         return fail(GNN_ERR_BADARG, "gnn_segclf_backward: bad argument");
     if ((g->n_segments > 0 && (!e_all || !grad_out)) || (g->n_hits > 0 && !H_all))
@@ -1361,6 +1385,8 @@ int gnn_profile_begin(int32_t capacity)
     for (hipEvent_t ev : g_prof.ev) (void)hipEventDestroy(ev);
     g_prof.ev.assign(2 * (size_t)capacity, nullptr);
     g_prof.name.assign((size_t)capacity, nullptr);
+    g_prof.start.assign((size_t)capacity, 0);
+    g_prof.chain = g_prof.have_prev = false;
     for (auto &ev : g_prof.ev) {
         hipError_t err = hipEventCreate(&ev);
         if (err != hipSuccess) return fail(-(int)err, "hipEventCreate failed");
@@ -1380,7 +1406,7 @@ int gnn_profile_end(const char **names, float *ms, int32_t capacity_out)
         if (err != hipSuccess) return fail(-(int)err, "hipEventSynchronize failed");
         if (i < capacity_out) {
             float t = 0.0f;
-            (void)hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]);
+            (void)hipEventElapsedTime(&t, g_prof.ev[g_prof.start[i]], g_prof.ev[2 * i + 1]);
             if (ms) ms[i] = t;
             if (names) names[i] = g_prof.name[i];
         }

@@ -556,8 +556,17 @@ struct BL {                     // bf16 table layout, in 4-byte words
 };
 
 // row `o` of the record product in OUTPUT order -> (weight row pointer of length C, bias, scale)
+// Row order of the exact-fp32 records at D = 64 ("halves"): [P(D) | R(D)] - a hit's own P (or Q) half
+// is then 256 contiguous bytes, so reading it touches two lines of the 512-byte row, not four (the
+// interleaved order below costs every own-value read the whole row: 2.5 MB per 5000-hit level and
+// direction at c5).  A gathering lane reads its P piece and its R piece with one 16-byte load each,
+// as before.  bf16 rows and D = 32 keep the interleaved order (one load fetches both pieces there).
+template <int D, bool EX>
+constexpr bool row_halves() { return EX && D == 64; }
+
 template <int F, int D>
-__device__ __forceinline__ float record_weight(const gnn_params_t &p, bool last, int o, int k, bool bias)
+__device__ __forceinline__ float record_weight(const gnn_params_t &p, bool last, int o, int k, bool bias,
+                                               bool halves = false)
 {
     constexpr int C = F + D, d4 = D / 4;
     int m, d;                                  // m: 0 P, 1 R, 2 Q, 3 S, 4 U (table_entry's blocks)
@@ -567,6 +576,10 @@ __device__ __forceinline__ float record_weight(const gnn_params_t &p, bool last,
     } else if (o >= 4 * D) {
         m = 4;
         d = o - 4 * D;
+    } else if (halves) {
+        const int row = o / (2 * D), pos = o % (2 * D);
+        m = 2 * row + (pos >= D);
+        d = pos % D;
     } else {
         // bf16 record rows for k_iter_w, where a hit is 16 lanes and lane p owns dims DL p .. (DL =
         // D / 16): [P(DL) R(DL)] per lane, so ONE load per lane fetches its piece of both halves and
@@ -644,6 +657,27 @@ __device__ __forceinline__ bf16x8_t act_frag(const float (*v)[4], int st)
     const u4v w = {pack_bf16(v[2 * st][0], v[2 * st][1]), pack_bf16(v[2 * st][2], v[2 * st][3]),
                    pack_bf16(v[2 * st + 1][0], v[2 * st + 1][1]), pack_bf16(v[2 * st + 1][2], v[2 * st + 1][3])};
     return __builtin_bit_cast(bf16x8_t, w);
+}
+
+// Stores of the NEXT pass's records / vectors: nobody reads them in this launch, but as plain stores
+// their lines stay in the XCD's L2 (6.4 MB per 5000-hit level at D = 64) and push out the record
+// tables the sweeps gather from.  GNN_WT_STORES=1 builds write them through (sc1: the line is not
+// kept, MI355X_MICROARCH.md "stores of each flavour").
+__device__ __forceinline__ void store4_next(float *dst, float __attribute__((ext_vector_type(4))) c)
+{
+#ifdef GNN_WT_STORES
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(c) : "memory");
+#else
+    *reinterpret_cast<float __attribute__((ext_vector_type(4))) *>(dst) = c;
+#endif
+}
+__device__ __forceinline__ void store2_next(unsigned *dst, uint2 c)
+{
+#ifdef GNN_WT_STORES
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst), "v"(c) : "memory");
+#else
+    *reinterpret_cast<uint2 *>(dst) = c;
+#endif
 }
 
 template <int F, int D, bool LAST, bool XP>
@@ -757,9 +791,9 @@ __device__ __forceinline__ void mfma_records(const bf16x8_t *Tm, const float *bm
             // gather records travel as bf16 (row = 2D halfwords, same position order): half the
             // bytes per list step, half the registers per record group
             unsigned *row = reinterpret_cast<unsigned *>(o < 2 * D ? PRn : QSn) + n * D + (o % (2 * D)) / 2;
-            *reinterpret_cast<uint2 *>(row) = make_uint2(pack_bf16(c.x, c.y), pack_bf16(c.z, c.w));
+            store2_next(row, make_uint2(pack_bf16(c.x, c.y), pack_bf16(c.z, c.w)));
         } else {
-            *reinterpret_cast<f4v *>(dst) = c;
+            store4_next(dst, c);
         }
     }
 }
@@ -800,11 +834,12 @@ __global__ __launch_bounds__(256) void k_pack32(gnn_params_t p, float *__restric
                                                 int64_t n_pad, int xp)
 {
     using B = BX<F, D>;
+    constexpr bool HV = row_halves<D, true>();
     if (blockIdx.x == 0 && threadIdx.x < 2 * D) {       // fp32 NULL records in k_iter_w's row order
         constexpr int DL = D / 16;
         const int t = threadIdx.x, blk = t / (2 * DL), w = t % (2 * DL);
-        const bool is_p = w < DL;
-        float pv = is_p ? kTwoLog2e * p.b1[blk * DL + w] : 0.0f;
+        const bool is_p = HV ? t < D : w < DL;
+        float pv = is_p ? kTwoLog2e * p.b1[HV ? t : blk * DL + w] : 0.0f;
         if (xp && is_p) pv = __builtin_amdgcn_exp2f(pv);
         const float qv = (xp && is_p) ? 1.0f : 0.0f;
         PRa[n_pad * 2 * D + t] = PRb[n_pad * 2 * D + t] = pv;
@@ -821,15 +856,15 @@ __global__ __launch_bounds__(256) void k_pack32(gnn_params_t p, float *__restric
             const int fr = frag - (last ? B::o_tml : B::o_tmn) / 64;
             const int T = fr / B::KS2, st = fr % B::KS2, o = 16 * T + (l & 15);
             const int k = st < B::KS1 ? B::kidx(st, g) : (g < F ? D + g : -1);
-            v = k < 0 ? 0.0f : record_weight<F, D>(p, last, o, k, false);
+            v = k < 0 ? 0.0f : record_weight<F, D>(p, last, o, k, false, HV);
         }
         tf[i] = v;
     }
     for (int i = blockIdx.x * 256 + threadIdx.x; i < 8 * D; i += gridDim.x * 256) {
         float v;
         if (i < D) v = p.b4[i];
-        else if (i < 6 * D) v = record_weight<F, D>(p, false, i - D, 0, true);
-        else v = record_weight<F, D>(p, true, i - 6 * D, 0, true);
+        else if (i < 6 * D) v = record_weight<F, D>(p, false, i - D, 0, true, HV);
+        else v = record_weight<F, D>(p, true, i - 6 * D, 0, true, HV);
         tf[B::o_b4 + i] = v;
     }
 }
@@ -867,14 +902,15 @@ __device__ __forceinline__ void mfma_records_x(const float *Tm, const float *bm,
         } else {
             dst = (o < 2 * D ? PRn + n * 2 * D + o : QSn + n * 2 * D + (o - 2 * D));
             constexpr int DL = D / 16;
-            expo = (o % (2 * DL)) < DL;
-            expo_half = DL == 2;
+            constexpr bool HV = row_halves<D, true>();
+            expo = HV ? (o % (2 * D)) < D : (o % (2 * DL)) < DL;
+            expo_half = !HV && DL == 2;
         }
         if (XP && expo) {
             c.x = __builtin_amdgcn_exp2f(c.x); c.y = __builtin_amdgcn_exp2f(c.y);
             if (!expo_half) { c.z = __builtin_amdgcn_exp2f(c.z); c.w = __builtin_amdgcn_exp2f(c.w); }
         }
-        *reinterpret_cast<f4v *>(dst) = c;
+        store4_next(dst, c);
     }
 }
 
@@ -1659,12 +1695,12 @@ template <> struct PieceW<2> {
 };
 // the same pieces of fp32 rows (exact mode): 32 bytes at D = 64, 16 at D = 32
 template <int DL> struct PieceX;
-template <> struct PieceX<4> {
+template <> struct PieceX<4> {         // D = 64, rows [P(64) | R(64)] (row_halves): the R piece is 256 bytes on
     float4 a, b;
     __device__ __forceinline__ void load(const void *p)
     {
         a = reinterpret_cast<const float4 *>(p)[0];
-        b = reinterpret_cast<const float4 *>(p)[1];
+        b = reinterpret_cast<const float4 *>(p)[16];
     }
     __device__ __forceinline__ void first(float *f) const { f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; }
     __device__ __forceinline__ void second(float *f) const { f[0] = b.x; f[1] = b.y; f[2] = b.z; f[3] = b.w; }
@@ -1680,6 +1716,8 @@ template <int D, bool EX = false>
 struct RecW {                   // one step group (4 list steps): this lane's piece of each of the 4 records
     static constexpr int DL = D / 16;
     static constexpr unsigned row_bytes = (EX ? 8 : 4) * D;      // 2D fp32 or 2D bf16
+    // byte offset of lane p's piece inside a row (halves order: the P piece; R follows 4 D bytes on)
+    static constexpr unsigned piece_bytes = row_halves<D, EX>() ? 4 * DL : (EX ? 8 : 4) * DL;
     std::conditional_t<EX, PieceX<DL>, PieceW<DL>> r[4];
     // 32-bit byte offsets off the wave-uniform table base (one v_lshl_or / v_mad per address instead
     // of a 64-bit multiply-add; the host checks that the table is below 4 GB)
@@ -1758,7 +1796,7 @@ __device__ __forceinline__ void sweep_w(const int32_t *__restrict__ lst, int i16
     if (len <= 0) return;
     constexpr int DL = D / 16;
     const int ng = (len + 3) >> 2;
-    const unsigned lane_off = (unsigned)((EX ? 8 : 4) * DL * p);
+    const unsigned lane_off = RecW<D, EX>::piece_bytes * (unsigned)p;
     const unsigned st_off = (unsigned)((SLICE * (p & 3) + i16) * 4);      // byte offset of step (p & 3)
     auto index_of = [&](int c) {               // lane p reads step 4c + (p & 3); quads broadcast it
         const int cur = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(lst) +
@@ -1780,19 +1818,35 @@ __device__ __forceinline__ void sweep_w(const int32_t *__restrict__ lst, int i16
     }
 }
 
+// this hit's own P (or Q) values: lane p's DL dims of the first half of the hit's row in REC
+template <int D, bool EX>
+__device__ __forceinline__ void load_own_w(const unsigned *__restrict__ REC, int64_t n, int p, float *out)
+{
+    constexpr int DL = D / 16;
+    if constexpr (row_halves<D, EX>()) {
+        load_vec<DL>(reinterpret_cast<const float *>(REC) + n * 2 * D + DL * p, out);
+    } else {
+        constexpr int WPR = EX ? 2 * D : D, WPL = EX ? 2 * DL : DL;   // 4-byte words per row / per lane piece
+        std::conditional_t<EX, PieceX<DL>, PieceW<DL>> w;
+        w.load(REC + n * WPR + WPL * p);
+        w.first(out);
+    }
+}
+
 template <int F, int D, bool LAST, bool XP, bool EX = false>
 __global__ __launch_bounds__(1024) void k_iter_w(
     const float *__restrict__ X, const float *__restrict__ table, const unsigned *__restrict__ t16,
     const int32_t *__restrict__ tiles, const int32_t *__restrict__ in_off, const int32_t *__restrict__ in_nbr,
     const int32_t *__restrict__ out_off, const int32_t *__restrict__ out_nbr, const unsigned *__restrict__ PR,
     const unsigned *__restrict__ QS, float *__restrict__ U, float *__restrict__ PRn, float *__restrict__ QSn,
-    float *__restrict__ Pc, float *__restrict__ Qc, int64_t n_pad, int tiles_per_xcd, int n_tiles)
+    float *__restrict__ Pc, float *__restrict__ Qc, int64_t n_pad, int tiles_per_xcd, int n_tiles, int wmax)
 {
     using L = TL<F, D>;
     using B = std::conditional_t<EX, BX<F, D>, BL<F, D>>;      // EX: exact fp32 fragments and fp32 record rows
     static_assert(D % 32 == 0, "16 lanes x 4 dims per hit, matrix-core tail");
-    (void)tiles; (void)tiles_per_xcd; (void)n_tiles;   // (the walk is over slices; tiles only order them)
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    // (no static LDS: the opt-in for > 64 KB of dynamic LDS is for the whole 160 KB)
+    int *grp = reinterpret_cast<int *>(smem + B::template lds_words<LAST>() + (EX ? 12 : 8) * 16 * B::tr_stride);
     unsigned *tb = reinterpret_cast<unsigned *>(smem);
     {
         constexpr int n1 = B::NT1 * B::KS1 * (EX ? 64 : 256), nm = B::template tm_words<LAST>();
@@ -1802,14 +1856,11 @@ __global__ __launch_bounds__(1024) void k_iter_w(
         for (int i = threadIdx.x; i < (LAST ? 2 : 5) * D; i += 1024)
             tb[n1 + nm + D + i] = t16[(LAST ? B::o_bml : B::o_bmn) + i];
     }
-    __syncthreads();                                   // the only barrier: waves are independent below
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int hs = lane >> 4, p = lane & 15;
     // Teams: 4 waves share a slice (wave m of team t sweeps hits 4m .. 4m+3), so only 4 slices per
-    // CU = 2048 hits per XCD are in progress at a time and the records they gather (one level's
-    // [P|R] and [Q|S] tables, 2.6 MB at 5000-hit levels) stay in the XCD's 4 MB L2 - with a whole
-    // slice per wave the 8192 hits in progress per XCD span 1.6 levels and 52 % of the gathers
-    // missed L2 (profiles/r02_c5_b).  The team's scratch is double-buffered: one barrier per round.
+    // CU = 2048 hits per XCD are in progress at a time.  The team's scratch is double-buffered: one
+    // barrier per round.
     const int team = wv >> 2, mem = wv & 3;
     float *scratch = smem + B::template lds_words<LAST>();
     constexpr int DL = D / 16;                         // dims per lane
@@ -1817,35 +1868,82 @@ __global__ __launch_bounds__(1024) void k_iter_w(
 #pragma unroll
     for (int i = 0; i < DL; ++i) w2[i] = table[(p >> 2) * L::stride + L::o_w2 + DL * (p & 3) + i];
     const float b2 = table[L::o_b2];
-    // XCD x (blockIdx & 7) walks its own contiguous eighth of the slices (whole graphs stay in one
-    // L2); its workgroups take consecutive groups of 4 slices round-robin, so the slices in progress
-    // on an XCD are one contiguous run of 4 x (workgroups per XCD) slices
+    // XCD x (blockIdx & 7) walks its own contiguous eighth of the TILES (whole graphs stay in one L2).
+    // GROUPS: consecutive tiles whose start hits of incoming segments (and end hits of outgoing ones)
+    // lie in at most `wmax` consecutive records each - what an XCD's L2 holds of ONE record table (a
+    // detector level's tiles share both windows, so a group is normally a level).  A workgroup runs ALL
+    // in-sweeps of its slices of a group (only the [P|R] window is gathered from), parks the partial
+    // sums in U, then all out-sweeps + hit updates (only the [Q|S] window): the two 2.5 MB tables of a
+    // 5000-hit level at D = 64 are never live together in the 4 MB L2 (they were: 54 % hit rate,
+    // 2.6 GB of traffic per launch for 0.41 GB of records, profiles/r02_c5_final_f32).  Slices stay
+    // dealt round-robin in quads over the XCD's workgroups across group boundaries (every workgroup
+    // the same number +- 1 over the launch; no workgroup waits for another: the order is for locality
+    // only).
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
-    const int n_slices = (int)(n_pad / SLICE);
-    const int span = (((n_slices + 7) >> 3) + 3) & ~3;
-    const int s_end = (xcd + 1) * span < n_slices ? (xcd + 1) * span : n_slices;
+    const int t_begin = xcd * tiles_per_xcd;
+    const int t_end = t_begin + tiles_per_xcd < n_tiles ? t_begin + tiles_per_xcd : n_tiles;
+    __syncthreads();                                   // tables staged
+    if (t_begin >= t_end) return;                      // (workgroup-uniform)
+    const int x0 = __builtin_amdgcn_readfirstlane(tiles[(int64_t)t_begin * DESC]);
     int buf = 0;
-    {
-        for (int s0 = xcd * span + 4 * local; s0 < s_end; s0 += 4 * per_xcd, buf ^= 1) {   // workgroup-uniform
-            const int sl = s0 + team;
+    for (int t = t_begin; t < t_end;) {
+        if (wv == 0) {                                 // the next group: tiles t .. t + cnt - 1
+            const int tt = t + lane;
+            const bool in = tt < t_end;
+            const int32_t *d = tiles + (int64_t)(in ? tt : t) * DESC;
+            const int s1 = d[1];
+            int ilo = in && d[3] > 0 ? d[2] : 0x7FFFFFFF, ihi = in && d[3] > 0 ? d[2] + d[3] : -1;
+            int olo = in && d[5] > 0 ? d[4] : 0x7FFFFFFF, ohi = in && d[5] > 0 ? d[4] + d[5] : -1;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {         // inclusive prefix union of the windows
+                const int a = __shfl_up(ilo, o, 64), b = __shfl_up(ihi, o, 64);
+                const int c = __shfl_up(olo, o, 64), e = __shfl_up(ohi, o, 64);
+                if (lane >= o) {
+                    ilo = a < ilo ? a : ilo; ihi = b > ihi ? b : ihi;
+                    olo = c < olo ? c : olo; ohi = e > ohi ? e : ohi;
+                }
+            }
+            const bool ok = in && (lane == 0 || ((int64_t)ihi - ilo <= wmax && (int64_t)ohi - olo <= wmax));
+            const unsigned long long m = ~__ballot(ok);          // (ok is monotone along the lanes)
+            const int cnt = m ? __builtin_ctzll(m) : 64;
+            const int send = __shfl(s1, cnt - 1, 64);
+            if (lane == 0) { grp[0] = d[0]; grp[1] = send; grp[2] = t + cnt; }
+        }
+        __syncthreads();
+        const int sg0 = grp[0], sg1 = grp[1];
+        t = grp[2];
+        __syncthreads();                               // (grp is rewritten for the next group)
+        // this workgroup's quads of the group: q = local (mod per_xcd), slices x0 + 4 q + team
+        const int qmin = (sg0 - x0) >> 2;
+        const int q0 = qmin + (((local - qmin) % per_xcd) + per_xcd) % per_xcd;
+        // ---- phase A: segments ENDING at the hit: P[start] with the hit's own Q, adds e R[start]
+        for (int q = q0; x0 + 4 * q < sg1; q += per_xcd) {
+            const int sl = x0 + 4 * q + team;
+            if (sl < sg0 || sl >= sg1) continue;
+            const int ib = __builtin_amdgcn_readfirstlane(in_off[sl]);
+            const int il = (__builtin_amdgcn_readfirstlane(in_off[sl + 1]) - ib) >> 4;
+            if (il <= 0) continue;                     // (wave-uniform; U keeps the start value)
+            const int i16 = 4 * mem + hs;
+            const int64_t n = (int64_t)sl * SLICE + i16;
+            float acc[DL], ownQ[DL];
+            load_vec<DL>(U + n * D + DL * p, acc);
+            load_own_w<D, EX>(QS, n, p, ownQ);
+            sweep_w<D, XP, EX>(in_nbr + ib, i16, il, (int)n_pad, PR, p, ownQ, w2, b2, acc);
+            store_vec<DL>(U + n * D + DL * p, acc);    // (re-read by this same lane in phase B)
+        }
+        // ---- phase B: segments STARTING at the hit, then the hit update and the next records
+        for (int q = q0; x0 + 4 * q < sg1; q += per_xcd, buf ^= 1) {   // workgroup-uniform trip count
+            const int sl = x0 + 4 * q + team;
+            const bool on = sl >= sg0 && sl < sg1;
             float *tr = scratch + (buf * 4 + team) * 16 * B::tr_stride;
-            if (sl < s_end) {
-                const int ib = __builtin_amdgcn_readfirstlane(in_off[sl]);
-                const int il = (__builtin_amdgcn_readfirstlane(in_off[sl + 1]) - ib) >> 4;
+            if (on) {
                 const int ob = __builtin_amdgcn_readfirstlane(out_off[sl]);
                 const int ol = (__builtin_amdgcn_readfirstlane(out_off[sl + 1]) - ob) >> 4;
                 const int i16 = 4 * mem + hs;
                 const int64_t n = (int64_t)sl * SLICE + i16;
-                float acc[DL], ownQ[DL], ownP[DL];
+                float acc[DL], ownP[DL];
                 load_vec<DL>(U + n * D + DL * p, acc);
-                std::conditional_t<EX, PieceX<DL>, PieceW<DL>> qw, pw;
-                constexpr int WPR = EX ? 2 * D : D, WPL = EX ? 2 * DL : DL;   // 4-byte words per row / per lane piece
-                qw.load(QS + n * WPR + WPL * p);
-                pw.load(PR + n * WPR + WPL * p);
-                qw.first(ownQ);
-                pw.first(ownP);
-                // segments ending here: P[start] with own Q, adds e R[start]; then starting here
-                sweep_w<D, XP, EX>(in_nbr + ib, i16, il, (int)n_pad, PR, p, ownQ, w2, b2, acc);
+                load_own_w<D, EX>(PR, n, p, ownP);
                 sweep_w<D, XP, EX>(out_nbr + ob, i16, ol, (int)n_pad, QS, p, ownP, w2, b2, acc);
 #pragma unroll
                 for (int i = 0; i < DL; ++i) acc[i] = tanh_f(acc[i]);
@@ -1853,16 +1951,16 @@ __global__ __launch_bounds__(1024) void k_iter_w(
                 if (p < F) tr[i16 * B::tr_stride + D + p] = X[n * F + p];
             }
             __syncthreads();                           // the team's 16 hits are in the scratch
-            // hit update H' = tanh(W4 tanh(acc) + b4) (every wave of the team, 8 MFMAs) and this
-            // wave's quarter of the record tiles of the next pass (model.py:94-98,125)
+            // hit update H' = tanh(W4 tanh(acc) + b4) and this wave's quarter of the record tiles of
+            // the next pass (model.py:94-98,125)
             if constexpr (EX) {
                 // exact fp32: the team splits the tiles of hl = tanh(W4 q + b4) and meets again in th
                 float *th = scratch + (8 + team) * 16 * B::tr_stride;
-                if (sl < s_end) mfma_hidden_x<F, D, LAST>(smem, tr, th, lane, mem);
+                if (on) mfma_hidden_x<F, D, LAST>(smem, tr, th, lane, mem);
                 __syncthreads();
-                if (sl < s_end)
+                if (on)
                     mfma_tail_scratch_x<F, D, LAST, XP>(smem, tr, th, lane, (int64_t)sl * SLICE, PRn, QSn, U, Pc, Qc, mem, 4);
-            } else if (sl < s_end) {
+            } else if (on) {
                 mfma_tail_scratch<F, D, LAST, XP>(tb, tr, lane, (int64_t)sl * SLICE, PRn, QSn, U, Pc, Qc, mem, 4);
             }
         }
@@ -2692,6 +2790,16 @@ constexpr int t16_words()      // fragment tables of the wide kernels: bf16 (BL)
 template <int F, int D>
 constexpr bool can_exact_wide() { return D % 32 == 0 && F <= 4; }
 
+// k_iter_w's group bound: records of one table an XCD's 4 MB L2 can keep while a group's hits stream
+// through it (3 MB of rows; GNN_WIDE_WINDOW_KB overrides, 0 = every tile a group of its own,
+// 1 << 20 = no grouping effect: experiments)
+inline int wide_window_records(int row_bytes)
+{
+    static const long kb = getenv("GNN_WIDE_WINDOW_KB") ? atol(getenv("GNN_WIDE_WINDOW_KB")) : 3072;
+    const long r = kb * 1024 / row_bytes;
+    return (int)(r < 0 ? 0 : r > 0x3FFFFFFF ? 0x3FFFFFFF : r);
+}
+
 template <int F, int D, bool XP>
 int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e_out, char *ws,
               hipStream_t s)
@@ -2842,18 +2950,19 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
                     }
                     const int ncu = device_cus();
                     const unsigned wgs = (unsigned)(((nt < ncu ? nt : ncu) + 7) / 8 * 8);   // persistent, 8 | grid
-                    const size_t trw = (size_t)2 * 4 * 16 * B::tr_stride;      // double-buffered scratch of the 4 teams
+                    const size_t trw = (size_t)2 * 4 * 16 * B::tr_stride + 4;  // double-buffered scratch of the 4 teams + the group word
+                    const int wmax = wide_window_records(4 * D);
                     const unsigned *PRh = reinterpret_cast<const unsigned *>(PR), *QSh = reinterpret_cast<const unsigned *>(QS);
                     if (t + 1 == n_iters)
                         GNN_LAUNCH_SH("k_iter_w", (k_iter_w<F, D, true, XP>), wgs, 1024,
                                       (B::template lds_words<true>() + trw) * 4, s, pl->X, w.table, w.t16, pl->tiles,
                                       pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PRh, QSh, w.U, PRn, QSn,
-                                      w.Pc, w.Qc, Np, tpx, nt);
+                                      w.Pc, w.Qc, Np, tpx, nt, wmax);
                     else
                         GNN_LAUNCH_SH("k_iter_w", (k_iter_w<F, D, false, XP>), wgs, 1024,
                                       (B::template lds_words<false>() + trw) * 4, s, pl->X, w.table, w.t16, pl->tiles,
                                       pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PRh, QSh, w.U, PRn, QSn,
-                                      w.Pc, w.Qc, Np, tpx, nt);
+                                      w.Pc, w.Qc, Np, tpx, nt, wmax);
                     launched = true;
                 }
             }
@@ -2867,18 +2976,19 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
                     }
                     const int ncu = device_cus();
                     const unsigned wgs = (unsigned)(((nt < ncu ? nt : ncu) + 7) / 8 * 8);
-                    const size_t trw = (size_t)(2 * 4 + 4) * 16 * B::tr_stride;   // double-buffered q scratch + hl scratch
+                    const size_t trw = (size_t)(2 * 4 + 4) * 16 * B::tr_stride + 4;   // double-buffered q scratch + hl scratch + the group word
+                    const int wmax = wide_window_records(8 * D);
                     const unsigned *PRh = reinterpret_cast<const unsigned *>(PR), *QSh = reinterpret_cast<const unsigned *>(QS);
                     if (t + 1 == n_iters)
                         GNN_LAUNCH_SH("k_iter_w", (k_iter_w<F, D, true, XP, true>), wgs, 1024,
                                       (B::template lds_words<true>() + trw) * 4, s, pl->X, w.table, w.t16, pl->tiles,
                                       pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PRh, QSh, w.U, PRn, QSn,
-                                      w.Pc, w.Qc, Np, tpx, nt);
+                                      w.Pc, w.Qc, Np, tpx, nt, wmax);
                     else
                         GNN_LAUNCH_SH("k_iter_w", (k_iter_w<F, D, false, XP, true>), wgs, 1024,
                                       (B::template lds_words<false>() + trw) * 4, s, pl->X, w.table, w.t16, pl->tiles,
                                       pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PRh, QSh, w.U, PRn, QSn,
-                                      w.Pc, w.Qc, Np, tpx, nt);
+                                      w.Pc, w.Qc, Np, tpx, nt, wmax);
                     launched = true;
                 }
             }
@@ -2972,6 +3082,7 @@ size_t sell_workspace_bytes(int64_t n_pad, int64_t n_segments, int F, int D)
 int sell_forward(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e_out, void *ws,
                  size_t ws_bytes, hipStream_t s)
 {
+    ProfChain chain_;      // (profiling runs: one event per kernel boundary of this call)
     const size_t need = sell_workspace_bytes(pl->n_pad, pl->n_segments, p->F, p->D);
     if (need == 0) return fail(GNN_ERR_UNSUPPORTED, "no fused kernel for input_dim=%d hidden_dim=%d", p->F, p->D);
     if (!ws || ws_bytes < need) return fail(GNN_ERR_WORKSPACE, "workspace too small: need %zu bytes", need);

@@ -684,16 +684,33 @@ def test_training_gradients_are_bit_reproducible(hip, kind):
     b = HitGraphBatch.from_graphs(graphs).cuda()
     y = b.y.cuda()
     m = SegmentClassifier(input_dim=F, hidden_dim=8, n_iters=3).cuda().train()
-    runs = []
-    for _ in range(3):
-        m.zero_grad()
-        loss = BCELoss()(m(b), y)
-        loss.backward()
-        runs.append([loss.detach().clone()] + [p.grad.detach().clone() for p in m.parameters()])
-    for other in runs[1:]:
-        for a, c in zip(runs[0], other):
+
+    def three_runs(policy, batch):
+        m.level_order_training = policy
+        runs = []
+        for _ in range(3):
+            m.zero_grad()
+            loss = BCELoss()(m(batch), y)
+            loss.backward()
+            runs.append([loss.detach().clone()] + [p.grad.detach().clone() for p in m.parameters()])
+        return runs
+
+    fixed = {}
+    for policy in (False, True):               # in the caller's order / on the level-ordered twin
+        runs = fixed[policy] = three_runs(policy, b)
+        for other in runs[1:]:
+            for a, c in zip(runs[0], other):
+                assert torch.equal(a, c)
+        assert all(float(g.abs().max()) > 0 for g in runs[0][1:])
+    # the default, "auto": the first step on a batch object runs in the caller's order, every later
+    # one on the twin (detector-size batches only) - each bit-identical to the fixed policy's runs
+    b2 = HitGraphBatch.from_graphs(graphs).cuda()
+    auto = three_runs("auto", b2)
+    for a, c in zip(auto[0], fixed[False][0]):
+        assert torch.equal(a, c)
+    for run in auto[1:]:
+        for a, c in zip(run, fixed[True][0]):
             assert torch.equal(a, c)
-    assert all(float(g.abs().max()) > 0 for g in runs[0][1:])
 
 
 @pytest.mark.parametrize("kind", ["muon events", "detector graphs", "masked"])
