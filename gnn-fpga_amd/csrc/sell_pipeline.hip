@@ -659,27 +659,6 @@ __device__ __forceinline__ bf16x8_t act_frag(const float (*v)[4], int st)
     return __builtin_bit_cast(bf16x8_t, w);
 }
 
-// Stores of the NEXT pass's records / vectors: nobody reads them in this launch, but as plain stores
-// their lines stay in the XCD's L2 (6.4 MB per 5000-hit level at D = 64) and push out the record
-// tables the sweeps gather from.  GNN_WT_STORES=1 builds write them through (sc1: the line is not
-// kept, MI355X_MICROARCH.md "stores of each flavour").
-__device__ __forceinline__ void store4_next(float *dst, float __attribute__((ext_vector_type(4))) c)
-{
-#ifdef GNN_WT_STORES
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(c) : "memory");
-#else
-    *reinterpret_cast<float __attribute__((ext_vector_type(4))) *>(dst) = c;
-#endif
-}
-__device__ __forceinline__ void store2_next(unsigned *dst, uint2 c)
-{
-#ifdef GNN_WT_STORES
-    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst), "v"(c) : "memory");
-#else
-    *reinterpret_cast<uint2 *>(dst) = c;
-#endif
-}
-
 template <int F, int D, bool LAST, bool XP>
 __device__ __forceinline__ void mfma_records(const bf16x8_t *Tm, const float *bm,
                                              const float (*v)[4], bf16x8_t xb, int lane, int64_t n0,
@@ -791,9 +770,9 @@ __device__ __forceinline__ void mfma_records(const bf16x8_t *Tm, const float *bm
             // gather records travel as bf16 (row = 2D halfwords, same position order): half the
             // bytes per list step, half the registers per record group
             unsigned *row = reinterpret_cast<unsigned *>(o < 2 * D ? PRn : QSn) + n * D + (o % (2 * D)) / 2;
-            store2_next(row, make_uint2(pack_bf16(c.x, c.y), pack_bf16(c.z, c.w)));
+            *reinterpret_cast<uint2 *>(row) = make_uint2(pack_bf16(c.x, c.y), pack_bf16(c.z, c.w));
         } else {
-            store4_next(dst, c);
+            *reinterpret_cast<f4v *>(dst) = c;
         }
     }
 }
@@ -910,7 +889,7 @@ __device__ __forceinline__ void mfma_records_x(const float *Tm, const float *bm,
             c.x = __builtin_amdgcn_exp2f(c.x); c.y = __builtin_amdgcn_exp2f(c.y);
             if (!expo_half) { c.z = __builtin_amdgcn_exp2f(c.z); c.w = __builtin_amdgcn_exp2f(c.w); }
         }
-        store4_next(dst, c);
+        *reinterpret_cast<f4v *>(dst) = c;
     }
 }
 
@@ -1875,17 +1854,16 @@ __global__ __launch_bounds__(1024) void k_iter_w(
     // in-sweeps of its slices of a group (only the [P|R] window is gathered from), parks the partial
     // sums in U, then all out-sweeps + hit updates (only the [Q|S] window): the two 2.5 MB tables of a
     // 5000-hit level at D = 64 are never live together in the 4 MB L2 (they were: 54 % hit rate,
-    // 2.6 GB of traffic per launch for 0.41 GB of records, profiles/r02_c5_final_f32).  Slices stay
-    // dealt round-robin in quads over the XCD's workgroups across group boundaries (every workgroup
-    // the same number +- 1 over the launch; no workgroup waits for another: the order is for locality
-    // only).
+    // 2.6 GB of traffic per launch for 0.41 GB of records, profiles/r02_c5_final_f32; 1.8 GB now,
+    // profiles/r03_c5_f32).  The deal of slice quads over the XCD's workgroups continues round-robin
+    // across group boundaries (every workgroup the same number +- 1 over the launch; no workgroup waits
+    // for another: the order is for locality only).
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
     const int t_begin = xcd * tiles_per_xcd;
     const int t_end = t_begin + tiles_per_xcd < n_tiles ? t_begin + tiles_per_xcd : n_tiles;
     __syncthreads();                                   // tables staged
     if (t_begin >= t_end) return;                      // (workgroup-uniform)
-    const int x0 = __builtin_amdgcn_readfirstlane(tiles[(int64_t)t_begin * DESC]);
-    int buf = 0;
+    int buf = 0, rot = 0;
     for (int t = t_begin; t < t_end;) {
         if (wv == 0) {                                 // the next group: tiles t .. t + cnt - 1
             const int tt = t + lane;
@@ -1913,11 +1891,18 @@ __global__ __launch_bounds__(1024) void k_iter_w(
         const int sg0 = grp[0], sg1 = grp[1];
         t = grp[2];
         __syncthreads();                               // (grp is rewritten for the next group)
-        // this workgroup's quads of the group: q = local (mod per_xcd), slices x0 + 4 q + team
-        const int qmin = (sg0 - x0) >> 2;
-        const int q0 = qmin + (((local - qmin) % per_xcd) + per_xcd) % per_xcd;
+        // this workgroup's quads of the group (quad q = slices sg0 + 4 q .. + 3, one per team): dealt
+        // round-robin from where the previous group's deal stopped, so that no quad straddles two
+        // groups (a straddling quad was a round with idle teams in each of them: + 7 % at c5 x 8)
+        const int nq = (sg1 - sg0 + 3) >> 2;
+        const int q0 = (((local - rot) % per_xcd) + per_xcd) % per_xcd;
+        rot = (rot + nq) % per_xcd;
+        const int x0 = sg0;
+        // (bf16 rows: both tables of a level fit the L2 together and the split only costs - 2.27 -> 2.44 ms
+        // at c5 x 8 - so there a hit's two sweeps stay back to back in phase B)
+        constexpr bool SPLIT = EX;
         // ---- phase A: segments ENDING at the hit: P[start] with the hit's own Q, adds e R[start]
-        for (int q = q0; x0 + 4 * q < sg1; q += per_xcd) {
+        for (int q = q0; SPLIT && x0 + 4 * q < sg1; q += per_xcd) {
             const int sl = x0 + 4 * q + team;
             if (sl < sg0 || sl >= sg1) continue;
             const int ib = __builtin_amdgcn_readfirstlane(in_off[sl]);
@@ -1928,7 +1913,9 @@ __global__ __launch_bounds__(1024) void k_iter_w(
             float acc[DL], ownQ[DL];
             load_vec<DL>(U + n * D + DL * p, acc);
             load_own_w<D, EX>(QS, n, p, ownQ);
+#ifndef GNN_ABLATE_W_SWEEP
             sweep_w<D, XP, EX>(in_nbr + ib, i16, il, (int)n_pad, PR, p, ownQ, w2, b2, acc);
+#endif
             store_vec<DL>(U + n * D + DL * p, acc);    // (re-read by this same lane in phase B)
         }
         // ---- phase B: segments STARTING at the hit, then the hit update and the next records
@@ -1943,8 +1930,19 @@ __global__ __launch_bounds__(1024) void k_iter_w(
                 const int64_t n = (int64_t)sl * SLICE + i16;
                 float acc[DL], ownP[DL];
                 load_vec<DL>(U + n * D + DL * p, acc);
-                load_own_w<D, EX>(PR, n, p, ownP);
+                if constexpr (!SPLIT) {
+                    const int ib = __builtin_amdgcn_readfirstlane(in_off[sl]);
+                    const int il = (__builtin_amdgcn_readfirstlane(in_off[sl + 1]) - ib) >> 4;
+                    float ownQ[DL];
+                    load_own_w<D, EX>(QS, n, p, ownQ);
+                    load_own_w<D, EX>(PR, n, p, ownP);
+                    sweep_w<D, XP, EX>(in_nbr + ib, i16, il, (int)n_pad, PR, p, ownQ, w2, b2, acc);
+                } else {
+                    load_own_w<D, EX>(PR, n, p, ownP);
+                }
+#ifndef GNN_ABLATE_W_SWEEP
                 sweep_w<D, XP, EX>(out_nbr + ob, i16, ol, (int)n_pad, QS, p, ownP, w2, b2, acc);
+#endif
 #pragma unroll
                 for (int i = 0; i < DL; ++i) acc[i] = tanh_f(acc[i]);
                 store_vec<DL>(tr + i16 * B::tr_stride + DL * p, acc);
@@ -1956,10 +1954,14 @@ __global__ __launch_bounds__(1024) void k_iter_w(
             if constexpr (EX) {
                 // exact fp32: the team splits the tiles of hl = tanh(W4 q + b4) and meets again in th
                 float *th = scratch + (8 + team) * 16 * B::tr_stride;
+#ifndef GNN_ABLATE_W_TAIL
                 if (on) mfma_hidden_x<F, D, LAST>(smem, tr, th, lane, mem);
+#endif
                 __syncthreads();
+#ifndef GNN_ABLATE_W_TAIL
                 if (on)
                     mfma_tail_scratch_x<F, D, LAST, XP>(smem, tr, th, lane, (int64_t)sl * SLICE, PRn, QSn, U, Pc, Qc, mem, 4);
+#endif
             } else if (on) {
                 mfma_tail_scratch<F, D, LAST, XP>(tb, tr, lane, (int64_t)sl * SLICE, PRn, QSn, U, Pc, Qc, mem, 4);
             }
