@@ -60,6 +60,9 @@ struct PlusI4 {
     __host__ __device__ I4 operator()(const I4 &x, const I4 &y) const { return {x.a + y.a, x.b + y.b, x.c + y.c, x.d + y.d}; }
 };
 
+// "the last key that is not -1" as a scan operator (associative, not commutative): pb_seg_keys
+struct CarryKey { __host__ __device__ int operator()(int a, int b) const { return b >= 0 ? b : a; } };
+
 // ---- workspace ------------------------------------------------------------------------------------
 struct Bounds { int64_t nt_max, np_max, ns_max, m_max, c_max; };
 inline Bounds bounds_of(int64_t n, int64_t E, int CH)
@@ -78,7 +81,7 @@ struct Ws {
     int64_t *hdr;
     int *chg;                                  // [kMaxLevelIters] "this sweep raised a level"
     // hits
-    int *deg_in, *deg_out, *gid, *lvA, *lvB, *down, *iota, *base, *oor, *tpos, *uflag, *uscan, *ustart, *inv;
+    int *deg_in, *deg_out, *gid, *lvA, *lvB, *down, *iota, *base, *oor, *tpos, *uflag, *uscan, *ustart, *inv, *hkey;
     unsigned long long *k64a, *k64b;
     // tiles
     int *tile_bounds, *tpad_off, *sbase, *t_desc;      // t_desc: [nt_max][8]
@@ -107,7 +110,7 @@ size_t rocprim_temp_bytes(int64_t n, int64_t E, const Bounds &b)
                                   rocprim::plus<int>(), (hipStream_t)0, false);
     up(t);
     (void)rocprim::inclusive_scan(nullptr, t, (const int *)nullptr, (int *)nullptr, (size_t)E + 1,
-                                  rocprim::maximum<int>(), (hipStream_t)0, false);
+                                  CarryKey(), (hipStream_t)0, false);
     up(t);
     (void)rocprim::exclusive_scan(nullptr, t, (const I2 *)nullptr, (I2 *)nullptr, I2{0, 0}, (size_t)b.np_max + 1, PlusI2(),
                                   (hipStream_t)0, false);
@@ -133,7 +136,7 @@ Ws carve(char *p, int64_t n, int64_t E, int CH)
     w.chg = ints(kMaxLevelIters + 2);
     w.deg_in = ints(n); w.deg_out = ints(n);                    // (one memset clears hdr .. lvB)
     w.lvA = ints(n); w.lvB = ints(n);
-    w.gid = ints(n); w.down = ints(n);
+    w.gid = ints(n); w.down = ints(n); w.hkey = ints(n);
     w.iota = ints(n); w.base = ints(n); w.oor = ints(n); w.tpos = ints(n); w.uflag = ints(n + 1); w.uscan = ints(n + 1);
     w.ustart = ints(n + 2); w.inv = ints(n + 1);
     w.k64a = reinterpret_cast<unsigned long long *>(take((size_t)n * 8));
@@ -167,6 +170,24 @@ __device__ __forceinline__ void hdr_add(int64_t *hdr, int slot, long long v)
 {
     atomicAdd(reinterpret_cast<unsigned long long *>(hdr + slot), (unsigned long long)v);
 }
+// One atomic per WORKGROUP on a header word, not one per wave or per thread: tens of thousands of
+// atomics on ONE address serialise at the memory side (pb_degrees' valid count and pb_fill_hits' three
+// feature maxima were most of those kernels' time at c3 x 256).  All threads of the workgroup call.
+template <typename OP>
+__device__ __forceinline__ int block_reduce_i(int v, int *red, OP op)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = op(v, __shfl_xor(v, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int r = red[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = op(r, red[w]);
+    return r;
+}
+struct OpAdd { __device__ int operator()(int a, int b) const { return a + b; } };
+struct OpMax { __device__ int operator()(int a, int b) const { return a > b ? a : b; } };
+struct OpOr { __device__ int operator()(int a, int b) const { return a | b; } };
 
 // ---- stage 1 kernels ------------------------------------------------------------------------------
 // In / out degree of every hit.  Two global atomics per segment (51 M at c3 x 256) were 2 ms of a
@@ -238,10 +259,10 @@ __global__ __launch_bounds__(1024) void pb_degrees(const int *__restrict__ src, 
             }
         __syncthreads();
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-    if ((threadIdx.x & 63) == 0 && cnt) hdr_add(hdr, H_NVALID, cnt);
-    if (__any(bad) && (threadIdx.x & 63) == 0) set_status(hdr, ST_ENDPOINT);
+    cnt = block_reduce_i(cnt, red, OpAdd());
+    bad = block_reduce_i(bad, red, OpOr());
+    if (threadIdx.x == 0 && cnt) hdr_add(hdr, H_NVALID, cnt);
+    if (threadIdx.x == 0 && bad) set_status(hdr, ST_ENDPOINT);
 }
 
 // gid[i] = number of interior graph boundaries hit_ptr[1..G-1] that are <= i   (plan.py: add.at + cumsum)
@@ -268,20 +289,46 @@ __global__ __launch_bounds__(TB) void pb_gid(const int64_t *__restrict__ hit_ptr
 // Levels are swept as BYTES (the iterate never exceeds kMaxLevelIters = 64): 2.5 MB for the 2.56 M hits of
 // c3 x 256, which every XCD's 4 MB L2 holds, where the int32 table's 10 MB lived in the MALL - the
 // sweep is one random level[src] read per segment and nothing else.  pb_widen hands int32 levels on.
+// BLOCK LIVENESS: the segments that raise a hit in sweep t are exactly those whose start hit has a
+// longest walk >= t - 1 - a set that only shrinks as t grows.  So a block of consecutive
+// segments that raised nothing in one sweep never raises anything again and is skipped from then on
+// (one byte per block of `blk` segments).  The reference emits segments grouped by layer pair (gnn/graph.py:80-93): the
+// block of layer pair (l, l + 1) dies after sweep l + 1, and the 12 sweeps of a 10-layer batch read
+// about half of what 12 full passes over src / dst read.  Any segment order stays exact.
+// (blocks of `blk` segments: 4096 for large batches, 1024 for small ones so that a single graph still
+// spreads over ~100 workgroups; eight segments per thread are in flight at a time)
 __global__ __launch_bounds__(TB) void pb_level_sweep(const int *__restrict__ src, const int *__restrict__ dst, int64_t E, int n,
-                                                     unsigned char *level, int *chg, int t)
+                                                     unsigned char *level, int *chg, int t, unsigned char *dead, int blk)
 {
     if (t > 1 && chg[t - 1] == 0) return;
-    int any = 0;
-    GS_LOOP(j, E) {
-        const int s = src[j], d = dst[j];
-        if (!seg_ok(s, d, n)) continue;
-        if ((int)level[s] >= t - 1) {
-            level[d] = (unsigned char)t;
-            any = 1;
+    const int64_t nb = (E + blk - 1) / blk;
+    int fired = 0;
+    for (int64_t b = blockIdx.x; b < nb; b += gridDim.x) {
+        if (dead && dead[b]) continue;                     // (workgroup-uniform)
+        const int64_t j0 = b * blk, j1 = j0 + blk < E ? j0 + blk : E;
+        int any = 0;
+        for (int64_t jb = j0 + threadIdx.x; jb < j1; jb += 8 * TB) {
+            int sv[8], dv[8], lv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t j = jb + (int64_t)u * TB;
+                sv[u] = j < j1 ? src[j] : -1;
+                dv[u] = j < j1 ? dst[j] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) lv[u] = seg_ok(sv[u], dv[u], n) ? (int)level[sv[u]] : -1;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (lv[u] >= t - 1) {                      // (t >= 1: never true for the -1 of an invalid segment)
+                    level[dv[u]] = (unsigned char)t;
+                    any = 1;
+                }
         }
+        any = __syncthreads_or(any);
+        if (!any && dead && threadIdx.x == 0) dead[b] = 1;
+        fired |= any;
     }
-    if (__any(any) && (threadIdx.x & 63) == 0 && chg[t] == 0) chg[t] = 1;
+    if (fired && threadIdx.x == 0 && chg[t] == 0) chg[t] = 1;
 }
 
 __global__ __launch_bounds__(TB) void pb_widen(const unsigned char *__restrict__ a, int *b, int64_t n)
@@ -329,8 +376,9 @@ __global__ __launch_bounds__(TB) void pb_down(const int *__restrict__ src, const
 // hits without incoming segments sit one level below their nearest end hit; sort key 1
 __global__ __launch_bounds__(TB) void pb_key1(int64_t n, const int *__restrict__ deg_in, const int *__restrict__ deg_out,
                                               const int *__restrict__ gid, int *level, const int *__restrict__ down,
-                                              unsigned long long *key, int *iota, int64_t *hdr)
+                                              unsigned long long *key, int *iota, int *hkey, int64_t *hdr)
 {
+    __shared__ int red[TB / 64];
     int bad = 0, lmax = 0;
     GS_LOOP(i, n) {
         const int di = deg_in[i], dout = deg_out[i];
@@ -345,9 +393,12 @@ __global__ __launch_bounds__(TB) void pb_key1(int64_t n, const int *__restrict__
         key[i] = ((unsigned long long)(unsigned)gid[i] << 39) | ((unsigned long long)(lv & 127) << 32) |
                  ((unsigned long long)(0xFFFF - (di & 0xFFFF)) << 16) | (unsigned long long)(0xFFFF - (dout & 0xFFFF));
         iota[i] = (int)i;
+        hkey[i] = gid[i] * 128 + (lv & 127);       // (graph, level) of a hit in one word: the chunk runs' key
     }
-    if (bad) set_status(hdr, ST_DEGREE);
-    hdr_max(hdr, H_MAXLEVEL, lmax);
+    bad = block_reduce_i(bad, red, OpOr());
+    lmax = block_reduce_i(lmax, red, OpMax());
+    if (threadIdx.x == 0 && bad) set_status(hdr, ST_DEGREE);
+    if (threadIdx.x == 0) hdr_max(hdr, H_MAXLEVEL, lmax);
 }
 
 __global__ __launch_bounds__(TB) void pb_unit_flags(int64_t n, const unsigned long long *__restrict__ key, int *flag)
@@ -375,11 +426,16 @@ __global__ __launch_bounds__(TB) void pb_compact(int64_t n, const int *__restric
 // threads compute that jump for the units of a chunk staged in LDS (binary search), one thread then
 // follows the chain - one LDS read per TILE instead of a dependent step per unit.  A tile still open
 // at the end of a chunk is carried over by its start position.
-constexpr int kCutChunk = 4096;
+// (The walk itself is sequential - a tile starts where the previous one ended.  jmp[i] holds the next
+// FOUR cut positions after a tile that starts at unit i, when all four steps are ordinary ones inside
+// the chunk: the loop-carried chain of the one walking thread is then one 16-byte LDS read per four
+// tiles instead of four dependent 4-byte reads per tile - 0.43 -> 0.1 ms for the 2816 units of c3 x 256.)
+constexpr int kCutChunk = 2048;
 __global__ __launch_bounds__(1024) void pb_cut_tiles(const int *__restrict__ ustart, int n, int T, int *tile_bounds,
                                                      int64_t *hdr, int nt_max)
 {
     __shared__ int st[kCutChunk + 1], nxt[kCutChunk];
+    __shared__ int4 jmp[kCutChunk];
     const int nu = (int)hdr[H_NUNITS];
     int nb = 0, last = 0;
     bool over = false;
@@ -406,6 +462,16 @@ __global__ __launch_bounds__(1024) void pb_cut_tiles(const int *__restrict__ ust
         __syncthreads();
         for (int i = threadIdx.x; i < cnt; i += blockDim.x) nxt[i] = first_over(i, cnt, st[i] + T);
         __syncthreads();
+        for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+            int4 q = make_int4(-1, -1, -1, -1);
+            auto step = [&](int u) { return (u >= 0 && u < cnt && st[u + 1] - st[u] <= T && nxt[u] < cnt) ? nxt[u] : -1; };
+            q.x = step(i);
+            q.y = step(q.x);
+            q.z = step(q.y);
+            q.w = step(q.z);
+            jmp[i] = q;
+        }
+        __syncthreads();
         if (threadIdx.x == 0) {
             int i = 0;
             if (anchor >= 0) {                     // the open tile ends inside this chunk, or goes on
@@ -414,6 +480,12 @@ __global__ __launch_bounds__(1024) void pb_cut_tiles(const int *__restrict__ ust
                 i = j;
             }
             while (i < cnt) {
+                const int4 q = jmp[i];
+                if (q.w >= 0) {                    // four ordinary steps at once
+                    push(st[q.x]); push(st[q.y]); push(st[q.z]); push(st[q.w]);
+                    i = q.w;
+                    continue;
+                }
                 const int s0 = st[i], sz = st[i + 1] - s0;
                 if (sz > T) {                      // split a big unit (a tile boundary stands at s0 already)
                     for (int a = s0 + T; a < s0 + sz; a += T) push(a);
@@ -564,6 +636,7 @@ __global__ __launch_bounds__(TB) void pb_tile_windows(const int *__restrict__ tp
     if (hdr[H_STATUS]) return;
     const int nt = (int)hdr[H_NTILES];
     __shared__ int red[4][TB / 64];
+    int m_rec = 0, m_in = 0, m_out = 0, n_lds = 0;      // (thread 0: this workgroup's tiles; one set of atomics at the end)
     for (int t = blockIdx.x; t < nt; t += gridDim.x) {
         const int h0 = tpad_off[t], h1 = tpad_off[t + 1];
         int ilo = 0x7FFFFFFF, ihi = -1, olo = 0x7FFFFFFF, ohi = -1;
@@ -597,33 +670,41 @@ __global__ __launch_bounds__(TB) void pb_tile_windows(const int *__restrict__ tp
             d[4] = ocnt > 0 ? olo : 0; d[5] = ocnt;
             d[6] = mode; d[7] = sbase[t];
             if (mode) {
-                hdr_max(hdr, H_LDSREC, icnt + ocnt + 2);
-                hdr_max(hdr, H_LDSIN, icnt);
-                hdr_max(hdr, H_LDSOUT, ocnt);
-                hdr_add(hdr, H_NLDSTILES, 1);
+                m_rec = icnt + ocnt + 2 > m_rec ? icnt + ocnt + 2 : m_rec;
+                m_in = icnt > m_in ? icnt : m_in;
+                m_out = ocnt > m_out ? ocnt : m_out;
+                ++n_lds;
             }
         }
+    }
+    if (threadIdx.x == 0 && n_lds) {
+        hdr_max(hdr, H_LDSREC, m_rec);
+        hdr_max(hdr, H_LDSIN, m_in);
+        hdr_max(hdr, H_LDSOUT, m_out);
+        hdr_add(hdr, H_NLDSTILES, n_lds);
     }
 }
 
 // ---- edge chunks (plan._chunk_bounds) ---------------------------------------------------------------
-__global__ __launch_bounds__(TB) void pb_valid_idx(const int *__restrict__ src, int64_t E, int *idx)
+// run starts of the (graph, start level) key; padded segments join the run before them: k[j] = key of
+// the last valid segment at or before j (-1 when there is none).  The key of a hit is ONE word (hkey,
+// written by pb_key1): one random 4-byte read per segment here, then a carry-forward scan ("the right
+// operand unless it is -1"; keys are >= 0) and a compare of neighbours - where four gathers per
+// segment (src[idx[j]], src[idx[j-1]], gid[], level[]) cost 0.46 ms at c3 x 256.
+__global__ __launch_bounds__(TB) void pb_seg_keys(const int *__restrict__ src, int64_t E, int n, const int *__restrict__ hkey,
+                                                  int *key)
 {
-    GS_LOOP(j, E) idx[j] = src[j] >= 0 ? (int)j : 0;
+    GS_LOOP(j, E) {
+        const int s = src[j];
+        key[j] = (unsigned)s < (unsigned)n ? hkey[s] : -1;              // (>= n: ST_ENDPOINT is set)
+    }
 }
 
-// run starts of the (graph, start level) key; padded segments join the run before them: k[j] = key of
-// the last valid segment at or before j (or of segment 0 when there is none)
-__global__ __launch_bounds__(TB) void pb_run_flags(const int *__restrict__ src, int64_t E, int n, const int *__restrict__ idx,
-                                                   const int *__restrict__ gid, const int *__restrict__ level, int *flag)
+__global__ __launch_bounds__(TB) void pb_run_flags(int64_t E, const int *__restrict__ k, int *flag)
 {
-    auto key_at = [&](int j) {
-        const int s = src[j];
-        return (unsigned)s < (unsigned)n ? (long long)gid[s] * 128 + level[s] : -1ll;   // (>= n: ST_ENDPOINT is set)
-    };
     GS_LOOP(j, E + 1) {
         int f = 0;
-        if (j < E) f = (j == 0) ? 1 : (key_at(idx[j]) != key_at(idx[j - 1]) ? 1 : 0);
+        if (j < E) f = (j == 0) ? 1 : (k[j] != k[j - 1] ? 1 : 0);
         flag[j] = f;
     }
 }
@@ -713,6 +794,7 @@ __global__ __launch_bounds__(TB) void pb_chunk_windows(const int *__restrict__ c
     if (hdr[H_STATUS]) return;
     const int nc = (int)hdr[H_NCHUNKS];
     __shared__ int red[4][TB / 64];
+    int m_rows = 0, n_lds = 0;                          // (thread 0: this workgroup's chunks)
     for (int c = blockIdx.x; c < nc; c += gridDim.x) {
         const int e0 = cb[c], e1 = cb[c + 1];
         int slo = 0x7FFFFFFF, shi = -1, dlo = 0x7FFFFFFF, dhi = -1;
@@ -748,10 +830,14 @@ __global__ __launch_bounds__(TB) void pb_chunk_windows(const int *__restrict__ c
             d[4] = dcnt > 0 ? dlo : 0; d[5] = dcnt;
             d[6] = mode; d[7] = 0;
             if (mode) {
-                hdr_max(hdr, H_EDGEROWS, scnt + dcnt + 2);
-                hdr_add(hdr, H_NLDSCHUNKS, 1);
+                m_rows = scnt + dcnt + 2 > m_rows ? scnt + dcnt + 2 : m_rows;
+                ++n_lds;
             }
         }
+    }
+    if (threadIdx.x == 0 && n_lds) {
+        hdr_max(hdr, H_EDGEROWS, m_rows);
+        hdr_add(hdr, H_NLDSCHUNKS, n_lds);
     }
 }
 
@@ -795,12 +881,13 @@ __global__ __launch_bounds__(TB) void pb_fill_hits(int64_t n, int F, const float
                 mx[k] = fmaxf(mx[k], fabsf(v));
             }
     }
+    __shared__ int red[TB / 64];
 #pragma unroll
     for (int k = 0; k < F_MAX; ++k) {
         if (k >= F) break;
-        float v = mx[k];
-        for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-        if ((threadIdx.x & 63) == 0 && v > 0.0f) atomicMax(&absmax[k], __float_as_uint(v));   // >= 0: bit order = value order
+        // >= 0: bit order = value order; one atomic per workgroup and feature
+        const int v = block_reduce_i((int)__float_as_uint(mx[k]), red, OpMax());
+        if (threadIdx.x == 0 && v > 0) atomicMax(&absmax[k], (unsigned)v);
     }
 }
 
@@ -1020,8 +1107,14 @@ int gnn_plan_build_sizes(const int32_t *src, const int32_t *dst, const int64_t *
         // round costs ~15 us, the 52 launches it usually saves cost 0.3 ms
     {
         unsigned char *lv8 = reinterpret_cast<unsigned char *>(w.lvB);   // (zeroed with the header)
+        // the blocks' "dead" bytes live in the zeroed rest of lvB (4 n bytes, n of them levels)
+        const int blk = E >= (4ll << 20) ? 4096 : 1024;
+        const int64_t nblk = (E + blk - 1) / blk;
+        const int64_t dead_off = (n + 255) / 256 * 256;
+        unsigned char *dead = dead_off + nblk <= 4 * n ? lv8 + dead_off : nullptr;
+        const unsigned sg = (unsigned)(nblk < 1 ? 1 : nblk > 8192 ? 8192 : nblk);
         for (int t = 1; t <= kMaxLevelIters; ++t) {
-            GNN_LAUNCH("pb_level_sweep", pb_level_sweep, gs(E), TB, s, src, dst, E, (int)n, lv8, w.chg, t);
+            GNN_LAUNCH("pb_level_sweep", pb_level_sweep, sg, TB, s, src, dst, E, (int)n, lv8, w.chg, t, dead, blk);
             if (t % kSweepRound == 0 && t < kMaxLevelIters) {
                 int raised = 1;
                 HIP_OK(hipMemcpyAsync(&raised, w.chg + t, sizeof(int), hipMemcpyDeviceToHost, s), "sweep flag read-back");
@@ -1033,7 +1126,7 @@ int gnn_plan_build_sizes(const int32_t *src, const int32_t *dst, const int64_t *
     }
     GNN_LAUNCH("pb_fill_i32", pb_fill_i32, gs(n), TB, s, w.down, n, 0x7FFFFFFF);
     GNN_LAUNCH("pb_down", pb_down, gs(E), TB, s, src, dst, E, (int)n, level, w.deg_in, w.down);
-    GNN_LAUNCH("pb_key1", pb_key1, gs(n), TB, s, n, w.deg_in, w.deg_out, w.gid, level, w.down, w.k64a, w.iota, w.hdr);
+    GNN_LAUNCH("pb_key1", pb_key1, gs(n), TB, s, n, w.deg_in, w.deg_out, w.gid, level, w.down, w.k64a, w.iota, w.hkey, w.hdr);
     size_t tb = w.temp_bytes;
     HIP_OK(rocprim::radix_sort_pairs(w.temp, tb, (const unsigned long long *)w.k64a, w.k64b, (const int *)w.iota, w.base,
                                      (size_t)n, 0u, 39u + bit_width((uint64_t)G), s, false), "hit sort 1");
@@ -1069,11 +1162,10 @@ int gnn_plan_build_sizes(const int32_t *src, const int32_t *dst, const int64_t *
     GNN_LAUNCH("pb_tile_windows", pb_tile_windows, 2048, TB, s, w.tpad_off, w.sbase, w.degn, w.ptr, w.sv_in, w.sv_out,
                (int)iter_records, w.t_desc, w.hdr);
     // edge chunks
-    GNN_LAUNCH("pb_valid_idx", pb_valid_idx, gs(E), TB, s, src, E, w.kscr);
+    GNN_LAUNCH("pb_seg_keys", pb_seg_keys, gs(E), TB, s, src, E, (int)n, w.hkey, w.kscr);
     tb = w.temp_bytes;
-    HIP_OK(rocprim::inclusive_scan(w.temp, tb, (const int *)w.kscr, w.rb, (size_t)E, rocprim::maximum<int>(), s, false),
-           "valid-index scan");
-    GNN_LAUNCH("pb_run_flags", pb_run_flags, gs(E + 1), TB, s, src, E, (int)n, w.rb, w.gid, level, w.mscan);
+    HIP_OK(rocprim::inclusive_scan(w.temp, tb, (const int *)w.kscr, w.rb, (size_t)E, CarryKey(), s, false), "key carry scan");
+    GNN_LAUNCH("pb_run_flags", pb_run_flags, gs(E + 1), TB, s, E, w.rb, w.mscan);
     tb = w.temp_bytes;
     HIP_OK(rocprim::exclusive_scan(w.temp, tb, (const int *)w.mscan, w.c_scan, 0, (size_t)E + 1, rocprim::plus<int>(), s, false),
            "run scan");
@@ -1119,7 +1211,7 @@ int gnn_plan_build_fill(const float *X, int32_t F, const int32_t *src, const int
     HIP_OK(hipMemsetAsync(out->out_nbr + sz->out_total, 0, 4 * SLICE * sizeof(int), s), "memset tail");
     HIP_OK(hipMemsetAsync(out->in_nbr16 + sz->in16_words, 0, 64 * sizeof(int), s), "memset tail");
     HIP_OK(hipMemsetAsync(out->out_nbr16 + sz->out16_words, 0, 64 * sizeof(int), s), "memset tail");
-    GNN_LAUNCH("pb_fill_hits", (pb_fill_hits<16>), gs(n), TB, s, n, (int)F, X, w.oor, w.inv, out->X, out->perm,
+    GNN_LAUNCH("pb_fill_hits", (pb_fill_hits<16>), gs(n) < 1024u ? gs(n) : 1024u, TB, s, n, (int)F, X, w.oor, w.inv, out->X, out->perm,
                reinterpret_cast<unsigned *>(out->x_absmax));
     GNN_LAUNCH("pb_fill_offsets", pb_fill_offsets, gs(ns + 1), TB, s, ns, w.off4, out->in_off, out->out_off, out->in_off16,
                out->out_off16);
