@@ -264,3 +264,29 @@ def test_calls_refuse_tensors_of_another_device():
             _lib._dev(torch.zeros(3), torch.float32, "x")
     finally:
         _lib._cur_dev = None
+
+
+def test_event_route_decision_is_pinned():
+    """`_lib.events_preferred` (which batches take the one-workgroup-per-graph kernels) on both sides of
+    each threshold: <= 1200 segments per graph (tools/cliff_probe.py: 256 x (150, 1000) one-launch 0.050
+    ms vs tiled 0.066; 256 x (300, 2000) 0.119 vs 0.069), hidden_dim <= 16 (one D = 32 toy graph 0.123 vs
+    0.089), the graph must fit the kernel's LDS.  The GPU twin of this test
+    (test_gpu_formats.py::test_event_route_crossover) checks the kernels that ran and their times."""
+    from gnn_fpga_amd import _lib
+    from gnn_fpga_amd.hitgraph import _EventLayout
+
+    def lay(h, s):
+        x = _EventLayout()
+        x.max_hits, x.max_segments = h, s
+        return x
+
+    assert _lib.EVENTS_MAX_SEGMENTS == 1200
+    assert _lib.events_preferred(3, 8, lay(150, 1000))
+    assert _lib.events_preferred(3, 8, lay(150, 1200))
+    assert not _lib.events_preferred(3, 8, lay(150, 1201))
+    assert not _lib.events_preferred(3, 8, lay(300, 2000))
+    assert _lib.events_preferred(11, 8, lay(40, 150))                 # the reference's muon graphs
+    assert _lib.events_preferred(3, 16, lay(100, 250))
+    assert not _lib.events_preferred(2, 32, lay(40, 144))             # wide hidden layers: tiled
+    assert not _lib.events_preferred(3, 8, None)                      # not block-diagonal
+    assert not _lib.events_preferred(3, 8, lay(40000, 1000))          # does not fit the LDS of one workgroup

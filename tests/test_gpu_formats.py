@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import gnn_fpga_amd
-from gnn_fpga_amd import HitGraphBatch
+from gnn_fpga_amd import HitGraphBatch, synth
 from golden_util import REF_WRITTEN
 from test_batcher_host import _fx, _sparse_graphs
 
@@ -107,3 +107,59 @@ def test_dense_inputs_are_converted_on_the_device(hip):
         assert int(b.src[Emax].item()) == -1 and int(b.dst[Emax].item()) == -1
     finally:
         HitGraphBatch.validate_dense = True
+
+
+def test_event_route_crossover(hip):
+    """Which kernels `SegmentClassifier.forward` launches on either side of the event-route thresholds
+    (`_lib.events_preferred`, `n_graphs <= 1024` in model.py), and that the route taken is not the slow
+    one: on each shape both routes are timed (HIP-graph replays) and the chosen one may be at most
+    1.3x the other's time - the cliff measured past the thresholds was 1.7x (tools/cliff_probe.py), so
+    a kernel change that moves the crossover fails here instead of silently costing 1.7x."""
+    import time
+    from gnn_fpga_amd.model import SegmentClassifier
+    torch.manual_seed(0)
+
+    def route_and_times(graphs, F, D):
+        m = SegmentClassifier(input_dim=F, hidden_dim=D, n_iters=3).cuda().eval()
+        b = HitGraphBatch.from_graphs(graphs).cuda()
+        with torch.no_grad():
+            m(b)
+            with hip.profile(64) as prof:
+                m(b)
+        names = {k for k, _ in prof.records}
+        times = {}
+        for ev in (True, False):
+            m.use_events = ev
+            with torch.no_grad():
+                for _ in range(3):
+                    m(b)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    m(b)
+                for _ in range(5):
+                    g.replay()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(50):
+                    g.replay()
+                torch.cuda.synchronize()
+                times[ev] = (time.perf_counter() - t0) / 50
+        return names, times
+
+    # below the segment threshold: one launch, one workgroup per graph
+    names, t = route_and_times([synth.layered_graph(150, 1000, 3, seed=s) for s in range(256)], 3, 8)
+    assert names == {"k_event"}
+    assert t[True] <= 1.3 * t[False], t
+    # above it: the tiled pipeline
+    names, t = route_and_times([synth.layered_graph(300, 2000, 3, seed=s) for s in range(256)], 3, 8)
+    assert "k_event" not in names and ("k_iter2" in names or "k_iter" in names)
+    # (forcing use_events = True changes nothing above the threshold: both timings are the tiled route)
+    # more than 1024 small graphs: the tiled pipeline's throughput wins
+    names, _ = route_and_times([synth.muon_graph(s) for s in range(1100)], 11, 8)
+    assert "k_event" not in names
+    names, t = route_and_times([synth.muon_graph(s) for s in range(512)], 11, 8)
+    assert names == {"k_event"}
+    assert t[True] <= 1.3 * t[False], t
+    # wide hidden layers never take it
+    names, _ = route_and_times([synth.bipartite_graph([4] * 10, 2, seed=1)], 2, 32)
+    assert "k_event" not in names

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import BATCHES, SINGLE, Fixture
+from golden_util import assert_grad_close, BATCHES, SINGLE, Fixture
 from gnn_fpga_amd import HitGraphBatch, synth
 from oracle import index_c
 
@@ -185,8 +185,7 @@ def test_submodules_are_differentiable_like_the_reference(hip, F, D):
     ((e_g * we.cuda()).sum() + (Hn_g * wh.cuda()).sum()).backward()
 
     def close(a, r, what):
-        err = np.abs(a - r).max()
-        assert err < 1e-6 + 1e-4 * np.abs(r).max(), (what, err)
+        assert_grad_close(a, r, "submodule " + what)
 
     close(Hg.grad.cpu().numpy(), Hc.grad.numpy(), "dL/dH")
     for k, p_ in m.named_parameters():
@@ -264,8 +263,7 @@ def test_training_step_matches_reference(hip, name):
     assert abs(loss.item() - fx.loss) < 1e-6
     for k, p in m.named_parameters():
         ref = fx.grads[k]
-        err = np.abs(p.grad.cpu().numpy() - ref).max()
-        assert err < 1e-6 + 1e-4 * np.abs(ref).max(), (k, err)
+        assert_grad_close(p.grad, ref, "reference training step " + k)
 
 
 def test_masked_training_gradients(hip):
@@ -296,9 +294,72 @@ def test_masked_training_gradients(hip):
     for k, p in m.named_parameters():
         g = p.grad.cpu().numpy()
         r = params[k].grad.numpy()
-        assert np.abs(g - r).max() < 1e-6 + 1e-4 * np.abs(r).max(), k
+        assert_grad_close(g, r, "masked " + k)
         if k in fx.masks:
             assert np.all(g[fx.masks[k] == 0] == 0)
+
+
+def test_reference_training_step_with_l1_and_masks(hip):
+    """The reference's training step WITH its L1 branch (gnn/estimator.py:49-60, `l1 > 0`): the loss
+    adds l1 * sum |W| over `layer.weight` of every layer of node_network.network and
+    edge_network.network that has one (:54-56; the raw weights, not W * mask), then loss.backward() and
+    optimizer.step().  Run statement for statement on the drop-in with masks set, against autograd
+    through the dense oracle with the same statements on CPU: loss, all ten gradients (the L1 term's
+    sign(W) included, zero where the mask zeroed W), and the weights after one SGD step."""
+    from gnn_fpga_amd.model import SegmentClassifier
+    from oracle import dense_torch
+    fx = Fixture("sector_masked_s2")
+    l1, lr = 1e-3, 0.05
+    me = [torch.from_numpy(fx.masks["edge_network.network.0.weight"]),
+          torch.from_numpy(fx.masks["edge_network.network.2.weight"])]
+    mn = [torch.from_numpy(fx.masks["node_network.network.0.weight"]),
+          torch.from_numpy(fx.masks["node_network.network.2.weight"])]
+    model = SegmentClassifier(input_dim=fx.F, hidden_dim=fx.D, n_iters=fx.n_iters, masks_e=me, masks_n=mn)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in fx.params.items()})
+    model.cuda().train()
+    for layer in (model.edge_network.network[0], model.edge_network.network[2],
+                  model.node_network.network[0], model.node_network.network[2]):
+        layer.set_mask(layer.mask)              # (as the constructor did before load_state_dict: zero W where masked)
+    start = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    optimizer = torch.optim.SGD(model.parameters(), lr=lr)
+    loss_func = torch.nn.BCELoss()
+    batch = HitGraphBatch.from_graphs([fx.graph]).cuda()
+    targets = (torch.arange(batch.n_segments) % 4 == 0).float()
+
+    def l1_penalty(arr):                        # gnn/estimator.py:46-47
+        return torch.abs(arr).sum()
+
+    # --- gnn/estimator.py:49-60, on the drop-in
+    model.zero_grad()
+    optimizer.zero_grad()
+    outputs = model(batch)
+    node_weights = [layer.weight for layer in model.node_network.network if hasattr(layer, 'weight')]
+    edge_weights = [layer.weight for layer in model.edge_network.network if hasattr(layer, 'weight')]
+    assert len(node_weights) == 2 and len(edge_weights) == 2
+    l1_regularization = l1 * sum([l1_penalty(arr) for arr in node_weights]) + l1 * sum([l1_penalty(arr) for arr in edge_weights])
+    loss = loss_func(outputs, targets.cuda()) + l1_regularization
+    loss.backward()
+    grads = {k: p.grad.detach().cpu().numpy().copy() for k, p in model.named_parameters()}
+    optimizer.step()
+
+    # --- the same statements through the dense oracle (CPU autograd)
+    params = {k: v.clone().requires_grad_(True) for k, v in start.items()}
+    masks = {k: torch.from_numpy(v) for k, v in fx.masks.items()}
+    Xd, Ri, Ro = (torch.from_numpy(a)[None] for a in synth.to_dense(fx.graph))
+    ref_out = dense_torch.segment_classifier(Xd, Ri, Ro, params, fx.n_iters, masks)[0]
+    ref_l1 = (l1 * sum(l1_penalty(params[k]) for k in ("node_network.network.0.weight", "node_network.network.2.weight")) +
+              l1 * sum(l1_penalty(params[k]) for k in ("edge_network.network.0.weight", "edge_network.network.2.weight")))
+    ref = loss_func(ref_out, targets) + ref_l1
+    ref.backward()
+    assert float(ref_l1) > 1e-3                  # the branch is live
+    assert abs(loss.item() - ref.item()) < 2e-6
+    for k, p in model.named_parameters():
+        r = params[k].grad.numpy()
+        assert_grad_close(grads[k], r, "l1 step " + k)
+        if k in fx.masks:
+            assert np.all(grads[k][fx.masks[k] == 0] == 0)           # |w|' = 0 at the zeroed weights, W * mask elsewhere
+        stepped = start[k].numpy() - lr * r
+        assert np.abs(p.detach().cpu().numpy() - stepped).max() < 1e-6 + 2e-6 * np.abs(stepped).max(), k
 
 
 def test_exp_product_bound_and_fallback(hip):
@@ -571,7 +632,7 @@ def test_wide_hidden_dims_train_and_submodules(hip, F, D, T):
     assert abs(loss.item() - ref.item()) < 1e-6
     for k, p in m.named_parameters():
         gk, r = p.grad.cpu().numpy(), params[k].grad.numpy()
-        assert np.abs(gk - r).max() < 1e-6 + 1e-4 * np.abs(r).max(), k
+        assert_grad_close(gk, r, "dense oracle " + k)
 
 
 @pytest.mark.parametrize("reduction", ["mean", "sum"])
@@ -623,7 +684,7 @@ def test_training_step_with_fused_loss_matches_reference(hip):
     assert abs(loss.item() - fx.loss) < 1e-6
     for k, p in m.named_parameters():
         g, r = p.grad.cpu().numpy(), fx.grads[k]
-        assert np.abs(g - r).max() < 1e-6 + 1e-4 * np.abs(r).max(), k
+        assert_grad_close(g, r, "fixture " + k)
 
 
 @pytest.mark.parametrize("F,D", [(3, 8), (11, 8), (2, 32)])
@@ -663,7 +724,7 @@ def test_training_gradients_are_additive_over_graphs(hip, F, D):
         off += b.n_segments
     assert np.abs(e_all - np.concatenate(e_parts)).max() < 1e-6
     for (k, _), a, r in zip(m.named_parameters(), g_all, g_sum):
-        assert np.abs(a - r).max() < 1e-6 + 1e-4 * np.abs(r).max(), k
+        assert_grad_close(a, r, "additivity " + k)
 
 
 @pytest.mark.parametrize("kind", ["detector graphs (per-pass kernels)", "muon events (one-launch kernels)"])
@@ -751,7 +812,7 @@ def test_direct_training_step_equals_the_autograd_step(hip, kind):
 def test_training_on_the_level_ordered_twin(hip, D):
     """Detector-size batches train on their level-ordered twin (hits renumbered in plan order: the
     gathers of the training kernels become L2-local): same loss and gradients as in the caller's
-    order (1e-4 of the largest entry: the sums run in another order), bit-reproducible.  D = 32: the
+    order (golden_util.GRAD_REL of the largest entry: the sums run in another order), bit-reproducible.  D = 32: the
     16-lanes-per-hit kernels of the wide shapes on the twin."""
     from gnn_fpga_amd.loss import BCELoss
     from gnn_fpga_amd.model import SegmentClassifier
@@ -793,8 +854,7 @@ def test_training_on_the_level_ordered_twin(hip, D):
     assert abs(float(l0) - float(l1)) < 1e-6
     for (k, _), a, c, d in zip(m.named_parameters(), g0, g1, g2):
         assert torch.equal(c, d), k
-        err = (a - c).abs().max().item()
-        assert err < 1e-7 + 1e-4 * a.abs().max().item(), (k, err)
+        assert_grad_close(c, a, "level-ordered twin " + k)
 
 
 @pytest.mark.parametrize("F,D,T", [(3, 8, 3), (11, 16, 2), (3, 4, 2), (11, 8, 1)])
@@ -1032,7 +1092,7 @@ def test_one_launch_backward_for_small_events(hip, F, D, T):
         _lib.segclf_backward_events = real
     assert len(calls) == 1                      # the one-launch path ran for use_events = True only
     for (k, _), a, r in zip(m.named_parameters(), out[True], out[False]):
-        assert np.abs(a - r).max() < 1e-7 + 1e-4 * np.abs(r).max(), k
+        assert_grad_close(a, r, "one-launch vs per-pass " + k)
     big = HitGraphBatch.from_graphs([synth.layered_graph(20000, 100000, 3, seed=1)])
     lb = big.event_layout()
     assert not _lib.events_backward_supported(3, 8, lb.max_hits, lb.max_segments)
