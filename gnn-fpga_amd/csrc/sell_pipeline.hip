@@ -284,12 +284,15 @@ struct Cfg {
     static constexpr int lds_bytes = 160 * 1024;
     static constexpr int table_bytes = TL<F, D>::total * 4;
     // k_iter window: records of 2D floats ([P|R] or [Q|S]); k_edge window: rows of D floats
-    static constexpr int it_rec = (D <= 16) ? (lds_bytes - table_bytes - 2048) / (8 * D) : 0;
+    // hidden_dim 16 with F <= 4 runs the 16-lanes-per-hit kernel (k_iter_w, exact fp32 matrix-core hit
+    // update), which gathers by ABSOLUTE hit id: no LDS windows (window-relative lists) for it either
+    static constexpr bool wide16 = (D == 16 && F <= 4);
+    static constexpr int it_rec = (D <= 16 && !wide16) ? (lds_bytes - table_bytes - 2048) / (8 * D) : 0;
     static constexpr int ed_rec = (D <= 16) ? (lds_bytes - 2048) / (4 * D) : 0;
     // D <= 16: > one 1000-hit detector level incl. fluctuations (LDS windows).  Wide shapes have no
     // LDS windows; 256-hit tiles = one slice per wave of k_iter_w's 16, and many workgroups per CU
     // for the fp32 k_iter (4 waves each)
-    static constexpr int tile_hits = (D <= 16) ? 1280 : 256;
+    static constexpr int tile_hits = (D <= 16 && !wide16) ? 1280 : 256;
     static constexpr int chunk_segments = 16384;   // > one level pair of a 100k-segment graph
     // Cross-slice prefetch keeps ~25 asm-loaded registers in flight while a slice is processed.
     // That is only legal if the register allocator never spills: a spill of an in-flight
@@ -790,7 +793,7 @@ __device__ __forceinline__ void mfma_records(const bf16x8_t *Tm, const float *bm
 // rows in k_iter_w's position order ([P(DL) R(DL)] per lane of a hit's 16).
 template <int F, int D>
 struct BX {                      // fp32 fragment layout, in floats
-    static_assert(D % 32 == 0 && F <= 4, "exact matrix-core path: D = 32 or 64, X in one k-step");
+    static_assert(D % 16 == 0 && F <= 4, "exact matrix-core path: D = 16, 32 or 64, X in one k-step");
     static constexpr int NT1 = D / 16, KS1 = D / 4;             // W4: tiles, k-steps
     static constexpr int KS2 = D / 4 + 1;                       // records: hn steps + the X step
     static constexpr int NT2N = 5 * D / 16, NT2L = 2 * D / 16;
@@ -884,6 +887,10 @@ __device__ __forceinline__ void mfma_records_x(const float *Tm, const float *bm,
             constexpr bool HV = row_halves<D, true>();
             expo = HV ? (o % (2 * D)) < D : (o % (2 * DL)) < DL;
             expo_half = !HV && DL == 2;
+            if constexpr (DL == 1) {                               // D = 16: [P R P R] inside one store
+                if (XP) { c.x = __builtin_amdgcn_exp2f(c.x); c.z = __builtin_amdgcn_exp2f(c.z); }
+                expo = false;
+            }
         }
         if (XP && expo) {
             c.x = __builtin_amdgcn_exp2f(c.x); c.y = __builtin_amdgcn_exp2f(c.y);
@@ -1666,6 +1673,12 @@ template <> struct PieceW<4> {
     __device__ __forceinline__ void first(float *f) const { f[0] = bf_lo(w.x); f[1] = bf_hi(w.x); f[2] = bf_lo(w.y); f[3] = bf_hi(w.y); }
     __device__ __forceinline__ void second(float *f) const { f[0] = bf_lo(w.z); f[1] = bf_hi(w.z); f[2] = bf_lo(w.w); f[3] = bf_hi(w.w); }
 };
+template <> struct PieceW<1> {         // (no bf16 rows at D = 16: only named by conditional types)
+    unsigned w;
+    __device__ __forceinline__ void load(const void *a) { w = *reinterpret_cast<const unsigned *>(a); }
+    __device__ __forceinline__ void first(float *f) const { f[0] = bf_lo(w); }
+    __device__ __forceinline__ void second(float *f) const { f[0] = bf_hi(w); }
+};
 template <> struct PieceW<2> {
     uint2 w;
     __device__ __forceinline__ void load(const void *a) { w = *reinterpret_cast<const uint2 *>(a); }
@@ -1683,6 +1696,12 @@ template <> struct PieceX<4> {         // D = 64, rows [P(64) | R(64)] (row_halv
     }
     __device__ __forceinline__ void first(float *f) const { f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; }
     __device__ __forceinline__ void second(float *f) const { f[0] = b.x; f[1] = b.y; f[2] = b.z; f[3] = b.w; }
+};
+template <> struct PieceX<1> {         // D = 16: [P R] per lane, one 8-byte load
+    float2 a;
+    __device__ __forceinline__ void load(const void *p) { a = *reinterpret_cast<const float2 *>(p); }
+    __device__ __forceinline__ void first(float *f) const { f[0] = a.x; }
+    __device__ __forceinline__ void second(float *f) const { f[0] = a.y; }
 };
 template <> struct PieceX<2> {
     float4 a;
@@ -1716,28 +1735,33 @@ __device__ __forceinline__ void score_w(const RecW<D, EX> &g, const float *own, 
                                         float *acc)
 {
     constexpr int DL = D / 16;
-    static_assert(DL % 2 == 0, "dimension pairs");
+    static_assert(DL == 1 || DL % 2 == 0, "one dimension per lane, or dimension pairs");
     const f2_t one2 = {1.0f, 1.0f};
     float part[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         float P[DL];
         g.r[j].first(P);
-        f2_t s2 = {0.0f, 0.0f};
+        if constexpr (DL == 1) {
+            const float a = XP ? fmaf(P[0], own[0], 1.0f) : __builtin_amdgcn_exp2f(P[0] + own[0]) + 1.0f;
+            part[j] = w2[0] * __builtin_amdgcn_rcpf(a);
+        } else {
+            f2_t s2 = {0.0f, 0.0f};
 #pragma unroll
-        for (int i = 0; i < DL; i += 2) {
-            const f2_t pj = {P[i], P[i + 1]}, o2 = {own[i], own[i + 1]};
-            f2_t a;
-            if constexpr (XP) {
-                a = pj * o2 + one2;
-            } else {
-                const f2_t z = pj + o2;
-                a = f2_t{__builtin_amdgcn_exp2f(z.x), __builtin_amdgcn_exp2f(z.y)} + one2;
+            for (int i = 0; i + 1 < DL; i += 2) {
+                const f2_t pj = {P[i], P[i + 1]}, o2 = {own[i], own[i + 1]};
+                f2_t a;
+                if constexpr (XP) {
+                    a = pj * o2 + one2;
+                } else {
+                    const f2_t z = pj + o2;
+                    a = f2_t{__builtin_amdgcn_exp2f(z.x), __builtin_amdgcn_exp2f(z.y)} + one2;
+                }
+                const f2_t r = {__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)};
+                s2 = f2_t{w2[i], w2[i + 1]} * r + s2;
             }
-            const f2_t r = {__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)};
-            s2 = f2_t{w2[i], w2[i + 1]} * r + s2;
+            part[j] = s2.x + s2.y;
         }
-        part[j] = s2.x + s2.y;
     }
     // 4x4 transpose-add inside the quad (as score4), then the other three quads of this hit
     const int q = p & 3;
@@ -1755,12 +1779,16 @@ __device__ __forceinline__ void score_w(const RecW<D, EX> &g, const float *own, 
     for (int j = 0; j < 4; ++j) {
         float R[DL];
         g.r[j].second(R);
-        const f2_t e2 = {e4[j], e4[j]};
+        if constexpr (DL == 1) {
+            acc[0] = fmaf(R[0], e4[j], acc[0]);
+        } else {
+            const f2_t e2 = {e4[j], e4[j]};
 #pragma unroll
-        for (int i = 0; i < DL; i += 2) {
-            const f2_t a2 = f2_t{R[i], R[i + 1]} * e2 + f2_t{acc[i], acc[i + 1]};
-            acc[i] = a2.x;
-            acc[i + 1] = a2.y;
+            for (int i = 0; i + 1 < DL; i += 2) {
+                const f2_t a2 = f2_t{R[i], R[i + 1]} * e2 + f2_t{acc[i], acc[i + 1]};
+                acc[i] = a2.x;
+                acc[i + 1] = a2.y;
+            }
         }
     }
 }
@@ -1812,8 +1840,10 @@ __device__ __forceinline__ void load_own_w(const unsigned *__restrict__ REC, int
     }
 }
 
+// (hidden_dim 16: registers and LDS allow TWO workgroups per CU - 8 waves per SIMD - and the sweeps
+// there are bound by the latency of their dependent loads: 0.147 -> see DESIGN ms per launch at c3 x 32)
 template <int F, int D, bool LAST, bool XP, bool EX = false>
-__global__ __launch_bounds__(1024) void k_iter_w(
+__global__ __launch_bounds__(1024, (D == 16 ? 8 : 4)) void k_iter_w(
     const float *__restrict__ X, const float *__restrict__ table, const unsigned *__restrict__ t16,
     const int32_t *__restrict__ tiles, const int32_t *__restrict__ in_off, const int32_t *__restrict__ in_nbr,
     const int32_t *__restrict__ out_off, const int32_t *__restrict__ out_nbr, const unsigned *__restrict__ PR,
@@ -1822,7 +1852,7 @@ __global__ __launch_bounds__(1024) void k_iter_w(
 {
     using L = TL<F, D>;
     using B = std::conditional_t<EX, BX<F, D>, BL<F, D>>;      // EX: exact fp32 fragments and fp32 record rows
-    static_assert(D % 32 == 0, "16 lanes x 4 dims per hit, matrix-core tail");
+    static_assert(D % 16 == 0, "16 lanes x D / 16 dims per hit, matrix-core tail");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // (no static LDS: the opt-in for > 64 KB of dynamic LDS is for the whole 160 KB)
     int *grp = reinterpret_cast<int *>(smem + B::template lds_words<LAST>() + (EX ? 12 : 8) * 16 * B::tr_stride);
@@ -1898,9 +1928,10 @@ __global__ __launch_bounds__(1024) void k_iter_w(
         const int q0 = (((local - rot) % per_xcd) + per_xcd) % per_xcd;
         rot = (rot + nq) % per_xcd;
         const int x0 = sg0;
-        // (bf16 rows: both tables of a level fit the L2 together and the split only costs - 2.27 -> 2.44 ms
-        // at c5 x 8 - so there a hit's two sweeps stay back to back in phase B)
-        constexpr bool SPLIT = EX;
+        // (bf16 rows, and fp32 rows narrower than 512 bytes: both tables of a level fit the L2 together and
+        // the split only costs - bf16 2.27 -> 2.44 ms at c5 x 8 - so there a hit's two sweeps stay back to
+        // back in phase B)
+        constexpr bool SPLIT = EX && D >= 64;
         // ---- phase A: segments ENDING at the hit: P[start] with the hit's own Q, adds e R[start]
         for (int q = q0; SPLIT && x0 + 4 * q < sg1; q += per_xcd) {
             const int sl = x0 + 4 * q + team;
@@ -2787,10 +2818,11 @@ constexpr int t16_words()      // fragment tables of the wide kernels: bf16 (BL)
 {
     if constexpr (D % 32 == 0 && F <= 4) return BL<F, D>::total > BX<F, D>::total ? BL<F, D>::total : BX<F, D>::total;
     else if constexpr (D % 32 == 0 && F <= 8) return BL<F, D>::total;
+    else if constexpr (D % 16 == 0 && F <= 4) return BX<F, D>::total;      // D = 16: exact fp32 fragments only
     else return 0;
 }
 template <int F, int D>
-constexpr bool can_exact_wide() { return D % 32 == 0 && F <= 4; }
+constexpr bool can_exact_wide() { return D % 16 == 0 && F <= 4; }
 
 // k_iter_w's group bound: records of one table an XCD's 4 MB L2 can keep while a group's hits stream
 // through it (3 MB of rows; GNN_WIDE_WINDOW_KB overrides, 0 = every tile a group of its own,
@@ -2810,7 +2842,7 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
     using G = Cfg<F, D>;
     const int64_t Np = pl->n_pad, E = pl->n_segments;
     Ws w = carve(ws, Np, L::total, D, t16_words<F, D>());
-    constexpr bool can_bf = t16_words<F, D>() > 0;
+    constexpr bool can_bf = D % 32 == 0 && F <= 8;
     // (k_iter_w addresses record rows and list steps with 32-bit byte offsets)
     const bool bf = can_bf && (p->flags & GNN_FLAG_BF16_MLP) && n_iters > 0 &&
                     (uint64_t)(Np + 2) * D * 4 < (1ull << 32);
@@ -2818,15 +2850,19 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
         if (bf && Np > 0)
             GNN_LAUNCH("k_pack16", (k_pack16<F, D>), 64, 256, s, *p, w.t16, w.PRa, w.PRb, w.QSa, w.QSb, Np,
                        XP ? 1 : 0);
-    if (Np == 0 || G::pack_first)   // no hits (nothing for k_input4 to do), or a big table
+    // hidden_dim 16 (F <= 4) takes the 16-lanes-per-hit kernel too - one dim per lane, the hit update (1776
+    // multiply-adds per hit on the vector pipe before, with its weights read from LDS) on the fp32
+    // matrix-core instruction - where its two 128 KB record windows per 1000-hit level never fitted
+    // the LDS of k_iter; GNN_NO_WIDE_EXACT=1 keeps the general kernel
+    constexpr bool can_ex = can_exact_wide<F, D>();
+    const bool ex = can_ex && !bf && n_iters > 0 && Np > 0 && (uint64_t)(Np + 2) * D * 8 < (1ull << 32) &&
+                    !getenv("GNN_NO_WIDE_EXACT");
+    if (Np == 0 || G::pack_first || ex)   // no hits (nothing for k_input4 to do), a big table, or k_input4_x reads it
         GNN_LAUNCH("k_pack", (k_pack<F, D, XP>), (L::total + 255) / 256, 256, s, *p, w.table, w.PRa, w.PRb,
                    w.QSa, w.QSb, w.U, w.Pc, w.Qc, Np);
     // wide hidden layers in exact fp32 (the default): 16 lanes per hit over fp32 record rows, hit
     // update on v_mfma_f32_16x16x4_f32 (BX).  k_pack32 runs after k_pack: its NULL rows use k_iter_w's
     // row order and replace the general kernels'.
-    constexpr bool can_ex = can_exact_wide<F, D>() && G::pack_first;
-    const bool ex = can_ex && !bf && n_iters > 0 && Np > 0 && (uint64_t)(Np + 2) * D * 8 < (1ull << 32) &&
-                    !getenv("GNN_NO_WIDE_EXACT");
     if constexpr (can_ex)
         if (ex)
             GNN_LAUNCH("k_pack32", (k_pack32<F, D>), 64, 256, s, *p, reinterpret_cast<float *>(w.t16), w.PRa, w.PRb,
@@ -2976,7 +3012,7 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
                         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter_w<F, D, true, XP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
                         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter_w<F, D, false, XP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
                     }
-                    const int ncu = device_cus();
+                    const int ncu = device_cus() * (D == 16 ? 2 : 1);      // D = 16: two workgroups per CU
                     const unsigned wgs = (unsigned)(((nt < ncu ? nt : ncu) + 7) / 8 * 8);
                     const size_t trw = (size_t)(2 * 4 + 4) * 16 * B::tr_stride + 4;   // double-buffered q scratch + hl scratch + the group word
                     const int wmax = wide_window_records(8 * D);

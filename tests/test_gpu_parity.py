@@ -978,9 +978,9 @@ def test_wide_backward_on_sixteen_lanes_per_hit(hip, F, D, T, monkeypatch):
         assert (a - c).abs().max().item() <= 1e-9 + 1e-5 * c.abs().max().item()
 
 
-@pytest.mark.parametrize("F,D,T", [(3, 64, 3), (2, 32, 4), (3, 32, 2)])
+@pytest.mark.parametrize("F,D,T", [(3, 64, 3), (2, 32, 4), (3, 32, 2), (3, 16, 3), (2, 16, 2)])
 def test_exact_wide_path_and_its_fallback(hip, F, D, T, monkeypatch):
-    """hidden_dim 32 / 64 in fp32: the 16-lanes-per-hit kernel with the hit update on
+    """hidden_dim 16 (F <= 4) / 32 / 64 in fp32: the 16-lanes-per-hit kernel with the hit update on
     v_mfma_f32_16x16x4_f32 (a chain of fp32 fmas: nothing is rounded) is the default; the general
     4-lanes-per-hit kernel stays as the fallback for tables beyond 32-bit record offsets
     (GNN_NO_WIDE_EXACT forces it).  Both within the fp32 tolerance of the C oracle, both

@@ -17,3 +17,8 @@ for F, D, T in ((3, 4, 3), (3, 8, 3), (3, 16, 3), (11, 8, 3), (11, 16, 3), (3, 3
         for _ in range(20): m(b)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
     print("F=%2d D=%2d T=%d  c3 x %d: %.3f ms  %.3g segments/s" % (F, D, T, G, dt * 1e3, b.n_segments / dt))
+    if os.environ.get("SHAPE_PROBE_KERNELS"):            # per-launch medians (bench.event_medians)
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        with torch.no_grad():
+            print("      " + "  ".join("%s %.3f" % kv for kv in bench.event_medians(lambda: m(b), 10)))
