@@ -2001,6 +2001,217 @@ __global__ __launch_bounds__(1024, (D == 16 ? 8 : 4)) void k_iter_w(
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_iter_wx: the exact-fp32 wide iteration (D = 32 / 64) with SWEEP waves and MATRIX-CORE waves
+// ---------------------------------------------------------------------------------------------
+// What the ablation of k_iter_w<EX> said (c5 x 8, ms per launch): sweeps alone 0.34, hit update alone
+// 0.24, both 0.56 - the sum: every round of a workgroup is sweep -> barrier -> W4 product -> barrier ->
+// record products for all 16 waves together, so the matrix pipe idles during the sweeps and the
+// memory system during the products.  Measured and dropped on the way here (same workload, ms per
+// middle launch, the barrier kernel at 0.574): the record tiles deferred into the NEXT sweep of the
+// same wave (0.60: in-order issue - a dependent chain of v_mfma_f32_16x16x4_f32 holds its wave for 40
+// cycles per instruction, and the four waves of a SIMD reach their chunks together); one-team
+// workgroups that drift apart, fragments read from the L2 as A operands (0.67: every MFMA waits for a
+// global load); write-through record stores (0.57); all 16 waves sweeping with the update of a slice
+// run by one wave of its team in turn (0.576: the updating wave holds its team's next slot back); a
+// third record group in flight per sweep wave (no change at D = 32, 180 bytes of scratch at D = 64).
+//
+// Here the 16 waves of the workgroup (one per CU, fragments in LDS as before) take ROLES: waves 0-11
+// are three sweep teams, waves 12-15 - one per SIMD - do nothing but hit updates (0.527).  A team's
+// four waves sweep four hits each of a slice, write q = tanh(acc) and X into a slot of a 12-slot ring
+// in LDS and publish it (one LDS add per wave); a matrix-core wave takes every fourth slot in sequence,
+// reads the 16 hits' rows into registers, hands the slot back, and runs the whole update of the slice
+// alone (64 + 340 MFMAs at D = 64; the hidden layer goes from the accumulators straight into the next
+// product's B operands: no second LDS exchange).  No workgroup barrier after the table staging: a sweep
+// team never waits for a product, a matrix-core wave never for a sweep it does not need.
+//   prod[s]  += 1 by each of the 4 waves that filled slot s   -> full at 4 (generation + 1)
+//   cons[s]  += 1 by the matrix-core wave once its rows are in registers -> the slot's next generation
+//   fin      += 1 by each sweep wave when it has published its last slice
+// Every wait is on a counter that only grows and only depends on work with a smaller sequence number,
+// and a matrix-core wave that finds fin == 12 BEFORE it finds its slot not yet full knows that no
+// further slot comes (fin is read first).  Slots are dealt in sequence i = 3 round + team; a team with
+// no slice left in a round publishes an empty slot, so the sequence has no holes.  Waits are bounded
+// (2^24 polls: a wave gives up instead of hanging - a bug, not a state the protocol reaches).
+template <int F, int D, bool LAST, bool XP>
+__global__ __launch_bounds__(1024, 4) void k_iter_wx(
+    const float *__restrict__ X, const float *__restrict__ table, const unsigned *__restrict__ t16,
+    const int32_t *__restrict__ tiles, const int32_t *__restrict__ in_off, const int32_t *__restrict__ in_nbr,
+    const int32_t *__restrict__ out_off, const int32_t *__restrict__ out_nbr, const unsigned *__restrict__ PR,
+    const unsigned *__restrict__ QS, float *__restrict__ U, float *__restrict__ PRn, float *__restrict__ QSn,
+    float *__restrict__ Pc, float *__restrict__ Qc, int64_t n_pad, int tiles_per_xcd, int n_tiles, int wmax)
+{
+    using L = TL<F, D>;
+    using B = BX<F, D>;
+    constexpr bool EX = true;
+    constexpr int DL = D / 16, NSLOT = 12, NSW = 12, NMX = 4, NTEAM = NSW / 4;   // slots, sweep waves, matrix-core waves
+    constexpr int n1 = B::NT1 * B::KS1 * 64, nm = B::template tm_words<LAST>();
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *ring = smem + B::template lds_words<LAST>();
+    int *sync = reinterpret_cast<int *>(ring + NSLOT * 16 * B::tr_stride);   // prod[12] cons[12] meta[12] fin
+    int *prod = sync, *cons = sync + NSLOT, *meta = sync + 2 * NSLOT, *fin = sync + 3 * NSLOT;
+    {
+        unsigned *tb = reinterpret_cast<unsigned *>(smem);
+        for (int i = threadIdx.x; i < n1; i += 1024) tb[i] = t16[B::o_t4 + i];
+        for (int i = threadIdx.x; i < nm; i += 1024) tb[n1 + i] = t16[(LAST ? B::o_tml : B::o_tmn) + i];
+        for (int i = threadIdx.x; i < D; i += 1024) tb[n1 + nm + i] = t16[B::o_b4 + i];
+        for (int i = threadIdx.x; i < (LAST ? 2 : 5) * D; i += 1024)
+            tb[n1 + nm + D + i] = t16[(LAST ? B::o_bml : B::o_bmn) + i];
+        if (threadIdx.x < 3 * NSLOT + 1) sync[threadIdx.x] = 0;
+    }
+    __syncthreads();                                   // the only workgroup barrier
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    auto ld = [](const int *w) { return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto bump = [](int *w) { (void)__hip_atomic_fetch_add(w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    constexpr int kSpinLimit = 1 << 24;
+
+    if (wv >= NSW) {
+        // ---------------- matrix-core wave: slots c, c + 4, c + 8, ... -------------------------------
+        const float *T4 = smem, *Tm = smem + n1, *b4 = smem + n1 + nm, *bm = b4 + D;
+        const int hit = lane & 15, g = lane >> 4;
+        for (int i = wv - NSW;; i += NMX) {
+            const int slot = i % NSLOT, need = 4 * (i / NSLOT + 1);
+            bool got = false;
+            for (int spins = 0; spins < kSpinLimit; ++spins) {
+                const int f = ld(fin);                 // BEFORE prod: see the protocol above
+                if (ld(prod + slot) >= need) { got = true; break; }
+                if (f >= NSW) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (!got) break;
+            const int sl = __builtin_amdgcn_readfirstlane(ld(meta + slot));
+            const float *tr = ring + slot * 16 * B::tr_stride;
+            float v[B::NT1][4];
+            float xb = 0.0f;
+            if (sl >= 0) {
+#pragma unroll
+                for (int t = 0; t < B::NT1; ++t) {
+                    const f4v r = *reinterpret_cast<const f4v *>(tr + hit * B::tr_stride + 16 * t + 4 * g);
+                    v[t][0] = r.x; v[t][1] = r.y; v[t][2] = r.z; v[t][3] = r.w;
+                }
+                xb = g < F ? tr[hit * B::tr_stride + D + (g < F ? g : 0)] : 0.0f;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the rows are in registers
+            if (lane == 0) bump(cons + slot);
+            if (sl < 0) continue;
+            // hl = tanh(W4 q + b4): accumulator r of tile T is exactly B operand (k-step 4 T + r) of the
+            // record products (BX::kidx)
+            float h[B::NT1][4];
+#pragma unroll
+            for (int T = 0; T < B::NT1; ++T) {
+                f4v c = *reinterpret_cast<const f4v *>(b4 + 16 * T + 4 * g);
+#pragma unroll
+                for (int st = 0; st < B::KS1; ++st)
+                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(T4[(T * B::KS1 + st) * 64 + lane], v[st / 4][st % 4], c, 0, 0, 0);
+                h[T][0] = tanh_f(c.x); h[T][1] = tanh_f(c.y); h[T][2] = tanh_f(c.z); h[T][3] = tanh_f(c.w);
+            }
+            mfma_records_x<F, D, LAST, XP>(Tm, bm, h, xb, lane, (int64_t)sl * SLICE, PRn, QSn, U, Pc, Qc, 0, 1);
+        }
+        return;
+    }
+
+    // ---------------- sweep wave ---------------------------------------------------------------------
+    const int hs = lane >> 4, p = lane & 15;
+    const int team = wv >> 2, mem = wv & 3;
+    float w2[DL];
+#pragma unroll
+    for (int i = 0; i < DL; ++i) w2[i] = table[(p >> 2) * L::stride + L::o_w2 + DL * (p & 3) + i];
+    const float b2 = table[L::o_b2];
+    // tiles, groups and the deal of slices: as in k_iter_w, with THREE slices per round (one per team);
+    // every sweep wave works the group bounds out for itself (no barrier to hand them over)
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int t_begin = xcd * tiles_per_xcd;
+    const int t_end = t_begin + tiles_per_xcd < n_tiles ? t_begin + tiles_per_xcd : n_tiles;
+    constexpr bool SPLIT = D >= 64;
+    int rot = 0, seq = team;                           // seq: this team's next slot sequence number
+    for (int t = t_begin; t < t_end;) {
+        int sg0, sg1;
+        {
+            const int tt = t + lane;
+            const bool in = tt < t_end;
+            const int32_t *d = tiles + (int64_t)(in ? tt : t) * DESC;
+            const int s1 = d[1];
+            int ilo = in && d[3] > 0 ? d[2] : 0x7FFFFFFF, ihi = in && d[3] > 0 ? d[2] + d[3] : -1;
+            int olo = in && d[5] > 0 ? d[4] : 0x7FFFFFFF, ohi = in && d[5] > 0 ? d[4] + d[5] : -1;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int a = __shfl_up(ilo, o, 64), b = __shfl_up(ihi, o, 64);
+                const int c = __shfl_up(olo, o, 64), e = __shfl_up(ohi, o, 64);
+                if (lane >= o) {
+                    ilo = a < ilo ? a : ilo; ihi = b > ihi ? b : ihi;
+                    olo = c < olo ? c : olo; ohi = e > ohi ? e : ohi;
+                }
+            }
+            const bool ok = in && (lane == 0 || ((int64_t)ihi - ilo <= wmax && (int64_t)ohi - olo <= wmax));
+            const unsigned long long m = ~__ballot(ok);
+            const int cnt = m ? __builtin_ctzll(m) : 64;
+            sg1 = __builtin_amdgcn_readfirstlane(__shfl(s1, cnt - 1, 64));
+            sg0 = __builtin_amdgcn_readfirstlane(__shfl(d[0], 0, 64));
+            t += cnt;
+        }
+        const int nq = (sg1 - sg0 + NTEAM - 1) / NTEAM;            // "quads" of three slices here
+        const int q0 = (((local - rot) % per_xcd) + per_xcd) % per_xcd;
+        rot = (rot + nq) % per_xcd;
+        // ---- phase A (D = 64): all in-sweeps of the group, partial sums parked in U
+        for (int q = q0; SPLIT && sg0 + NTEAM * q < sg1; q += per_xcd) {
+            const int sl = sg0 + NTEAM * q + team;
+            if (sl >= sg1) continue;
+            const int ib = __builtin_amdgcn_readfirstlane(in_off[sl]);
+            const int il = (__builtin_amdgcn_readfirstlane(in_off[sl + 1]) - ib) >> 4;
+            if (il <= 0) continue;
+            const int i16 = 4 * mem + hs;
+            const int64_t n = (int64_t)sl * SLICE + i16;
+            float acc[DL], ownQ[DL];
+            load_vec<DL>(U + n * D + DL * p, acc);
+            load_own_w<D, EX>(QS, n, p, ownQ);
+            sweep_w<D, XP, EX>(in_nbr + ib, i16, il, (int)n_pad, PR, p, ownQ, w2, b2, acc);
+            store_vec<DL>(U + n * D + DL * p, acc);
+        }
+        // ---- phase B: out-sweeps (and the in-sweeps when the group is not split), then publish
+        for (int q = q0; sg0 + NTEAM * q < sg1; q += per_xcd, seq += NTEAM) {
+            const int sl = sg0 + NTEAM * q + team;
+            const bool on = sl < sg1;
+            float acc[DL];
+            if (on) {
+                const int ob = __builtin_amdgcn_readfirstlane(out_off[sl]);
+                const int ol = (__builtin_amdgcn_readfirstlane(out_off[sl + 1]) - ob) >> 4;
+                const int i16 = 4 * mem + hs;
+                const int64_t n = (int64_t)sl * SLICE + i16;
+                float ownP[DL];
+                load_vec<DL>(U + n * D + DL * p, acc);
+                if constexpr (!SPLIT) {
+                    const int ib = __builtin_amdgcn_readfirstlane(in_off[sl]);
+                    const int il = (__builtin_amdgcn_readfirstlane(in_off[sl + 1]) - ib) >> 4;
+                    float ownQ[DL];
+                    load_own_w<D, EX>(QS, n, p, ownQ);
+                    load_own_w<D, EX>(PR, n, p, ownP);
+                    sweep_w<D, XP, EX>(in_nbr + ib, i16, il, (int)n_pad, PR, p, ownQ, w2, b2, acc);
+                } else {
+                    load_own_w<D, EX>(PR, n, p, ownP);
+                }
+                sweep_w<D, XP, EX>(out_nbr + ob, i16, ol, (int)n_pad, QS, p, ownP, w2, b2, acc);
+#pragma unroll
+                for (int i = 0; i < DL; ++i) acc[i] = tanh_f(acc[i]);
+            }
+            // the slot of sequence number seq: free once its previous generation has been taken
+            const int slot = seq % NSLOT, gen = seq / NSLOT;
+            for (int spins = 0; spins < kSpinLimit && ld(cons + slot) < gen; ++spins) __builtin_amdgcn_s_sleep(2);
+            float *tr = ring + slot * 16 * B::tr_stride;
+            if (on) {
+                const int i16 = 4 * mem + hs;
+                const int64_t n = (int64_t)sl * SLICE + i16;
+                store_vec<DL>(tr + i16 * B::tr_stride + DL * p, acc);
+                if (p < F) tr[i16 * B::tr_stride + D + p] = X[n * F + p];
+            }
+            if (mem == 0 && lane == 0) __hip_atomic_store(meta + slot, on ? sl : -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's rows have landed in the slot
+            if (lane == 0) bump(prod + slot);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) bump(fin);
+}
+
+// ---------------------------------------------------------------------------------------------
 // exact-fp32 matrix-core products of k_iter2 (D = 8): v_mfma_f32_16x16x4_f32 is a k-ordered fmaf
 // chain, so moving the per-hit MLPs there changes no tolerance - and frees the vector pipe.
 // ---------------------------------------------------------------------------------------------
@@ -3014,6 +3225,33 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
                     }
                     const int ncu = device_cus() * (D == 16 ? 2 : 1);      // D = 16: two workgroups per CU
                     const unsigned wgs = (unsigned)(((nt < ncu ? nt : ncu) + 7) / 8 * 8);
+                    if constexpr (D >= 32) {       // sweep waves + matrix-core waves (k_iter_wx)
+                        static const bool lockstep = getenv("GNN_WIDE_LOCKSTEP") != nullptr;
+                        if (!lockstep) {
+                            static DevOnce wx_attr;
+                            if (wx_attr.need()) {
+                                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter_wx<F, D, true, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
+                                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter_wx<F, D, false, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
+                            }
+                            const size_t ringw = (size_t)12 * 16 * B::tr_stride + 40;      // 12 slots + the counters
+                            const unsigned *PRx = reinterpret_cast<const unsigned *>(PR), *QSx = reinterpret_cast<const unsigned *>(QS);
+                            const int wmx = wide_window_records(8 * D);
+                            if (t + 1 == n_iters)
+                                GNN_LAUNCH_SH("k_iter_w", (k_iter_wx<F, D, true, XP>), wgs, 1024,
+                                              (B::template lds_words<true>() + ringw) * 4, s, pl->X, w.table, w.t16, pl->tiles,
+                                              pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PRx, QSx, w.U, PRn, QSn,
+                                              w.Pc, w.Qc, Np, tpx, nt, wmx);
+                            else
+                                GNN_LAUNCH_SH("k_iter_w", (k_iter_wx<F, D, false, XP>), wgs, 1024,
+                                              (B::template lds_words<false>() + ringw) * 4, s, pl->X, w.table, w.t16, pl->tiles,
+                                              pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PRx, QSx, w.U, PRn, QSn,
+                                              w.Pc, w.Qc, Np, tpx, nt, wmx);
+                            launched = true;
+                            float *t1 = PR; PR = PRn; PRn = t1;
+                            float *t2 = QS; QS = QSn; QSn = t2;
+                            continue;
+                        }
+                    }
                     const size_t trw = (size_t)(2 * 4 + 4) * 16 * B::tr_stride + 4;   // double-buffered q scratch + hl scratch + the group word
                     const int wmax = wide_window_records(8 * D);
                     const unsigned *PRh = reinterpret_cast<const unsigned *>(PR), *QSh = reinterpret_cast<const unsigned *>(QS);
