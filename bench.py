@@ -71,10 +71,10 @@ def algorithmic(n, e, F, D, T, w=4):
     f_in = 2 * n * F * D
     it_b, it_f = b_edge + b_node, f_edge + f_agg + f_node
     return {"bytes": {"k_input": b_in, "k_input4": b_in, "k_edge": b_edge, "k_node": b_node, "k_iter": it_b,
-                      "k_iter_w": it_b, "k_iter2": it_b, "k_pack": 0, "k_pack16": 0,
+                      "k_iter_w": it_b, "k_iter_wx": it_b, "k_iter2": it_b, "k_pack": 0, "k_pack16": 0,
                       "forward": b_in + (T + 1) * b_edge + T * b_node},
             "flops": {"k_input": f_in, "k_input4": f_in, "k_edge": f_edge, "k_node": f_agg + f_node,
-                      "k_iter": it_f, "k_iter_w": it_f, "k_iter2": it_f, "k_pack": 0, "k_pack16": 0,
+                      "k_iter": it_f, "k_iter_w": it_f, "k_iter_wx": it_f, "k_iter2": it_f, "k_pack": 0, "k_pack16": 0,
                       "forward": f_in + (T + 1) * f_edge + T * (f_agg + f_node)}}
 
 
@@ -211,7 +211,7 @@ def c5_record(dev, steps, pmc_path, G=8):
                     sub["counters_source"] = sec.get("source")
             rec[tag] = sub
     rec["bound"] = "hbm"
-    rec["note"] = ("k_iter_w: one launch per iteration; hbm_frac = SURVEY 8(d) B_edge + B_node of the "
+    rec["note"] = ("k_iter_wx (fp32) / k_iter_w (bf16): one launch per iteration; hbm_frac = SURVEY 8(d) B_edge + B_node of the "
                    "launch / its median time / 8 TB/s; traffic = FETCH_SIZE x 2 + WRITE_SIZE of a committed "
                    "rocprofv3 --pmc pass; valu_busy = SQ_ACTIVE_INST_VALU x 4 / SQ_BUSY_CU_CYCLES there")
     return rec

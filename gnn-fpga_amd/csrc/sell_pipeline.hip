@@ -1884,8 +1884,8 @@ __global__ __launch_bounds__(1024, (D == 16 ? 8 : 4)) void k_iter_w(
     // in-sweeps of its slices of a group (only the [P|R] window is gathered from), parks the partial
     // sums in U, then all out-sweeps + hit updates (only the [Q|S] window): the two 2.5 MB tables of a
     // 5000-hit level at D = 64 are never live together in the 4 MB L2 (they were: 54 % hit rate,
-    // 2.6 GB of traffic per launch for 0.41 GB of records, profiles/r02_c5_final_f32; 1.8 GB now,
-    // profiles/r03_c5_f32).  The deal of slice quads over the XCD's workgroups continues round-robin
+    // 2.6 GB of traffic per launch for 0.41 GB of records, profiles/r02_c5_final_f32; 1.8 GB with the
+    // split, 1.6 GB in k_iter_wx, profiles/r03_c5_f32).  The deal of slice quads over the XCD's workgroups continues round-robin
     // across group boundaries (every workgroup the same number +- 1 over the launch; no workgroup waits
     // for another: the order is for locality only).
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
@@ -2048,7 +2048,7 @@ __global__ __launch_bounds__(1024, 4) void k_iter_wx(
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *ring = smem + B::template lds_words<LAST>();
     int *sync = reinterpret_cast<int *>(ring + NSLOT * 16 * B::tr_stride);   // prod[12] cons[12] meta[12] fin
-    int *prod = sync, *cons = sync + NSLOT, *meta = sync + 2 * NSLOT, *fin = sync + 3 * NSLOT;
+    int *prod = sync, *cons = sync + NSLOT, *meta = sync + 2 * NSLOT, *fin = sync + 3 * NSLOT, *pha = fin + 1;
     {
         unsigned *tb = reinterpret_cast<unsigned *>(smem);
         for (int i = threadIdx.x; i < n1; i += 1024) tb[i] = t16[B::o_t4 + i];
@@ -2056,7 +2056,7 @@ __global__ __launch_bounds__(1024, 4) void k_iter_wx(
         for (int i = threadIdx.x; i < D; i += 1024) tb[n1 + nm + i] = t16[B::o_b4 + i];
         for (int i = threadIdx.x; i < (LAST ? 2 : 5) * D; i += 1024)
             tb[n1 + nm + D + i] = t16[(LAST ? B::o_bml : B::o_bmn) + i];
-        if (threadIdx.x < 3 * NSLOT + 1) sync[threadIdx.x] = 0;
+        if (threadIdx.x < 3 * NSLOT + 2) sync[threadIdx.x] = 0;
     }
     __syncthreads();                                   // the only workgroup barrier
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2122,7 +2122,7 @@ __global__ __launch_bounds__(1024, 4) void k_iter_wx(
     const int t_begin = xcd * tiles_per_xcd;
     const int t_end = t_begin + tiles_per_xcd < n_tiles ? t_begin + tiles_per_xcd : n_tiles;
     constexpr bool SPLIT = D >= 64;
-    int rot = 0, seq = team;                           // seq: this team's next slot sequence number
+    int rot = 0, seq = team, ngrp = 0;                 // seq: this team's next slot sequence number
     for (int t = t_begin; t < t_end;) {
         int sg0, sg1;
         {
@@ -2166,6 +2166,14 @@ __global__ __launch_bounds__(1024, 4) void k_iter_wx(
             sweep_w<D, XP, EX>(in_nbr + ib, i16, il, (int)n_pad, PR, p, ownQ, w2, b2, acc);
             store_vec<DL>(U + n * D + DL * p, acc);
         }
+        if constexpr (SPLIT) {
+            // the sweep waves of the workgroup change phase TOGETHER (an LDS counter, the matrix-core
+            // waves are not involved): teams that ran ahead into the other table while their mates still
+            // gathered from this one undid the split's effect (L2 hit rate 52 % instead of 67 %)
+            ++ngrp;
+            if (lane == 0) bump(pha);
+            for (int spins = 0; spins < kSpinLimit && ld(pha) < NSW * ngrp; ++spins) __builtin_amdgcn_s_sleep(2);
+        }
         // ---- phase B: out-sweeps (and the in-sweeps when the group is not split), then publish
         for (int q = q0; sg0 + NTEAM * q < sg1; q += per_xcd, seq += NTEAM) {
             const int sl = sg0 + NTEAM * q + team;
@@ -2206,6 +2214,7 @@ __global__ __launch_bounds__(1024, 4) void k_iter_wx(
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's rows have landed in the slot
             if (lane == 0) bump(prod + slot);
         }
+        // (a second meeting point here, before the next group's phase A: 6 % less traffic, 2 % more time)
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) bump(fin);
@@ -3233,16 +3242,16 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
                                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter_wx<F, D, true, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
                                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter_wx<F, D, false, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
                             }
-                            const size_t ringw = (size_t)12 * 16 * B::tr_stride + 40;      // 12 slots + the counters
+                            const size_t ringw = (size_t)12 * 16 * B::tr_stride + 40;      // 12 slots + the counters (38 words)
                             const unsigned *PRx = reinterpret_cast<const unsigned *>(PR), *QSx = reinterpret_cast<const unsigned *>(QS);
                             const int wmx = wide_window_records(8 * D);
                             if (t + 1 == n_iters)
-                                GNN_LAUNCH_SH("k_iter_w", (k_iter_wx<F, D, true, XP>), wgs, 1024,
+                                GNN_LAUNCH_SH("k_iter_wx", (k_iter_wx<F, D, true, XP>), wgs, 1024,
                                               (B::template lds_words<true>() + ringw) * 4, s, pl->X, w.table, w.t16, pl->tiles,
                                               pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PRx, QSx, w.U, PRn, QSn,
                                               w.Pc, w.Qc, Np, tpx, nt, wmx);
                             else
-                                GNN_LAUNCH_SH("k_iter_w", (k_iter_wx<F, D, false, XP>), wgs, 1024,
+                                GNN_LAUNCH_SH("k_iter_wx", (k_iter_wx<F, D, false, XP>), wgs, 1024,
                                               (B::template lds_words<false>() + ringw) * 4, s, pl->X, w.table, w.t16, pl->tiles,
                                               pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PRx, QSx, w.U, PRn, QSn,
                                               w.Pc, w.Qc, Np, tpx, nt, wmx);

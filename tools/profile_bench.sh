@@ -7,8 +7,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-train --no-pruned $*"
-TRACE_ARGS="--steps 30 --warmup 5 --no-cpu-baseline --no-train --no-pruned $*"   # long enough that the clock ramp of the first steps does not dominate the averages
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-train --no-pruned --no-c5 $*"
+TRACE_ARGS="--steps 30 --warmup 5 --no-cpu-baseline --no-train --no-pruned --no-c5 $*"   # long enough that the clock ramp of the first steps does not dominate the averages
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" $TRACE_ARGS > "$OUT/trace.log" 2>&1 || { echo trace failed; tail -5 "$OUT/trace.log"; exit 1; }
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INST_CYCLES_VMEM" "GRBM_GUI_ACTIVE"; do
   name=$(echo $pass | tr ' ' '_')
