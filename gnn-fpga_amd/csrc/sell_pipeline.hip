@@ -2031,7 +2031,10 @@ __global__ __launch_bounds__(1024, (D == 16 ? 8 : 4)) void k_iter_w(
 // further slot comes (fin is read first).  Slots are dealt in sequence i = 3 round + team; a team with
 // no slice left in a round publishes an empty slot, so the sequence has no holes.  Waits are bounded
 // (2^24 polls: a wave gives up instead of hanging - a bug, not a state the protocol reaches).
-template <int F, int D, bool LAST, bool XP>
+// EX = false: the same roles on bf16 records and bf16 fragments (GNN_FLAG_BF16_MLP): there the update is
+// cheap on the matrix cores but sat, with its 16 tanh per lane and its stores, behind the round barrier
+// of every wave (k_iter_w without its sweeps still took 0.25 of its 0.345 ms per launch at c5 x 8).
+template <int F, int D, bool LAST, bool XP, bool EX = true>
 __global__ __launch_bounds__(1024, 4) void k_iter_wx(
     const float *__restrict__ X, const float *__restrict__ table, const unsigned *__restrict__ t16,
     const int32_t *__restrict__ tiles, const int32_t *__restrict__ in_off, const int32_t *__restrict__ in_nbr,
@@ -2040,10 +2043,9 @@ __global__ __launch_bounds__(1024, 4) void k_iter_wx(
     float *__restrict__ Pc, float *__restrict__ Qc, int64_t n_pad, int tiles_per_xcd, int n_tiles, int wmax)
 {
     using L = TL<F, D>;
-    using B = BX<F, D>;
-    constexpr bool EX = true;
+    using B = std::conditional_t<EX, BX<F, D>, BL<F, D>>;
     constexpr int DL = D / 16, NSLOT = 12, NSW = 12, NMX = 4, NTEAM = NSW / 4;   // slots, sweep waves, matrix-core waves
-    constexpr int n1 = B::NT1 * B::KS1 * 64, nm = B::template tm_words<LAST>();
+    constexpr int n1 = B::NT1 * B::KS1 * (EX ? 64 : 256), nm = B::template tm_words<LAST>();
     typedef float f4v __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *ring = smem + B::template lds_words<LAST>();
@@ -2068,6 +2070,7 @@ __global__ __launch_bounds__(1024, 4) void k_iter_wx(
         // ---------------- matrix-core wave: slots c, c + 4, c + 8, ... -------------------------------
         const float *T4 = smem, *Tm = smem + n1, *b4 = smem + n1 + nm, *bm = b4 + D;
         const int hit = lane & 15, g = lane >> 4;
+        (void)T4; (void)Tm; (void)b4; (void)bm; (void)hit; (void)g;
         for (int i = wv - NSW;; i += NMX) {
             const int slot = i % NSLOT, need = 4 * (i / NSLOT + 1);
             bool got = false;
@@ -2080,6 +2083,14 @@ __global__ __launch_bounds__(1024, 4) void k_iter_wx(
             if (!got) break;
             const int sl = __builtin_amdgcn_readfirstlane(ld(meta + slot));
             const float *tr = ring + slot * 16 * B::tr_stride;
+            if constexpr (!EX) {                       // bf16: the whole tail from the slot, then hand it back
+                if (sl >= 0)
+                    mfma_tail_scratch<F, D, LAST, XP>(reinterpret_cast<const unsigned *>(smem), tr, lane, (int64_t)sl * SLICE,
+                                                      PRn, QSn, U, Pc, Qc, 0, 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) bump(cons + slot);
+                continue;
+            }
             float v[B::NT1][4];
             float xb = 0.0f;
             if (sl >= 0) {
@@ -2104,7 +2115,8 @@ __global__ __launch_bounds__(1024, 4) void k_iter_wx(
                     c = __builtin_amdgcn_mfma_f32_16x16x4f32(T4[(T * B::KS1 + st) * 64 + lane], v[st / 4][st % 4], c, 0, 0, 0);
                 h[T][0] = tanh_f(c.x); h[T][1] = tanh_f(c.y); h[T][2] = tanh_f(c.z); h[T][3] = tanh_f(c.w);
             }
-            mfma_records_x<F, D, LAST, XP>(Tm, bm, h, xb, lane, (int64_t)sl * SLICE, PRn, QSn, U, Pc, Qc, 0, 1);
+            if constexpr (EX)
+                mfma_records_x<F, D, LAST, XP>(Tm, bm, h, xb, lane, (int64_t)sl * SLICE, PRn, QSn, U, Pc, Qc, 0, 1);
         }
         return;
     }
@@ -2121,7 +2133,7 @@ __global__ __launch_bounds__(1024, 4) void k_iter_wx(
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
     const int t_begin = xcd * tiles_per_xcd;
     const int t_end = t_begin + tiles_per_xcd < n_tiles ? t_begin + tiles_per_xcd : n_tiles;
-    constexpr bool SPLIT = D >= 64;
+    constexpr bool SPLIT = EX && D >= 64;
     int rot = 0, seq = team, ngrp = 0;                 // seq: this team's next slot sequence number
     for (int t = t_begin; t < t_end;) {
         int sg0, sg1;
@@ -3211,6 +3223,28 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
                     const size_t trw = (size_t)2 * 4 * 16 * B::tr_stride + 4;  // double-buffered scratch of the 4 teams + the group word
                     const int wmax = wide_window_records(4 * D);
                     const unsigned *PRh = reinterpret_cast<const unsigned *>(PR), *QSh = reinterpret_cast<const unsigned *>(QS);
+                    static const bool lockstep_bf = getenv("GNN_WIDE_LOCKSTEP") != nullptr;
+                    if (!lockstep_bf) {             // sweep waves + matrix-core waves (k_iter_wx)
+                        static DevOnce wxb_attr;
+                        if (wxb_attr.need()) {
+                            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter_wx<F, D, true, XP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
+                            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter_wx<F, D, false, XP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
+                        }
+                        const size_t ringw = (size_t)12 * 16 * B::tr_stride + 40;
+                        if (t + 1 == n_iters)
+                            GNN_LAUNCH_SH("k_iter_wx", (k_iter_wx<F, D, true, XP, false>), wgs, 1024,
+                                          (B::template lds_words<true>() + ringw) * 4, s, pl->X, w.table, w.t16, pl->tiles,
+                                          pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PRh, QSh, w.U, PRn, QSn,
+                                          w.Pc, w.Qc, Np, tpx, nt, wmax);
+                        else
+                            GNN_LAUNCH_SH("k_iter_wx", (k_iter_wx<F, D, false, XP, false>), wgs, 1024,
+                                          (B::template lds_words<false>() + ringw) * 4, s, pl->X, w.table, w.t16, pl->tiles,
+                                          pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PRh, QSh, w.U, PRn, QSn,
+                                          w.Pc, w.Qc, Np, tpx, nt, wmax);
+                        float *t1 = PR; PR = PRn; PRn = t1;
+                        float *t2 = QS; QS = QSn; QSn = t2;
+                        continue;
+                    }
                     if (t + 1 == n_iters)
                         GNN_LAUNCH_SH("k_iter_w", (k_iter_w<F, D, true, XP>), wgs, 1024,
                                       (B::template lds_words<true>() + trw) * 4, s, pl->X, w.table, w.t16, pl->tiles,
