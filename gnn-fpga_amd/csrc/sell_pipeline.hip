@@ -2035,7 +2035,7 @@ __global__ __launch_bounds__(1024, (D == 16 ? 8 : 4)) void k_iter_w(
 // cheap on the matrix cores but sat, with its 16 tanh per lane and its stores, behind the round barrier
 // of every wave (k_iter_w without its sweeps still took 0.25 of its 0.345 ms per launch at c5 x 8).
 template <int F, int D, bool LAST, bool XP, bool EX = true>
-__global__ __launch_bounds__(1024, 4) void k_iter_wx(
+__global__ __launch_bounds__(1024, (D == 16 ? 8 : 4)) void k_iter_wx(
     const float *__restrict__ X, const float *__restrict__ table, const unsigned *__restrict__ t16,
     const int32_t *__restrict__ tiles, const int32_t *__restrict__ in_off, const int32_t *__restrict__ in_nbr,
     const int32_t *__restrict__ out_off, const int32_t *__restrict__ out_nbr, const unsigned *__restrict__ PR,
@@ -3223,7 +3223,7 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
                     const size_t trw = (size_t)2 * 4 * 16 * B::tr_stride + 4;  // double-buffered scratch of the 4 teams + the group word
                     const int wmax = wide_window_records(4 * D);
                     const unsigned *PRh = reinterpret_cast<const unsigned *>(PR), *QSh = reinterpret_cast<const unsigned *>(QS);
-                    static const bool lockstep_bf = getenv("GNN_WIDE_LOCKSTEP") != nullptr;
+                    const bool lockstep_bf = getenv("GNN_WIDE_LOCKSTEP") != nullptr;      // (A / B switch: the barrier kernel k_iter_w)
                     if (!lockstep_bf) {             // sweep waves + matrix-core waves (k_iter_wx)
                         static DevOnce wxb_attr;
                         if (wxb_attr.need()) {
@@ -3268,8 +3268,8 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
                     }
                     const int ncu = device_cus() * (D == 16 ? 2 : 1);      // D = 16: two workgroups per CU
                     const unsigned wgs = (unsigned)(((nt < ncu ? nt : ncu) + 7) / 8 * 8);
-                    if constexpr (D >= 32) {       // sweep waves + matrix-core waves (k_iter_wx)
-                        static const bool lockstep = getenv("GNN_WIDE_LOCKSTEP") != nullptr;
+                    if constexpr (D >= 16) {       // sweep waves + matrix-core waves (k_iter_wx)
+                        const bool lockstep = getenv("GNN_WIDE_LOCKSTEP") != nullptr;         // (A / B switch: the barrier kernel k_iter_w)
                         if (!lockstep) {
                             static DevOnce wx_attr;
                             if (wx_attr.need()) {

@@ -1006,6 +1006,36 @@ def test_exact_wide_path_and_its_fallback(hip, F, D, T, monkeypatch):
         assert np.abs(ew - ref).max() < TOL and np.abs(eg - ref).max() < TOL
 
 
+@pytest.mark.parametrize("F,D,T,bf16", [(3, 64, 3, False), (3, 64, 2, True), (2, 32, 3, False), (3, 32, 2, True), (3, 16, 3, False)])
+def test_role_split_wide_kernel_equals_the_barrier_kernel(hip, F, D, T, bf16, monkeypatch):
+    """k_iter_wx (sweep waves + matrix-core waves, LDS ring and counters instead of workgroup barriers:
+    the default for hidden_dim 16 / 32 / 64) against k_iter_w (every round behind barriers;
+    GNN_WIDE_LOCKSTEP=1): the same sweeps in the same order and the same k-ordered products, so the
+    scores must be BIT-identical - on ragged graphs, graphs smaller than a slice, many more slices than
+    ring slots, repeated (a lost or doubled slot hand-off would show), exact fp32 and bf16 records."""
+    from gnn_fpga_amd.model import SegmentClassifier
+    torch.manual_seed(11 * D + T)
+    graphs = ([synth.layered_graph(2500, 20000, F, seed=40 + i) for i in range(5)] +
+              [synth.layered_graph(7, 9, F, n_layers=3, seed=3), synth.layered_graph(300, 2900, F, n_layers=4, seed=4)])
+    m = SegmentClassifier(input_dim=F, hidden_dim=D, n_iters=T).cuda().eval()
+    m.use_events = False
+    m.mlp_bf16 = bf16
+    batch = HitGraphBatch.from_graphs(graphs).cuda()
+    with torch.no_grad():
+        monkeypatch.delenv("GNN_WIDE_LOCKSTEP", raising=False)
+        with hip.profile(64) as prof:
+            a = m(batch).clone()
+        assert "k_iter_wx" in {k for k, _ in prof.records}
+        again = [m(batch).clone() for _ in range(3)]
+        monkeypatch.setenv("GNN_WIDE_LOCKSTEP", "1")
+        with hip.profile(64) as prof:
+            b = m(batch).clone()
+        assert "k_iter_w" in {k for k, _ in prof.records} and "k_iter_wx" not in {k for k, _ in prof.records}
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, x) for x in again)
+    assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("lim_over", [{}, {"iter_records": 0, "edge_records": 0}])
 def test_plan_built_on_the_gpu_equals_the_host_plan(hip, lim_over):
     """HitGraphBatch.build_plan on a CUDA batch runs plan_device.DeviceSellPlan (torch sorts and
