@@ -3055,6 +3055,9 @@ constexpr int t16_words()      // fragment tables of the wide kernels: bf16 (BL)
 }
 template <int F, int D>
 constexpr bool can_exact_wide() { return D % 16 == 0 && F <= 4; }
+// k_iter_wx (sweep waves + matrix-core waves) from this many padded hits on; below it k_iter_w (round barriers).
+// GNN_WIDE_LOCKSTEP=1 / GNN_WIDE_ROLES=1 force one or the other (A / B runs, tests).
+constexpr int64_t kRoleSplitMinHits = 32768;
 
 // k_iter_w's group bound: records of one table an XCD's 4 MB L2 can keep while a group's hits stream
 // through it (3 MB of rows; GNN_WIDE_WINDOW_KB overrides, 0 = every tile a group of its own,
@@ -3223,7 +3226,9 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
                     const size_t trw = (size_t)2 * 4 * 16 * B::tr_stride + 4;  // double-buffered scratch of the 4 teams + the group word
                     const int wmax = wide_window_records(4 * D);
                     const unsigned *PRh = reinterpret_cast<const unsigned *>(PR), *QSh = reinterpret_cast<const unsigned *>(QS);
-                    const bool lockstep_bf = getenv("GNN_WIDE_LOCKSTEP") != nullptr;      // (A / B switch: the barrier kernel k_iter_w)
+                    // (small batches - a workgroup gets a handful of slices - keep the barrier kernel: the ring's polls and its
+                    // end-of-work detection cost more than they hide there, 1k hits at D = 32: 137 vs 159 us per forward)
+                    const bool lockstep_bf = getenv("GNN_WIDE_LOCKSTEP") != nullptr || (Np < kRoleSplitMinHits && !getenv("GNN_WIDE_ROLES"));
                     if (!lockstep_bf) {             // sweep waves + matrix-core waves (k_iter_wx)
                         static DevOnce wxb_attr;
                         if (wxb_attr.need()) {
@@ -3269,7 +3274,7 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
                     const int ncu = device_cus() * (D == 16 ? 2 : 1);      // D = 16: two workgroups per CU
                     const unsigned wgs = (unsigned)(((nt < ncu ? nt : ncu) + 7) / 8 * 8);
                     if constexpr (D >= 16) {       // sweep waves + matrix-core waves (k_iter_wx)
-                        const bool lockstep = getenv("GNN_WIDE_LOCKSTEP") != nullptr;         // (A / B switch: the barrier kernel k_iter_w)
+                        const bool lockstep = getenv("GNN_WIDE_LOCKSTEP") != nullptr || (Np < kRoleSplitMinHits && !getenv("GNN_WIDE_ROLES"));
                         if (!lockstep) {
                             static DevOnce wx_attr;
                             if (wx_attr.need()) {

@@ -212,6 +212,13 @@ class HitGraphBatch:
             ok = (hp[0] == 0 and sp[0] == 0 and hp[-1] == self.n_hits and
                   sp[-1] == self.n_segments and np.all(np.diff(hp) >= 0) and np.all(np.diff(sp) >= 0)
                   and self.n_hits < 2 ** 31 and self.n_segments < 2 ** 31)
+            if ok:
+                # graphs too large for the one-workgroup-per-graph kernels never take them: skip the
+                # endpoint check, which copies src / dst to the host (50 us and a synchronisation on the
+                # first forward of every detector-size batch)
+                from . import _lib
+                if int(np.diff(sp).max(initial=0)) > _lib.EVENTS_MAX_SEGMENTS:
+                    ok = False
             if ok and self.n_segments:
                 src, dst = self.src.cpu().numpy(), self.dst.cpu().numpy()
                 gseg = np.repeat(np.arange(self.n_graphs), np.diff(sp))

@@ -1023,14 +1023,17 @@ def test_role_split_wide_kernel_equals_the_barrier_kernel(hip, F, D, T, bf16, mo
     batch = HitGraphBatch.from_graphs(graphs).cuda()
     with torch.no_grad():
         monkeypatch.delenv("GNN_WIDE_LOCKSTEP", raising=False)
+        monkeypatch.setenv("GNN_WIDE_ROLES", "1")          # (batches below 32k hits take the barrier kernel by default)
         with hip.profile(64) as prof:
             a = m(batch).clone()
         assert "k_iter_wx" in {k for k, _ in prof.records}
         again = [m(batch).clone() for _ in range(3)]
-        monkeypatch.setenv("GNN_WIDE_LOCKSTEP", "1")
+        monkeypatch.delenv("GNN_WIDE_ROLES")
         with hip.profile(64) as prof:
-            b = m(batch).clone()
+            b = m(batch).clone()                               # 13 k hits: the default here is the barrier kernel
         assert "k_iter_w" in {k for k, _ in prof.records} and "k_iter_wx" not in {k for k, _ in prof.records}
+        monkeypatch.setenv("GNN_WIDE_LOCKSTEP", "1")
+        assert torch.equal(b, m(batch))
     torch.cuda.synchronize()
     assert all(torch.equal(a, x) for x in again)
     assert torch.equal(a, b)
