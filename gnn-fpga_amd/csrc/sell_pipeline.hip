@@ -2227,6 +2227,13 @@ __global__ __launch_bounds__(1024, (D == 16 ? 8 : 4)) void k_iter_wx(
             if (lane == 0) bump(prod + slot);
         }
         // (a second meeting point here, before the next group's phase A: 6 % less traffic, 2 % more time)
+        if constexpr (!SPLIT) {
+            // unsplit groups (bf16 rows, D < 64): the sweep waves still enter a GROUP together, so that the
+            // workgroup's teams do not spread over several levels' tables
+            ++ngrp;
+            if (lane == 0) bump(pha);
+            for (int spins = 0; spins < kSpinLimit && ld(pha) < NSW * ngrp; ++spins) __builtin_amdgcn_s_sleep(2);
+        }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) bump(fin);

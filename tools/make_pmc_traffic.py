@@ -23,12 +23,18 @@ def short(name):
     return re.sub(r"^void ", "", name).split("(")[0]
 
 
+# a c5 run times the other arithmetic beside the one it is about: keep the kernels of the section's own
+# (k_iter_wx<F, D, LAST, XP, EX>: EX = true is the exact fp32 form)
+DROP = {"c5_f32": r"k_iter_wx<.*, false>$|k_iter_w<.*, false>$|k_input4_bf|k_pack16",
+        "c5_bf16": r"k_iter_wx<.*, true>$|k_iter_w<.*, true>$|k_input4_x|k_pack32"}.get(section)
 res, sq = {}, {}
 for line in open(os.path.join(out, "summary.txt")):
     m = re.match(r"\s+(k_\S.*?)\s{2,}(\S.*)$", line)
     if not m:
         continue
     k = short(m.group(1))
+    if DROP and re.search(DROP, k):
+        continue
     for c, v, n in re.findall(r"(\w+) mean (\S+) \(n=(\d+)\)", m.group(2)):
         if c in ("FETCH_SIZE", "WRITE_SIZE"):
             res.setdefault(k, {})[c + "_KB_mean"] = float(v)
