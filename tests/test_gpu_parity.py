@@ -589,8 +589,8 @@ def test_small_event_path_declines_what_it_cannot_hold(hip):
     from gnn_fpga_amd.model import SegmentClassifier
     big = synth.layered_graph(3000, 20000, 3, seed=1)
     b = HitGraphBatch.from_graphs([big]).cuda()
-    lay = b.event_layout()
-    assert lay is not None and not hip.events_supported(3, 8, lay.max_hits, lay.max_segments)
+    assert b.event_layout() is None                       # beyond EVENTS_MAX_SEGMENTS: not even checked on the host
+    assert not hip.events_supported(3, 8, 3000, 20000)    # ... and it would not fit one workgroup's LDS anyway
     # segments crossing graph boundaries: legal for the global kernels, not for one-graph-per-workgroup
     g = synth.layered_graph(60, 100, 3, seed=2)
     cross = HitGraphBatch(g.X, g.src, g.dst, hit_ptr=[0, 30, 60], seg_ptr=[0, 50, 100]).cuda()
@@ -1127,8 +1127,8 @@ def test_one_launch_backward_for_small_events(hip, F, D, T):
     for (k, _), a, r in zip(m.named_parameters(), out[True], out[False]):
         assert_grad_close(a, r, "one-launch vs per-pass " + k)
     big = HitGraphBatch.from_graphs([synth.layered_graph(20000, 100000, 3, seed=1)])
-    lb = big.event_layout()
-    assert not _lib.events_backward_supported(3, 8, lb.max_hits, lb.max_segments)
+    assert big.event_layout() is None          # beyond EVENTS_MAX_SEGMENTS: no layout (and no host endpoint check)
+    assert not _lib.events_backward_supported(3, 8, 20000, 100000)
 
 
 def test_one_launch_training_forward_keeps_the_same_tensors(hip):
