@@ -163,3 +163,51 @@ def test_event_route_crossover(hip):
     # wide hidden layers never take it
     names, _ = route_and_times([synth.bipartite_graph([4] * 10, 2, seed=1)], 2, 32)
     assert "k_event" not in names
+
+
+def test_role_split_threshold(hip, monkeypatch):
+    """hidden_dim 16 / 32 / 64 batches of >= 32768 padded hits run the role-split kernel `k_iter_wx`, smaller ones
+    the barrier kernel `k_iter_w` (`kRoleSplitMinHits`, csrc/sell_pipeline.hip).  On a batch well below and one well
+    above the threshold both kernels are timed (HIP-graph replays): the one chosen may be at most 1.15x the other's
+    time, so a kernel change that moves the crossover is noticed."""
+    import time
+    from gnn_fpga_amd.model import SegmentClassifier
+    torch.manual_seed(0)
+
+    def times(graphs, D):
+        m = SegmentClassifier(input_dim=3, hidden_dim=D, n_iters=3).cuda().eval()
+        m.use_events = False
+        b = HitGraphBatch.from_graphs(graphs).cuda()
+        out = {}
+        for env in ("GNN_WIDE_ROLES", "GNN_WIDE_LOCKSTEP", None):
+            monkeypatch.delenv("GNN_WIDE_ROLES", raising=False)
+            monkeypatch.delenv("GNN_WIDE_LOCKSTEP", raising=False)
+            if env:
+                monkeypatch.setenv(env, "1")
+            with torch.no_grad():
+                for _ in range(3):
+                    m(b)
+                if env is None:
+                    with hip.profile(64) as prof:
+                        m(b)
+                    out["default"] = {k for k, _ in prof.records}
+                    continue
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    m(b)
+                for _ in range(5):
+                    g.replay()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(30):
+                    g.replay()
+                torch.cuda.synchronize()
+                out[env] = (time.perf_counter() - t0) / 30
+        return out
+
+    small = times([synth.layered_graph(4000, 30000, 3, seed=s) for s in range(2)], 32)          # 8 k hits
+    assert "k_iter_w" in small["default"] and "k_iter_wx" not in small["default"]
+    assert small["GNN_WIDE_LOCKSTEP"] <= 1.15 * small["GNN_WIDE_ROLES"], small
+    large = times([synth.layered_graph(10000, 100000, 3, seed=s) for s in range(24)], 64)      # 240 k hits
+    assert "k_iter_wx" in large["default"]
+    assert large["GNN_WIDE_ROLES"] <= 1.15 * large["GNN_WIDE_LOCKSTEP"], large
