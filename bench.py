@@ -356,7 +356,9 @@ def train_c4(dev, rank, world, rehearse, steps=60, warmup=15, n_global=512):
             torch.cuda.current_stream().wait_stream(side)
             sync_all()
             cg = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(cg):
+            # (thread-local capture mode with a collective inside: the RCCL watchdog thread's event
+            # queries must not invalidate the capture)
+            with torch.cuda.graph(cg, capture_error_mode="thread_local" if world > 1 else "global"):
                 step_direct()
             for _ in range(warmup):
                 cg.replay()
