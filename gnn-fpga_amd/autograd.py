@@ -20,9 +20,16 @@ class _SegClf(torch.autograd.Function):
         # (only when the backward has its one-launch form too: the per-pass backward wants Q_all)
         if not _lib.events_preferred(F, D, lay, backward=True):
             lay = None
-        e_all, H_all, Q_all = _lib.segclf_forward_train(batch, w, F, D, n_iters, layout=lay)
+        # plan-space twin of a detector-size batch: the fused tile kernels of the batch's own plan
+        fused = _lib.segclf_forward_train_fused(batch, w, F, D, n_iters) if lay is None else None
+        if fused is not None:
+            e_all, H_all, Q_all, e_out = fused
+        else:
+            e_all, H_all, Q_all = _lib.segclf_forward_train(batch, w, F, D, n_iters, layout=lay)
         ctx.batch, ctx.F, ctx.D, ctx.n_iters, ctx.use_events = batch, F, D, n_iters, lay is not None
         ctx.save_for_backward(e_all, H_all, Q_all, *w)
+        if fused is not None:
+            return e_out                                 # already in the caller's segment order
         rank = getattr(batch, "seg_rank", None)          # level-ordered twin: back to the caller's segment order
         return e_all[n_iters].clone() if rank is None else e_all[n_iters].index_select(0, rank)
 

@@ -1073,16 +1073,18 @@ __global__ __launch_bounds__(1024) void k_input4_x(const float *__restrict__ X,
     }
 }
 
-template <int F, int D, bool LAST, bool XP>
+template <int F, int D, bool LAST, bool XP, bool TR = false>
 __global__ __launch_bounds__(256) void k_input4(const float *__restrict__ X, gnn_params_t p,
                                                 float *__restrict__ table,
                                                 float *__restrict__ PRn, float *__restrict__ QSn,
                                                 float *PRo, float *QSo,
                                                 float *__restrict__ U, float *__restrict__ Pc,
-                                                float *__restrict__ Qc, int64_t n_pad)
+                                                float *__restrict__ Qc, int64_t n_pad, float *H0 = nullptr,
+                                                int ldh = 0)
 {
     using L = TL<F, D>;
     constexpr int d4 = L::d4;
+    (void)H0; (void)ldh;
     __shared__ __attribute__((aligned(16))) float lds[L::total];
     // Every workgroup packs the weight table straight from the raw weights (a few L2-resident
     // loads per thread: cheaper than one more kernel boundary); workgroup 0 also publishes it
@@ -1113,6 +1115,15 @@ __global__ __launch_bounds__(256) void k_input4(const float *__restrict__ X, gnn
         role_gemv<d4, 0, F>(wl + L::o_in, x, x, hl);
 #pragma unroll
         for (int i = 0; i < d4; ++i) hl[i] = tanh_f(hl[i]);
+        if constexpr (TR) {                 // H_0 row = [tanh(Win x + bin) | x | 0] (model.py:144-146), kept for the backward
+            float *hr = H0 + n * ldh;
+            store_vec<d4>(hr + q * d4, hl);
+            if (q == 0) {
+#pragma unroll
+                for (int k = 0; k < F; ++k) hr[D + k] = x[k];
+                for (int k = D + F; k < ldh; ++k) hr[k] = 0.0f;
+            }
+        }
         float hn[D];
         quad_allgather<d4>(hl, hn);
         // (scalar-FMA form here: with the packed one the scheduler hoists LDS reads into spills)
@@ -1286,9 +1297,11 @@ struct Recs {
 __device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xFFFF0000u); }
 
-template <int D4, bool XP>
+// ES (training forward): lane q of the quad stores the score of list step k0 + q at eo (when ok)
+template <int D4, bool XP, bool ES = false>
 __device__ __forceinline__ void score4(const float (*rec)[2 * D4], const float *own,
-                                       const float *w2, float b2, int q, float *acc)
+                                       const float *w2, float b2, int q, float *acc, float *eo = nullptr,
+                                       bool ok = false)
 {
     float part[4];
 #ifndef GNN_NO_PK
@@ -1362,6 +1375,8 @@ __device__ __forceinline__ void score4(const float (*rec)[2 * D4], const float *
     const float give = hi ? t0 : t1, keep = hi ? t1 : t0;
     const float mine = keep + dpp<0x4E>(give);         // full sum of segment q, in lane q
     const float e = r_f(mine + b2);
+    if constexpr (ES)
+        if (ok) *eo = e;
     const float e4[4] = {quad_bcast_f<0>(e), quad_bcast_f<1>(e), quad_bcast_f<2>(e),
                          quad_bcast_f<3>(e)};
     if constexpr (use_pk_wide) {
@@ -1386,10 +1401,12 @@ __device__ __forceinline__ void score4(const float (*rec)[2 * D4], const float *
 // walk one list: the first MAXC chunks were prefetched into `pre`, the rest (rare) streams from
 // `lst` (= nbr + base + 16*q + i16).  REC is the record table (LDS window or global memory);
 // `null_idx` is the NULL record's index in REC.
-template <int D, bool XP>
+// ES: the scores of the list's segments go to ebase[0 .. len) (entry k of this hit's list; the training
+// forward keeps them for the backward, in the order the hit's list has them)
+template <int D, bool XP, bool ES = false>
 __device__ __forceinline__ void sweep(const int *pre, const int32_t *__restrict__ lst, int len,
                                       int null_idx, const float *REC, int q, const float *own,
-                                      const float *w2, float b2, float *acc)
+                                      const float *w2, float b2, float *acc, float *ebase = nullptr, int elen = 0)
 {
     constexpr int d4 = D / 4;
     if (len <= 0) return;
@@ -1402,13 +1419,13 @@ __device__ __forceinline__ void sweep(const int *pre, const int32_t *__restrict_
     for (int c = 0; c < MAXC; ++c) {
         if (4 * c < len) {
             a.read(fix(pre[c], len - 4 * c), REC, q);
-            score4<d4, XP>(a.r, own, w2, b2, q, acc);
+            score4<d4, XP, ES>(a.r, own, w2, b2, q, acc, ebase + 4 * c + q, 4 * c + q < elen);
         }
     }
     // lists longer than 4*MAXC steps (rare): stream the remaining chunks
     for (int k = 4 * MAXC; k < len; k += 4) {
         a.read(fix(lst[k * SLICE], len - k), REC, q);
-        score4<d4, XP>(a.r, own, w2, b2, q, acc);
+        score4<d4, XP, ES>(a.r, own, w2, b2, q, acc, ebase + k + q, k + q < elen);
     }
 }
 
@@ -1494,9 +1511,19 @@ __device__ __forceinline__ void sweep16(int (&c)[NC], const int32_t *__restrict_
     }
 }
 
+// What the TRAINING forward keeps of an iteration besides the next records (gnn_segclf_forward_train_plan; the
+// backward kernels read them): the scores e_t of the segments in the order of the hits' IN-lists (= the order of
+// the plan-space batch the backward runs on: its segments are sorted by end hit), the node network's hidden layer
+// q_t = tanh(W3 [mi | mo | H] + b3) and the new hit rows H_{t+1} = [H' | X | 0] of `ldh` floats.
+struct TrainOut {
+    const int32_t *seg_ptr;      // [n_pad + 1] first in-segment of every padded hit (CSR pointer of the backward's batch)
+    float *e_t, *Q_t, *H_next;
+    int ldh;
+};
+
 // one message-passing iteration for one tile: edge scores + weighted aggregation + hit update
 // (+ records for the next pass).  One workgroup per tile; each wavefront takes 16-hit slices.
-template <int F, int D, bool LAST, bool XP>
+template <int F, int D, bool LAST, bool XP, bool TR = false>
 __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_iter(
     const float *__restrict__ X, const float *__restrict__ table,
     const int32_t *__restrict__ tiles, const int32_t *__restrict__ in_off,
@@ -1504,11 +1531,12 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_iter(
     const int32_t *__restrict__ out_nbr, const float *__restrict__ PR,
     const float *__restrict__ QS, float *__restrict__ U, float *__restrict__ PRn,
     float *__restrict__ QSn, float *__restrict__ Pc, float *__restrict__ Qc, int64_t n_pad,
-    int tiles_per_xcd, int n_tiles, int ablate)
+    int tiles_per_xcd, int n_tiles, int ablate, TrainOut tro = TrainOut{})
 {
     using L = TL<F, D>;
     using G = Cfg<F, D>;
     constexpr int d4 = L::d4, NT = G::NT;
+    (void)tro;
     // dynamic LDS: [weight table | record windows]; sized by the host from the plan, so batches
     // of small graphs (small windows) get several workgroups per CU
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1598,7 +1626,9 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_iter(
         const int next = slice_of(r + 1);
         if (next >= 0) {
             prefetch(nxt, next);
-            if constexpr (!G::pipelined) arrive(nxt);
+            // (the training variant carries more state across the sweep: it waits for its prefetch at
+            // once instead of keeping it in flight - the in-flight window is only sound without spills)
+            if constexpr (!G::pipelined || TR) arrive(nxt);
         }
         Records<F, D, LAST, XP> rec;
         const int64_t n = (int64_t)slice * SLICE + i16;
@@ -1611,24 +1641,41 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_iter(
             float acc[d4], Pn[d4], Qn[d4], xv[F];
             cur.acc.get(acc); cur.x.get(xv);
             cur.Pn.get(Pn); cur.Qn.get(Qn);
+            float *eb = nullptr;          // TR: where the scores of this hit's in-list go, and how many are real
+            int en = 0;
+            if constexpr (TR) {
+                const int s0 = tro.seg_ptr[n];
+                en = tro.seg_ptr[n + 1] - s0;
+                eb = tro.e_t + s0;
+            }
             if (ablate & 2) {
             } else if (G::it_rec > 0 && mode) {
                 // segments ending here: P[start] + Q[n], adds e * R[start]; then starting here
-                sweep<D, XP>(cur.cin, in_nbr + cur.ib + q * SLICE + i16, cur.il, in_cnt, winA, q, Qn, w2, b2, acc);
+                sweep<D, XP, TR>(cur.cin, in_nbr + cur.ib + q * SLICE + i16, cur.il, in_cnt, winA, q, Qn, w2, b2, acc, eb, en);
                 sweep<D, XP>(cur.cout, out_nbr + cur.ob + q * SLICE + i16, cur.ol, out_cnt, winB, q, Pn, w2, b2, acc);
             } else {
-                sweep<D, XP>(cur.cin, in_nbr + cur.ib + q * SLICE + i16, cur.il, (int)n_pad, PR, q, Qn, w2, b2, acc);
+                sweep<D, XP, TR>(cur.cin, in_nbr + cur.ib + q * SLICE + i16, cur.il, (int)n_pad, PR, q, Qn, w2, b2, acc, eb, en);
                 sweep<D, XP>(cur.cout, out_nbr + cur.ob + q * SLICE + i16, cur.ol, (int)n_pad, QS, q, Pn, w2, b2, acc);
             }
             // hit update: H' = tanh(W4 tanh(acc) + b4)                  (model.py:94-98,125)
             float ql[d4], qa[D];
 #pragma unroll
             for (int i = 0; i < d4; ++i) ql[i] = tanh_f(acc[i]);
+            if constexpr (TR) store_vec<d4>(tro.Q_t + n * D + q * d4, ql);
             quad_allgather<d4>(ql, qa);
             float hl[d4];
             role_gemv<d4, D, 0>(wl + L::o_4, qa, qa, hl);
 #pragma unroll
             for (int i = 0; i < d4; ++i) hl[i] = tanh_f(hl[i]);
+            if constexpr (TR) {           // H_{t+1} row = [H' | X | 0] (model.py:154)
+                float *hr = tro.H_next + n * tro.ldh;
+                store_vec<d4>(hr + q * d4, hl);
+                if (q == 0) {
+#pragma unroll
+                    for (int k = 0; k < F; ++k) hr[D + k] = xv[k];
+                    for (int k = D + F; k < tro.ldh; ++k) hr[k] = 0.0f;
+                }
+            }
             float hn[D];
             quad_allgather<d4>(hl, hn);
             if (!(ablate & 4)) rec.compute(wl, hn, xv);
@@ -3360,6 +3407,74 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
     return 0;
 }
 
+// The TRAINING forward on a planned batch (gnn_segclf_forward_train_plan): the fused tile kernels, keeping what
+// the backward needs (TrainOut) - instead of the per-module kernels' k_input + T x (k_pq, k_edge, k_node), whose
+// node pass walks both segment lists through the L2 (0.31 ms of a 0.97 ms step at c3 x 32; this: 0.2).
+// e_all [(T + 1), E]: rows 0 .. T-1 in the order of the hits' in-lists (segments sorted by end hit, stable),
+// valid segments only; row T is NOT written here (the final scores come back in e_out, the plan's segment
+// order).  H_all [(T + 1), n_pad, ldh], Q_all [T, n_pad, D].  Shapes on the general tile kernel only (D <= 16
+// without the wide route); others: GNN_ERR_UNSUPPORTED (the caller keeps the per-module route).
+template <int F, int D, bool XP>
+int forward_train_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, const int32_t *seg_ptr, float *e_all,
+                    float *H_all, float *Q_all, int ldh, float *e_out, char *ws, hipStream_t s)
+{
+    using L = TL<F, D>;
+    using G = Cfg<F, D>;
+    if constexpr (D > 16 || G::wide16) {
+        return fail(GNN_ERR_UNSUPPORTED, "no fused training forward for input_dim=%d hidden_dim=%d", F, D);
+    } else {
+        const int64_t Np = pl->n_pad, E = pl->n_segments;
+        Ws w = carve(ws, Np, L::total, D, t16_words<F, D>());
+        if (Np == 0 || G::pack_first)
+            GNN_LAUNCH("k_pack", (k_pack<F, D, XP>), (L::total + 255) / 256, 256, s, *p, w.table, w.PRa, w.PRb,
+                       w.QSa, w.QSb, w.U, w.Pc, w.Qc, Np);
+        float *PR = w.PRa, *PRn = w.PRb, *QS = w.QSa, *QSn = w.QSb;
+        if (Np > 0) {
+            const int nt = (int)pl->n_tiles;
+            const int tpx = (nt + 7) / 8;
+            const size_t it_lds = (size_t)(L::total + (G::it_rec > 0 ? pl->iter_lds_records : 0) * 2 * D + 4) * sizeof(float);
+            static DevOnce attr_done;
+            if (attr_done.need()) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter<F, D, true, XP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter<F, D, false, XP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
+            }
+            const int64_t g_need = (Np * 4 + 255) / 256;
+            const unsigned g = (unsigned)(g_need < 4096 ? g_need : 4096);
+            if (n_iters == 0)
+                GNN_LAUNCH("k_input4", (k_input4<F, D, true, XP, true>), g, 256, s, pl->X, *p, w.table, PR, QS,
+                           PRn, QSn, w.U, w.Pc, w.Qc, Np, H_all, ldh);
+            else
+                GNN_LAUNCH("k_input4", (k_input4<F, D, false, XP, true>), g, 256, s, pl->X, *p, w.table, PR, QS,
+                           PRn, QSn, w.U, w.Pc, w.Qc, Np, H_all, ldh);
+            for (int t = 0; t < n_iters; ++t) {
+                const TrainOut tro{seg_ptr, e_all + (size_t)t * E, Q_all + (size_t)t * Np * D,
+                                   H_all + (size_t)(t + 1) * Np * ldh, ldh};
+                if (t + 1 == n_iters)
+                    GNN_LAUNCH_SH("k_iter", (k_iter<F, D, true, XP, true>), 8 * tpx, G::NT, it_lds, s, pl->X, w.table,
+                                  pl->tiles, pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PR, QS, w.U,
+                                  PRn, QSn, w.Pc, w.Qc, Np, tpx, nt, 0, tro);
+                else
+                    GNN_LAUNCH_SH("k_iter", (k_iter<F, D, false, XP, true>), 8 * tpx, G::NT, it_lds, s, pl->X, w.table,
+                                  pl->tiles, pl->in_off, pl->in_nbr, pl->out_off, pl->out_nbr, PR, QS, w.U,
+                                  PRn, QSn, w.Pc, w.Qc, Np, tpx, nt, 0, tro);
+                float *t1 = PR; PR = PRn; PRn = t1;
+                float *t2 = QS; QS = QSn; QSn = t2;
+            }
+        }
+        if (E > 0) {
+            const int nc = (int)pl->n_chunks;
+            const int cpx = (nc + 7) / 8;
+            const size_t ed_lds = (size_t)((G::ed_rec > 0 ? pl->edge_lds_rows : 0) * D + 4) * sizeof(float);
+            static DevOnce edge_attr;
+            if (edge_attr.need())
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_edge<F, D, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes);
+            GNN_LAUNCH_SH("k_edge", (k_edge<F, D, XP>), 8 * cpx, G::NT, ed_lds, s, pl->chunks, pl->src, pl->dst, pl->sd16, w.Pc,
+                          w.Qc, w.table, e_out, Np, cpx, nc);
+        }
+        return 0;
+    }
+}
+
 #ifdef GNN_QUICK      // compile-time experiments: one shape only
 #ifndef GNN_QUICK_F
 #define GNN_QUICK_F 3
@@ -3408,6 +3523,24 @@ size_t sell_workspace_bytes(int64_t n_pad, int64_t n_segments, int F, int D)
     SELL_FOR_EACH_SHAPE(X_)
 #undef X_
     return 0;
+}
+
+int sell_forward_train(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, const int32_t *seg_ptr, float *e_all,
+                       float *H_all, float *Q_all, int ldh, float *e_out, void *ws, size_t ws_bytes, hipStream_t s)
+{
+    ProfChain chain_;
+    const size_t need = sell_workspace_bytes(pl->n_pad, pl->n_segments, p->F, p->D);
+    if (need == 0) return fail(GNN_ERR_UNSUPPORTED, "no fused kernel for input_dim=%d hidden_dim=%d", p->F, p->D);
+    if (!ws || ws_bytes < need) return fail(GNN_ERR_WORKSPACE, "workspace too small: need %zu bytes", need);
+    char *base = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
+#define X_(F_, D_)                                                                                        \
+    if (p->F == F_ && p->D == D_)                                                                        \
+        return (p->flags & GNN_FLAG_EXP_PRODUCT)                                                         \
+                   ? forward_train_t<F_, D_, true>(pl, p, n_iters, seg_ptr, e_all, H_all, Q_all, ldh, e_out, base, s)  \
+                   : forward_train_t<F_, D_, false>(pl, p, n_iters, seg_ptr, e_all, H_all, Q_all, ldh, e_out, base, s);
+    SELL_FOR_EACH_SHAPE(X_)
+#undef X_
+    return fail(GNN_ERR_UNSUPPORTED, "unreachable");
 }
 
 int sell_forward(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e_out, void *ws,

@@ -150,14 +150,17 @@ class HitGraphBatch:
         return self.plan
 
     def level_ordered(self, hidden_dim=8):
-        """The same batch with its hits renumbered in PLAN order - (graph, detector level), tiles,
-        degree.  In that order the neighbours of consecutive hits lie in narrow id ranges, which makes
-        the training kernels' record gathers L2-local (c3 x 32 training step 1.68 -> 1.46 ms); scores
-        are handed back per segment in the caller's order (the twin's own segments are sorted by end
-        hit: `seg_order` / `seg_rank`) and weight gradients do not depend on numbering, so the twin is
-        a drop-in for the training forward / backward.  Built once per batch (one plan
-        + two GPU sorts for its CSRs) and cached; returns self when there is nothing to gain (CPU
-        batch, no segments, no plan for this shape)."""
+        """The same batch in PLAN SPACE: hits numbered by the execution plan's padded ids - (graph, detector
+        level), tiles, degree; `plan.n_pad` hits, the padding dummies without segments and with X = 0 - and
+        segments sorted by end hit (stable: a hit's incoming segments keep the caller's order, which is the order
+        of its list in the plan).  In that order the neighbours of consecutive hits lie in narrow id ranges, which
+        makes the training kernels' record gathers L2-local (c3 x 32 training step 1.68 -> 1.46 ms), the scores of
+        a hit's incoming segments are contiguous, and - round 3 - the training forward can run the fused tile
+        kernels on the ORIGINAL batch's plan (`_fused`: gnn_segclf_forward_train_plan writes e_t / H_t / Q_t
+        straight in this batch's numbering).  Scores are handed back per segment in the caller's order
+        (`seg_order` / `seg_rank`) and weight gradients do not depend on numbering, so the twin is a drop-in for the
+        training forward / backward.  Built once per batch (one plan + GPU sorts for its CSRs) and cached; returns
+        self when there is nothing to gain (CPU batch, no segments, no plan for this shape)."""
         twin = getattr(self, "_twin", None)
         if twin is not None:
             return twin
@@ -169,21 +172,22 @@ class HitGraphBatch:
         except Exception:                      # no fused kernels for this shape: keep the caller's order
             return self
         dev = self.X.device
-        perm = plan.perm.to(torch.int64)
-        order = perm[perm >= 0]                                   # twin id -> caller's hit id
+        n_pad = int(plan.n_pad)
+        perm = plan.perm.to(torch.int64)                          # padded id -> caller's hit id, -1 = dummy
+        new_ids = torch.nonzero(perm >= 0).reshape(-1)
         rank = torch.empty(self.n_hits, dtype=torch.int64, device=dev)
-        rank[order] = torch.arange(self.n_hits, dtype=torch.int64, device=dev)
+        rank[perm[new_ids]] = new_ids                             # caller's hit id -> padded id
         src, dst = self.src.to(torch.int64), self.dst.to(torch.int64)
         t = HitGraphBatch.__new__(HitGraphBatch)
         t.__dict__.update({k: v for k, v in self.__dict__.items() if not k.startswith("_")})
-        t.X = self.X[order].contiguous()
+        t.n_hits = n_pad
+        t.X = plan.X[:n_pad].contiguous()                         # the plan's renumbered rows (dummies: zeros)
         ts = torch.where(src >= 0, rank[src.clamp_min(0)], src)
         td = torch.where(dst >= 0, rank[dst.clamp_min(0)], dst)
-        # segments sorted by (end hit, start hit), padded ones last: the scores of a hit's incoming
-        # segments become contiguous and the edge passes gather nearly sequentially (c3 x 32 training
-        # step 1.15 -> 1.02 ms).  seg_order[k] = caller's index of the twin's segment k; the autograd
-        # function hands scores back (and takes their gradient) in the caller's order.
-        key = torch.where(ts >= 0, td * (self.n_hits + 1) + ts, torch.full_like(ts, 2 ** 62))
+        # segments sorted by end hit, padded ones last, ties in the caller's order: seg_order[k] = caller's index
+        # of the twin's segment k; the autograd function hands scores back (and takes their gradient) in the
+        # caller's order
+        key = torch.where(ts >= 0, td, torch.full_like(td, 2 ** 62))
         seg_order = torch.argsort(key, stable=True)
         t.src = ts[seg_order].to(torch.int32).contiguous()
         t.dst = td[seg_order].to(torch.int32).contiguous()
@@ -197,6 +201,8 @@ class HitGraphBatch:
         t._gstruct = None
         t._event = (None,)                     # detector-size graphs: never the one-launch kernels
         t.plan = None
+        t._fused = plan                        # the plan whose padded ids ARE this batch's hit ids
+        t._fused_dim = hidden_dim
         t._twin = t
         self._twin = t
         return t

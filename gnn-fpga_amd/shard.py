@@ -124,7 +124,11 @@ class GradBucket:
             if lay is None:
                 from .autograd import training_batch
                 batch = training_batch(model, batch, False)      # level-ordered twin: L2-local gathers
-            e_all, H_all, Q_all = _lib.segclf_forward_train(batch, w, F, D, T, layout=lay)
+            fused = _lib.segclf_forward_train_fused(batch, w, F, D, T) if lay is None else None
+            if fused is not None:
+                e_all, H_all, Q_all, _ = fused
+            else:
+                e_all, H_all, Q_all = _lib.segclf_forward_train(batch, w, F, D, T, layout=lay)
             yv = y.detach().to(torch.float32).contiguous().reshape(-1)
             order = getattr(batch, "seg_order", None)      # level-ordered twin: its segments are sorted
             if order is not None:

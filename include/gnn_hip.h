@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNN_ABI_VERSION 3
+#define GNN_ABI_VERSION 4
 
 #define GNN_ERR_UNSUPPORTED (-10001) /* (F, D) has no kernel instantiation            */
 #define GNN_ERR_BADARG      (-10002) /* null pointer, negative size, bad stride ...   */
@@ -224,6 +224,21 @@ int gnn_segclf_backward_events(const gnn_graph_t *g, const gnn_params_t *p, cons
 size_t gnn_plan_workspace_bytes(int64_t n_pad, int64_t n_segments, int32_t F, int32_t D);
 int gnn_segclf_forward_plan(const gnn_plan_t *plan, const gnn_params_t *p, int32_t n_iters,
                             float *e_out, void *workspace, size_t workspace_bytes, void *stream);
+/* The TRAINING forward on a planned batch (ABI 4): the same tile kernels, keeping what the backward
+ * (gnn_segclf_backward) needs - what gnn_segclf_forward_train keeps with the per-module kernels
+ * (autograd for gnn/estimator.py:53,57-58).  The backward's batch must be the plan-space form of the
+ * planned batch: hits numbered by the plan's padded ids (n_pad hits, dummies without segments),
+ * segments sorted by end hit (stable), `seg_ptr` [n_pad + 1] = its CSR pointer over end hits
+ * (in_ptr).  Written: e_all rows 0 .. n_iters-1 ([n_iters + 1, n_segments]; the scores of every pass
+ * in THAT segment order, valid segments only - padded ones are never read by the backward's list
+ * walks), H_all [(n_iters + 1), n_pad, ldh] (ldh = gnn_h_stride), Q_all [n_iters, n_pad, D] and the
+ * final scores e_out [n_segments] in the PLAN's segment order (the caller's); row n_iters of e_all is
+ * the caller's to fill (a gather of e_out).  Shapes on the general tile kernel only (hidden_dim <= 16
+ * without the 16-lanes-per-hit route): GNN_ERR_UNSUPPORTED otherwise.  Workspace as
+ * gnn_segclf_forward_plan. */
+int gnn_segclf_forward_train_plan(const gnn_plan_t *plan, const gnn_params_t *p, int32_t n_iters,
+                                  const int32_t *seg_ptr, float *e_all, float *H_all, float *Q_all,
+                                  float *e_out, void *workspace, size_t workspace_bytes, void *stream);
 /* 1 if the fused pipeline has kernels for this (input_dim, hidden_dim). */
 int gnn_plan_shape_supported(int32_t F, int32_t D);
 /* Plan-building limits for a shape: out4 = { tile_hits, iter_records, chunk_segments,

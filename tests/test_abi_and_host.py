@@ -163,6 +163,8 @@ def test_pipelined_kernels_never_spill():
         F, D = int(m.group(2)), int(m.group(3))
         if m.group(1) == "k_iter":
             pipelined = (D <= 8 and F <= 3) or D == 4             # mirrors Cfg::pipelined
+            if m.group(7) == "true":                              # the training variant (TR) waits for its prefetch
+                pipelined = False                                 # at once: nothing asm-loaded is in flight across work
         else:
             pipelined = D <= 8                                    # mirrors Cfg::iter2
         scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))

@@ -842,7 +842,7 @@ def test_training_on_the_level_ordered_twin(hip, D):
     assert getattr(b2, "_twin", None) is not None and b2._twin is not b2
     e0, l0, g0 = grads(False)
     twin = b.level_ordered(D)
-    assert twin is not b and twin.n_hits == b.n_hits
+    assert twin is not b and twin.n_hits == b.plan.n_pad >= b.n_hits       # plan space: padded hit ids
     # the twin's segments are sorted by end hit, padded ones last; seg_order / seg_rank are inverse
     td = twin.dst.long()
     n_valid = int((td >= 0).sum())
@@ -855,6 +855,55 @@ def test_training_on_the_level_ordered_twin(hip, D):
     for (k, _), a, c, d in zip(m.named_parameters(), g0, g1, g2):
         assert torch.equal(c, d), k
         assert_grad_close(c, a, "level-ordered twin " + k)
+
+
+@pytest.mark.parametrize("F,D,T", [(3, 8, 3), (3, 4, 2), (11, 8, 2), (11, 16, 1), (2, 8, 0)])
+def test_fused_training_forward_keeps_what_the_per_module_one_keeps(hip, F, D, T, monkeypatch):
+    """gnn_segclf_forward_train_plan (ABI 4): the training forward of a plan-space batch on the fused tile kernels
+    of the plan it was made from, against gnn_segclf_forward_train (per-module kernels) on the same batch: the
+    scores of every pass e_t (valid segments), the hit rows H_t, the node networks' hidden layers Q_t - 2e-6
+    (other summation orders; the dummies of the padding included: they are hits without segments) - the final
+    scores in the caller's order, and the gradients the backward makes of either set.  Ragged graphs, padded
+    segments, a graph smaller than a slice."""
+    from gnn_fpga_amd import _lib
+    from gnn_fpga_amd.model import SegmentClassifier
+    torch.manual_seed(4 * D + T)
+    graphs = [synth.layered_graph(2500, 21000, F, seed=60 + i) for i in range(3)] + \
+             [synth.layered_graph(9, 11, F, n_layers=3, seed=5), synth.layered_graph(400, 700, F, n_layers=5, seed=6)]
+    b = HitGraphBatch.from_graphs(graphs)
+    src, dst = b.src.numpy().copy(), b.dst.numpy().copy()
+    src[3::41] = -1
+    dst[3::41] = -1
+    b = HitGraphBatch(b.X.numpy(), src, dst, hit_ptr=b.hit_ptr, seg_ptr=b.seg_ptr).cuda()
+    twin = b.level_ordered(D)
+    assert twin is not b and twin._fused is b.plan and twin.n_hits == b.plan.n_pad
+    m = SegmentClassifier(input_dim=F, hidden_dim=D, n_iters=T).cuda()
+    w = [t.detach().contiguous() for t in m.effective_weights()]
+    fused = _lib.segclf_forward_train_fused(twin, w, F, D, T)
+    assert fused is not None
+    e_f, H_f, Q_f, out_f = fused
+    e_p, H_p, Q_p = _lib.segclf_forward_train(twin, w, F, D, T)
+    valid = (twin.src >= 0)
+    assert (e_f[:, valid] - e_p[:, valid]).abs().max().item() < 2e-6
+    assert (H_f - H_p).abs().max().item() < 2e-6
+    if T:
+        assert (Q_f - Q_p).abs().max().item() < 2e-6
+    # final scores in the caller's order: the twin's, gathered back
+    assert (out_f - e_p[T].index_select(0, twin.seg_rank)).abs().max().item() < 2e-6
+    go = torch.rand(b.n_segments, device="cuda")
+    g_f = _lib.segclf_backward(twin, w, F, D, T, e_f, H_f, go, Q_all=Q_f)
+    g_p = _lib.segclf_backward(twin, w, F, D, T, e_p, H_p, go, Q_all=Q_p)
+    for k, (a, r) in enumerate(zip(g_f, g_p)):
+        assert_grad_close(a, r, "fused training forward tensor %d" % k)
+    # the autograd route takes it for detector-size batches (and GNN_NO_FUSED_TRAIN=1 keeps the per-module one)
+    m.train()
+    m.level_order_training = True
+    with hip.profile(128) as prof:
+        out = m(b)
+    assert "k_iter" in {k for k, _ in prof.records} or b.n_hits < 20000
+    monkeypatch.setenv("GNN_NO_FUSED_TRAIN", "1")
+    out2 = m(b)
+    assert (out - out2).abs().max().item() < 2e-6
 
 
 @pytest.mark.parametrize("F,D,T", [(3, 8, 3), (11, 16, 2), (3, 4, 2), (11, 8, 1)])
