@@ -106,6 +106,8 @@ SIGNATURES = {
     "gnn_plan_shape_supported": (ctypes.c_int, [_i32, _i32]),
     "gnn_plan_limits": (ctypes.c_int, [_i32, _i32, ctypes.POINTER(_i32)]),
     "gnn_exp_product_bound": (ctypes.c_int, [ctypes.POINTER(GnnParams), _f, _f, _f]),
+    "gnn_csr_build_workspace_bytes": (_sz, [_i64, _i64]),
+    "gnn_csr_build": (ctypes.c_int, [_f, _f, _i64, _i64, _f, _f, _f, _f, _f, _f, _f, _f, _sz, _f]),
     "gnn_plan_build_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "gnn_plan_build_sizes": (ctypes.c_int, [_f, _f, _f, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _f, _sz,
                                             _f, _f]),
@@ -470,6 +472,24 @@ def dense_to_index(Ri, Ro):
         _check(load().gnn_dense_to_index(_dev(Ri, torch.float32, "Ri"), _dev(Ro, torch.float32, "Ro"), B, N, E,
                                          src.data_ptr(), dst.data_ptr(), flags.data_ptr(), st))
     return src, dst, flags
+
+
+def csr_build(src, dst, n_hits):
+    """The two segment lists of a batch on the device (gnn_csr_build): (in_ptr, in_eid, in_nbr, out_ptr, out_eid,
+    out_nbr, status) - eid / nbr arrays of n_segments entries (the lists, then -1), status int32 [1] on the device
+    (bit 0: malformed endpoints).  Asynchronous, no read-back - the caller decides whether to look at the status."""
+    dev, i32 = src.device, torch.int32
+    E = int(src.numel())
+    ptrs = torch.empty((2, n_hits + 1), dtype=i32, device=dev)
+    lists = torch.empty((4, max(E, 1)), dtype=i32, device=dev)
+    status = torch.empty(1, dtype=i32, device=dev)
+    need = int(load().gnn_csr_build_workspace_bytes(n_hits, E))
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    with _on(src) as st:
+        _check(load().gnn_csr_build(_dev(src, i32, "src"), _dev(dst, i32, "dst"), n_hits, E, ptrs[0].data_ptr(),
+                                    lists[0].data_ptr(), lists[1].data_ptr(), ptrs[1].data_ptr(), lists[2].data_ptr(),
+                                    lists[3].data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel(), st))
+    return ptrs[0], lists[0][:E], lists[1][:E], ptrs[1], lists[2][:E], lists[3][:E], status
 
 
 def _grad_views(weights, dev):

@@ -1,0 +1,270 @@
+// csr_build.hip - the two segment lists of a batch (CSR over end hits and over start hits), built on the GPU.
+//
+// The reference keeps the hit <-> segment association as dense one-hot matrices Ri, Ro [N, E] built per graph on the
+// host (gnn/graph.py:28-35) and padded per batch (gnn/trainSegmentClassifier.py:66-95); its on-disk form is
+// `Ri.nonzero()` / `Ro.nonzero()` in row-major order (gnn/graph.py:20-26): for every hit the ids of the segments that
+// end (start) there, ascending.  gnn_csr_build makes exactly those arrays from the index form (src, dst): the same
+// arrays hitgraph._csr_by builds with a stable sort on the host, entry for entry - what the per-module kernels
+// (k_node, the backward walks) consume.  A never-seen batch used to pay two stable torch sorts and a read-back here
+// (0.45 ms for one 100k-segment graph: most of a trigger-style "one graph in, scores out" call,
+// gnn/Inference.ipynb cell 3); this is four or six small launches and no read-back.
+//
+//   k_csr_degrees   one lane per segment: atomic counts per end hit / start hit; malformed segments set the status word
+//   k_csr_scan*     exclusive scan of both count arrays -> in_ptr / out_ptr  (one workgroup per array up to 256k hits,
+//                   else block sums -> their scan -> block rescan)
+//   k_csr_fill      one lane per segment: claims a slot of its end hit's / start hit's list (atomic countdown on the
+//                   counts) - the order INSIDE a list depends on the atomics' arrival
+//   k_csr_rank      one lane per segment: its rank in its list = number of ids in the list smaller than its own
+//                   (lists are short: ~10 entries) -> the final slot; ascending ids whatever the arrival order was,
+//                   so the arrays (and every sum the kernels make over them) are the same in every run
+#include "common.h"
+
+namespace gnn {
+namespace {
+
+constexpr int kScanItems = 8;                          // per thread of a scan block
+constexpr int kScanTile = kBlock * kScanItems;         // 2048 counts per workgroup
+constexpr int64_t kOneBlockMax = 262144;               // up to here one workgroup scans an array in a loop
+
+__device__ __forceinline__ bool seg_ok(int s, int d, int64_t n) { return (unsigned)s < (unsigned)n && (unsigned)d < (unsigned)n; }
+
+__global__ __launch_bounds__(kBlock) void k_csr_degrees(const int32_t *__restrict__ src, const int32_t *__restrict__ dst,
+                                                        int64_t n_hits, int64_t n_segments, int32_t *__restrict__ deg_in,
+                                                        int32_t *__restrict__ deg_out, int32_t *__restrict__ status)
+{
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n_segments) return;
+    const int s = src[j], d = dst[j];
+    if (seg_ok(s, d, n_hits)) {
+        atomicAdd(deg_in + d, 1);
+        atomicAdd(deg_out + s, 1);
+    } else if (!(s < 0 && d < 0)) {
+        atomicOr(status, 1);                           // an end outside [0, n_hits), or exactly one end negative
+    }
+}
+
+// inclusive scan of one value per thread over the workgroup (kBlock threads); returns the thread's inclusive sum,
+// *total = the workgroup's sum
+__device__ __forceinline__ int block_scan_incl(int v, int *total)
+{
+    __shared__ int wsum[kBlock / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(v, o);
+        if (lane >= o) v += u;
+    }
+    __syncthreads();                                   // (wsum of a previous call has been read)
+    if (lane == 63) wsum[w] = v;
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int i = 0; i < kBlock / 64; ++i) {
+        if (i < w) before += wsum[i];
+        all += wsum[i];
+    }
+    *total = all;
+    return v + before;
+}
+
+// one workgroup per array (blockIdx.x: 0 = in, 1 = out): ptr[0 .. n] = exclusive scan of deg[0 .. n)
+// (no __restrict__: the block sums of a large array are scanned in place)
+__global__ __launch_bounds__(kBlock) void k_csr_scan_one(const int32_t *deg2, int32_t *in_ptr, int32_t *out_ptr, int64_t n,
+                                                         int64_t stride)
+{
+    const int32_t *deg = deg2 + blockIdx.x * stride;
+    int32_t *ptr = blockIdx.x ? out_ptr : in_ptr;
+    int carry = 0;
+    for (int64_t base = 0; base < n; base += kScanTile) {
+        const int64_t i0 = base + (int64_t)threadIdx.x * kScanItems;
+        int v[kScanItems], sum = 0;
+#pragma unroll
+        for (int k = 0; k < kScanItems; ++k) {
+            v[k] = i0 + k < n ? deg[i0 + k] : 0;
+            sum += v[k];
+        }
+        int total;
+        int run = carry + block_scan_incl(sum, &total) - sum;
+#pragma unroll
+        for (int k = 0; k < kScanItems; ++k) {
+            if (i0 + k < n) ptr[i0 + k] = run;
+            run += v[k];
+        }
+        carry += total;
+    }
+    if (threadIdx.x == 0) ptr[n] = carry;
+}
+
+// large arrays, step 1: sums of the 2048-count blocks (grid: blocks x 2)
+__global__ __launch_bounds__(kBlock) void k_csr_scan_sums(const int32_t *__restrict__ deg2, int64_t n, int64_t stride,
+                                                          int32_t *__restrict__ sums2, int64_t n_blocks)
+{
+    const int32_t *deg = deg2 + blockIdx.y * stride;
+    const int64_t i0 = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) sum += i0 + k < n ? deg[i0 + k] : 0;
+    int total;
+    (void)block_scan_incl(sum, &total);
+    if (threadIdx.x == 0) sums2[blockIdx.y * (n_blocks + 1) + blockIdx.x] = total;
+}
+
+// step 3: every block rescans its counts from its offset (sums2 holds the exclusive scan of the block sums by now)
+__global__ __launch_bounds__(kBlock) void k_csr_scan_blocks(const int32_t *__restrict__ deg2, int64_t n, int64_t stride,
+                                                            const int32_t *__restrict__ sums2, int64_t n_blocks,
+                                                            int32_t *__restrict__ in_ptr, int32_t *__restrict__ out_ptr)
+{
+    const int32_t *deg = deg2 + blockIdx.y * stride;
+    int32_t *ptr = blockIdx.y ? out_ptr : in_ptr;
+    const int32_t *sums = sums2 + blockIdx.y * (n_blocks + 1);
+    const int64_t i0 = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    int v[kScanItems], sum = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        v[k] = i0 + k < n ? deg[i0 + k] : 0;
+        sum += v[k];
+    }
+    int total;
+    int run = sums[blockIdx.x] + block_scan_incl(sum, &total) - sum;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        if (i0 + k < n) ptr[i0 + k] = run;
+        run += v[k];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) ptr[n] = sums[n_blocks];
+}
+
+__global__ __launch_bounds__(kBlock) void k_csr_fill(const int32_t *__restrict__ src, const int32_t *__restrict__ dst,
+                                                     int64_t n_hits, int64_t n_segments, const int32_t *__restrict__ in_ptr,
+                                                     const int32_t *__restrict__ out_ptr, int32_t *__restrict__ deg_in,
+                                                     int32_t *__restrict__ deg_out, int32_t *__restrict__ tmp_in,
+                                                     int32_t *__restrict__ tmp_out)
+{
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n_segments) return;
+    const int s = src[j], d = dst[j];
+    if (!seg_ok(s, d, n_hits)) return;
+    tmp_in[in_ptr[d] + atomicSub(deg_in + d, 1) - 1] = (int)j;
+    tmp_out[out_ptr[s] + atomicSub(deg_out + s, 1) - 1] = (int)j;
+}
+
+__device__ __forceinline__ int rank_in(const int32_t *__restrict__ lst, int b, int e, int j)
+{
+    int r = 0;
+    int k = b;
+    for (; k + 4 <= e; k += 4) {                       // four independent loads in flight
+        const int a0 = lst[k], a1 = lst[k + 1], a2 = lst[k + 2], a3 = lst[k + 3];
+        r += (a0 < j) + (a1 < j) + (a2 < j) + (a3 < j);
+    }
+    for (; k < e; ++k) r += lst[k] < j;
+    return r;
+}
+
+__global__ __launch_bounds__(kBlock) void k_csr_rank(const int32_t *__restrict__ src, const int32_t *__restrict__ dst,
+                                                     int64_t n_hits, int64_t n_segments, const int32_t *__restrict__ in_ptr,
+                                                     const int32_t *__restrict__ out_ptr, const int32_t *__restrict__ tmp_in,
+                                                     const int32_t *__restrict__ tmp_out, int32_t *__restrict__ in_eid,
+                                                     int32_t *__restrict__ in_nbr, int32_t *__restrict__ out_eid,
+                                                     int32_t *__restrict__ out_nbr)
+{
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n_segments) return;
+    if (j >= in_ptr[n_hits]) {                         // the tail past the valid entries: defined, never walked
+        in_eid[j] = in_nbr[j] = out_eid[j] = out_nbr[j] = -1;
+    }
+    const int s = src[j], d = dst[j];
+    if (!seg_ok(s, d, n_hits)) return;
+    {
+        const int b = in_ptr[d];
+        const int slot = b + rank_in(tmp_in, b, in_ptr[d + 1], (int)j);
+        in_eid[slot] = (int)j;
+        in_nbr[slot] = s;
+    }
+    {
+        const int b = out_ptr[s];
+        const int slot = b + rank_in(tmp_out, b, out_ptr[s + 1], (int)j);
+        out_eid[slot] = (int)j;
+        out_nbr[slot] = d;
+    }
+}
+
+struct CsrWs {
+    int32_t *deg;            // [2][stride]  counts, then countdown cursors
+    int32_t *tmp_in, *tmp_out;   // [n_segments] each
+    int32_t *sums;           // [2][n_blocks + 1]
+    int64_t stride, n_blocks;
+    size_t bytes;
+};
+
+CsrWs carve_csr(char *base, int64_t n_hits, int64_t n_segments)
+{
+    CsrWs w;
+    w.stride = (n_hits + 63) & ~(int64_t)63;
+    w.n_blocks = (n_hits + kScanTile - 1) / kScanTile;
+    size_t off = 0;
+    auto take = [&](size_t n) { char *p = base ? base + off : nullptr; off += align256(n); return p; };
+    w.deg = reinterpret_cast<int32_t *>(take((size_t)2 * w.stride * sizeof(int32_t)));
+    w.tmp_in = reinterpret_cast<int32_t *>(take((size_t)n_segments * sizeof(int32_t)));
+    w.tmp_out = reinterpret_cast<int32_t *>(take((size_t)n_segments * sizeof(int32_t)));
+    w.sums = reinterpret_cast<int32_t *>(take((size_t)2 * (w.n_blocks + 1) * sizeof(int32_t)));
+    w.bytes = off + 256;
+    return w;
+}
+
+}  // namespace
+}  // namespace gnn
+
+using namespace gnn;
+
+extern "C" {
+
+size_t gnn_csr_build_workspace_bytes(int64_t n_hits, int64_t n_segments)
+{
+    if (n_hits < 0 || n_segments < 0) return 0;
+    return carve_csr(nullptr, n_hits, n_segments).bytes;
+}
+
+int gnn_csr_build(const int32_t *src, const int32_t *dst, int64_t n_hits, int64_t n_segments, int32_t *in_ptr,
+                  int32_t *in_eid, int32_t *in_nbr, int32_t *out_ptr, int32_t *out_eid, int32_t *out_nbr,
+                  int32_t *status, void *workspace, size_t workspace_bytes, void *stream)
+{
+    ProfChain chain_;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n_hits < 0 || n_segments < 0 || n_hits >= (int64_t)1 << 31 || n_segments >= (int64_t)1 << 31)
+        return fail(GNN_ERR_BADARG, "gnn_csr_build: sizes outside the int32 index range");
+    if (!in_ptr || !out_ptr || !status)
+        return fail(GNN_ERR_BADARG, "gnn_csr_build: output pointer missing");
+    if (n_segments > 0 && (!src || !dst || !in_eid || !in_nbr || !out_eid || !out_nbr))
+        return fail(GNN_ERR_BADARG, "gnn_csr_build: segment array missing");
+    const size_t need = gnn_csr_build_workspace_bytes(n_hits, n_segments);
+    if (!workspace || workspace_bytes < need) return fail(GNN_ERR_WORKSPACE, "workspace too small: need %zu bytes", need);
+    char *base = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    CsrWs w = carve_csr(base, n_hits, n_segments);
+    hipError_t err = hipMemsetAsync(status, 0, sizeof(int32_t), s);
+    if (err == hipSuccess && w.stride > 0) err = hipMemsetAsync(w.deg, 0, (size_t)2 * w.stride * sizeof(int32_t), s);
+    if (err != hipSuccess) return fail(-(int)err, "gnn_csr_build: memset failed: %s", hipGetErrorString(err));
+    const unsigned gseg = (unsigned)((n_segments + kBlock - 1) / kBlock);
+    if (n_segments > 0)
+        GNN_LAUNCH("k_csr_degrees", k_csr_degrees, gseg, kBlock, s, src, dst, n_hits, n_segments, w.deg, w.deg + w.stride,
+                   status);
+    if (n_hits <= kOneBlockMax) {
+        GNN_LAUNCH("k_csr_scan", k_csr_scan_one, 2, kBlock, s, w.deg, in_ptr, out_ptr, n_hits, w.stride);
+    } else {
+        const dim3 g((unsigned)w.n_blocks, 2);
+        GNN_LAUNCH("k_csr_scan_sums", k_csr_scan_sums, g, kBlock, s, w.deg, n_hits, w.stride, w.sums, w.n_blocks);
+        // the block sums of both arrays, scanned in place ([n_blocks + 1] each: the last entry = the total)
+        GNN_LAUNCH("k_csr_scan", k_csr_scan_one, 2, kBlock, s, w.sums, w.sums, w.sums + (w.n_blocks + 1), w.n_blocks,
+                   w.n_blocks + 1);
+        GNN_LAUNCH("k_csr_scan_blocks", k_csr_scan_blocks, g, kBlock, s, w.deg, n_hits, w.stride, w.sums, w.n_blocks, in_ptr,
+                   out_ptr);
+    }
+    if (n_segments > 0) {
+        GNN_LAUNCH("k_csr_fill", k_csr_fill, gseg, kBlock, s, src, dst, n_hits, n_segments, in_ptr, out_ptr, w.deg,
+                   w.deg + w.stride, w.tmp_in, w.tmp_out);
+        GNN_LAUNCH("k_csr_rank", k_csr_rank, gseg, kBlock, s, src, dst, n_hits, n_segments, in_ptr, out_ptr, w.tmp_in,
+                   w.tmp_out, in_eid, in_nbr, out_eid, out_nbr);
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -9,7 +9,8 @@ stored once, in index form, for a *block-diagonal batch* of G graphs:
     X        float32 [N, F]     hit features, graphs concatenated (global hit ids)
     src,dst  int32   [E]        start / end hit of every segment; -1 = padded column
     in_ptr   int32   [N+1]      CSR over segments ENDING at each hit   (rows of Ri)
-    in_eid   int32   [E_valid]  segment ids, grouped by end hit, ascending id
+    in_eid   int32   [E_valid]  segment ids, grouped by end hit, ascending id (built on the GPU: [E], the
+                                entries from in_ptr[N] on are -1)
     in_nbr   int32   [E_valid]  = src[in_eid]   (the hit at the other end)
     out_ptr / out_eid / out_nbr the same for segments STARTING at each hit (rows of Ro),
                                 out_nbr = dst[out_eid]
@@ -99,10 +100,23 @@ class HitGraphBatch:
 
     _CSR_NAMES = ("in_ptr", "in_eid", "in_nbr", "out_ptr", "out_eid", "out_nbr")
 
+    # Device-built lists: False = trust the endpoints (they were checked where the batch was made: on the host in
+    # the constructor, by gnn_dense_to_index's flags for dense input; the builder skips malformed segments either
+    # way), True = read the builder's status word back - 4 bytes and one synchronisation per batch.
+    validate_csr = False
+
     def _ensure_csr(self):
         if self._csr is None:
             n = self.n_hits
-            if self.X.is_cuda:       # sorts on the GPU: 25.6 M segments in tens of ms, not 2 s
+            if self.X.is_cuda and os.environ.get("GNN_CSR_BUILDER", "hip") == "hip":
+                # gnn_csr_build (csrc/csr_build.hip): counting sort + rank, a handful of launches, no read-back;
+                # eid / nbr arrays keep all n_segments entries (the lists, then -1)
+                from . import _lib
+                parts = _lib.csr_build(self.src, self.dst, n)
+                if self.validate_csr and int(parts[6].item()) & 1:
+                    raise ValueError("segment endpoint out of range, or a segment with exactly one negative end")
+                self._csr, self._csr_status = parts[:6], parts[6]
+            elif self.X.is_cuda:     # torch ops (stable sorts on the GPU; GNN_CSR_BUILDER=torch): A / B runs
                 self._csr = _csr_by_device(self.dst, self.src, n) + _csr_by_device(self.src, self.dst, n)
             else:
                 src, dst = self._src_host, self._dst_host
@@ -225,8 +239,11 @@ class HitGraphBatch:
                 from . import _lib
                 if int(np.diff(sp).max(initial=0)) > _lib.EVENTS_MAX_SEGMENTS:
                     ok = False
-            if ok and self.n_segments:
-                src, dst = self.src.cpu().numpy(), self.dst.cpu().numpy()
+            if ok and self.n_segments and self.n_graphs > 1:
+                # (one graph: its endpoints were range-checked where the batch was made - nothing left to check;
+                # several: the host copies the constructor kept, else one copy back from the device)
+                src = self._src_host if self._src_host is not None else self.src.cpu().numpy()
+                dst = self._dst_host if self._dst_host is not None else self.dst.cpu().numpy()
                 gseg = np.repeat(np.arange(self.n_graphs), np.diff(sp))
                 lo, hi = hp[:-1][gseg], hp[1:][gseg]
                 pad = src < 0
@@ -234,15 +251,21 @@ class HitGraphBatch:
             lay = None
             if ok:
                 lay = _EventLayout()
-                lay.hit_ptr = torch.from_numpy(hp.astype(_I32))
-                lay.seg_ptr = torch.from_numpy(sp.astype(_I32))
+                both = torch.from_numpy(np.stack([hp, sp]).astype(_I32))     # one upload for the two pointers
+                lay._both = both
+                lay.hit_ptr, lay.seg_ptr = both[0], both[1]
                 lay.max_hits = int(np.diff(hp).max(initial=0))
                 lay.max_segments = int(np.diff(sp).max(initial=0))
             self._event = (lay,)
         lay = self._event[0]
         if lay is not None and lay.hit_ptr.device != self.X.device:
-            lay.hit_ptr = lay.hit_ptr.to(self.X.device)
-            lay.seg_ptr = lay.seg_ptr.to(self.X.device)
+            both = getattr(lay, "_both", None)
+            if both is not None:
+                both = lay._both = both.to(self.X.device)
+                lay.hit_ptr, lay.seg_ptr = both[0], both[1]
+            else:
+                lay.hit_ptr = lay.hit_ptr.to(self.X.device)
+                lay.seg_ptr = lay.seg_ptr.to(self.X.device)
         return lay
 
     # -- constructors ------------------------------------------------------------------

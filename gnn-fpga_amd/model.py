@@ -224,6 +224,16 @@ def compact_dead_units(weights, F, D, allowed_dims):
 class SegmentClassifier(nn.Module):
     """Segment classification GNN (reference gnn/model.py:127-156), HIP forward."""
 
+    # Inference route of batches too large for the one-launch kernels (a class attribute: set it on the class or
+    # on one model).  True = the fused tile pipeline; the plan is built at the first forward of a batch (0.6 ms for
+    # one 100k-segment graph, 5.7 ms for 256 of them).  False = the per-module kernels (one per reference module,
+    # segment lists by gnn_csr_build).  "auto" (default) = the fused pipeline for a batch that carries a plan of
+    # this width already (batch.build_plan) or is seen for the second time, the per-module kernels for the FIRST
+    # forward of a never-seen batch: a stream of never-repeated graphs (trigger-style use, gnn/Inference.ipynb
+    # cell 3) never pays a plan.  The two routes sum in different orders (scores differ by ~1e-7).
+    use_plan = "auto"
+    first_forward_max_segments = 4_000_000      # "auto": larger never-seen batches build their plan at once
+
     def __init__(self, input_dim=2, hidden_dim=8, n_iters=3, hidden_activation=nn.Tanh,
                  masks_e=None, masks_n=None):
         super(SegmentClassifier, self).__init__()
@@ -238,7 +248,6 @@ class SegmentClassifier(nn.Module):
         self.node_network = NodeNetwork(input_dim + hidden_dim, hidden_dim,
                                         hidden_activation, masks_n)
         self._workspace = None
-        self.use_plan = True      # False: per-module CSR kernels instead of the fused pipeline
         self.use_events = True    # batches of small graphs: whole forward in one launch
         # training on a batch's level-ordered twin (autograd.training_batch): "auto" (default) = from the
         # second time the same batch object is trained on - a stream of never-repeated batches (the
@@ -262,10 +271,19 @@ class SegmentClassifier(nn.Module):
 
     def _param_key(self):
         """Changes whenever a parameter is replaced, updated in place, moved, or (un)masked."""
-        layers = [self.edge_network.network[0], self.edge_network.network[2],
-                  self.node_network.network[0], self.node_network.network[2]]
-        return (tuple((id(p), p._version, p.data_ptr()) for p in self.parameters()) +
-                tuple((l.mask_flag, id(l.mask)) for l in layers))
+        # (the five layers' own parameter dicts, looked up afresh - a replaced Parameter is seen; walking
+        # self.parameters() instead costs 50 us per forward, a quarter of a single-graph call)
+        lay = self.__dict__.get("_layers5")
+        if lay is None:
+            lay = self.__dict__["_layers5"] = (self.input_network[0], self.edge_network.network[0],
+                                              self.edge_network.network[2], self.node_network.network[0],
+                                              self.node_network.network[2])
+        key = []
+        for l in lay:
+            for p in l._parameters.values():
+                if p is not None:
+                    key.append((id(p), p._version, p.data_ptr()))
+        return tuple(key) + tuple((l.mask_flag, id(l.mask)) for l in lay[1:])
 
     def _cached_weights(self):
         """(weights, GnnParams, D_run): the tensors the inference kernels consume and the hidden_dim
@@ -344,11 +362,17 @@ class SegmentClassifier(nn.Module):
                 e = e.view(batch.dense_shape[0], batch.dense_shape[2])
             return e
         fused = not trace and self.use_plan and _lib.plan_shape_supported(F, D)
+        if fused and self.use_plan == "auto" and (batch.plan is None or batch.plan.hidden_dim != D):
+            seen = getattr(batch, "_forwards", 0)
+            batch._forwards = seen + 1
+            # first forward of a never-seen batch: no plan yet - up to the size where the plan pays for itself
+            # at once (tools/fresh_probe.py: 32 c3 graphs 1.22 ms against 1.72 with the plan, 256 graphs 9.5
+            # against 6.7: the crossover is near 6.5 M segments)
+            fused = seen > 0 or batch.n_segments > self.first_forward_max_segments
         if fused:
             plan = batch.build_plan(D)
             need = _lib.plan_workspace_bytes(plan.n_pad, plan.n_segments, F, D)
         else:
-            D = self.hidden_dim
             need = _lib.workspace_bytes(batch.n_hits, batch.n_segments, F, D)
         if (self._workspace is None or self._workspace.numel() < need or
                 self._workspace.device != batch.X.device):
@@ -360,7 +384,9 @@ class SegmentClassifier(nn.Module):
                                                   (_lib.GNN_FLAG_BF16_MLP if self.mlp_bf16 else 0)),
                                            params=pstruct)
         else:         # CSR kernels, one per reference module (csrc/gnn_kernels.hip); traces
-            res = _lib.segclf_forward(batch, self.effective_weights(), F, D, self.n_iters,
+            # (inference: the cached - possibly compacted - weights at the width they run at; traces: full width)
+            res = _lib.segclf_forward(batch, self.effective_weights() if trace else weights, F,
+                                      self.hidden_dim if trace else D, self.n_iters,
                                       workspace=self._workspace, trace=trace)
         e = res[0] if trace else res
         if batch.dense_shape:

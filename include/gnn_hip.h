@@ -319,6 +319,21 @@ int gnn_plan_build_fill(const float *X, int32_t F, const int32_t *src, const int
                         int64_t n_segments, int32_t chunk_segments, const gnn_plan_sizes_t *sizes,
                         void *workspace, size_t workspace_bytes, const gnn_plan_out_t *out, void *stream);
 
+/* ---- the two segment lists, built on the GPU (csrc/csr_build.hip; ABI 4) --------------------------
+ * What gnn_graph_t's in_ptr / in_eid / in_nbr and out_ptr / out_eid / out_nbr hold, from the index form: for every
+ * hit the ids of the segments that end (start) there, ASCENDING - the reference's on-disk order, `Ri.nonzero()` /
+ * `Ro.nonzero()` row-major (gnn/graph.py:20-26), and the order its bmm against Ri / Ro sums in
+ * (gnn/model.py:114-119).  Replaces two stable sorts and a read-back per never-seen batch.
+ * src / dst [n_segments] int32 (-1 / -1 = padded segment, left out of both lists).  Written: in_ptr, out_ptr
+ * [n_hits + 1]; in_eid, in_nbr, out_eid, out_nbr [n_segments] - the first in_ptr[n_hits] (= out_ptr[n_hits]) entries
+ * are the lists, the rest is -1; status [1] (device): bit 0 = a segment with an end outside [0, n_hits) or with
+ * exactly one negative end (skipped like a padded one; the caller must raise).  The arrays are the same in every
+ * run (no dependence on the order atomics arrive in).  Asynchronous on `stream`; no host synchronisation. */
+size_t gnn_csr_build_workspace_bytes(int64_t n_hits, int64_t n_segments);
+int gnn_csr_build(const int32_t *src, const int32_t *dst, int64_t n_hits, int64_t n_segments, int32_t *in_ptr,
+                  int32_t *in_eid, int32_t *in_nbr, int32_t *out_ptr, int32_t *out_eid, int32_t *out_nbr,
+                  int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
+
 /* bound_out (device, 1 float) = the left side of the GNN_FLAG_EXP_PRODUCT condition;
  * x_absmax (device, [F]) = per-feature max |X|.  Asynchronous on `stream`. */
 int gnn_exp_product_bound(const gnn_params_t *p, const float *x_absmax, float *bound_out,

@@ -88,8 +88,9 @@ def test_dense_inputs_are_converted_on_the_device(hip):
     for k in ("X", "src", "dst"):
         assert torch.equal(getattr(host, k), getattr(dev, k).cpu()), k
     assert np.array_equal(host.hit_ptr, dev.hit_ptr) and np.array_equal(host.seg_ptr, dev.seg_ptr)
-    for name in HitGraphBatch._CSR_NAMES:                       # CSRs built on the device from it
-        assert torch.equal(getattr(host, name), getattr(dev, name).cpu()), name
+    for name in HitGraphBatch._CSR_NAMES:                       # segment lists built on the device from it
+        a, c = getattr(host, name), getattr(dev, name).cpu()    # (gnn_csr_build keeps [E] entries: the lists, then -1)
+        assert torch.equal(a, c[:a.numel()]) and bool((c[a.numel():] == -1).all()), name
     lay = dev.event_layout()
     assert lay.max_hits == Nmax and lay.max_segments == Emax
     bad = Ri.clone()

@@ -1119,20 +1119,116 @@ def test_plan_built_on_the_gpu_equals_the_host_plan(hip, lim_over):
         del os.environ["GNN_PLAN_BUILDER"]
 
 
-def test_csr_built_on_the_gpu_equals_the_host_csr(hip):
-    """The two CSRs of the per-module / training kernels are built where the batch lives: the
-    torch version (stable sort on the GPU) must give the host version's arrays, padded segments
-    (src = dst = -1) left out of both."""
-    graphs = [synth.layered_graph(2000, 15000, 3, seed=400 + s) for s in range(6)]
+def _host_and_device_twins(graphs, knock_out=13):
     b = HitGraphBatch.from_graphs(graphs)
     src, dst = b.src.numpy().copy(), b.dst.numpy().copy()
-    src[3::13] = -1
-    dst[3::13] = -1
+    if knock_out:
+        src[3::knock_out] = -1
+        dst[3::knock_out] = -1
     host = HitGraphBatch(b.X.numpy(), src, dst, hit_ptr=b.hit_ptr, seg_ptr=b.seg_ptr)
     dev = HitGraphBatch(b.X.numpy(), src, dst, hit_ptr=b.hit_ptr, seg_ptr=b.seg_ptr).cuda()
+    return host, dev
+
+
+@pytest.mark.parametrize("builder", ["hip", "torch"])
+@pytest.mark.parametrize("case", ["ragged", "one_graph", "many_hits", "no_segments", "all_padded", "hub"])
+def test_csr_built_on_the_gpu_equals_the_host_csr(hip, builder, case, monkeypatch):
+    """The two segment lists of the per-module / training kernels are built where the batch lives - by
+    gnn_csr_build (counting sort + rank: csrc/csr_build.hip) or, GNN_CSR_BUILDER=torch, by stable torch sorts - and
+    must be the host version's arrays entry for entry (= the reference's on-disk order, `Ri.nonzero()` row-major,
+    gnn/graph.py:20-26): padded segments (src = dst = -1) left out of both; the HIP builder keeps n_segments
+    entries per array, -1 past the lists.  Cases: ragged graphs, one graph, more hits than one scan workgroup takes
+    (block sums path), a batch without segments, only padded segments, one hit with 3000 segments."""
+    monkeypatch.setenv("GNN_CSR_BUILDER", builder)
+    if case == "ragged":
+        graphs = [synth.layered_graph(2000, 15000, 3, seed=400 + s) for s in range(6)] + \
+                 [synth.layered_graph(5, 4, 3, n_layers=2, seed=1), synth.layered_graph(30, 0, 3, n_layers=3, seed=2)]
+        host, dev = _host_and_device_twins(graphs)
+    elif case == "one_graph":
+        host, dev = _host_and_device_twins([synth.layered_graph(10000, 100000, 3, seed=7)], knock_out=0)
+    elif case == "many_hits":
+        host, dev = _host_and_device_twins([synth.layered_graph(300000, 400000, 2, seed=8)], knock_out=17)
+    elif case == "no_segments":
+        host, dev = _host_and_device_twins([synth.layered_graph(40, 0, 3, n_layers=3, seed=3)], knock_out=0)
+    elif case == "all_padded":
+        g = synth.layered_graph(50, 60, 3, n_layers=4, seed=4)
+        X = np.asarray(g.X, dtype=np.float32)
+        pad = np.full(60, -1, dtype=np.int32)
+        host, dev = HitGraphBatch(X, pad, pad), HitGraphBatch(X, pad, pad).cuda()
+    else:
+        rng = np.random.default_rng(5)
+        X = rng.standard_normal((4000, 3)).astype(np.float32)
+        src = np.concatenate([np.full(3000, 17), rng.integers(0, 4000, 5000)]).astype(np.int32)
+        dst = np.concatenate([rng.integers(0, 4000, 3000), np.full(2500, 99), rng.integers(0, 4000, 2500)]).astype(np.int32)
+        o = rng.permutation(8000)
+        host, dev = HitGraphBatch(X, src[o], dst[o]), HitGraphBatch(X, src[o], dst[o]).cuda()
+    n_valid = int(host.in_ptr[-1])
     for name in HitGraphBatch._CSR_NAMES:
         a, c = getattr(host, name), getattr(dev, name)
-        assert c.is_cuda and a.dtype == c.dtype and torch.equal(a, c.cpu()), name
+        assert c.is_cuda and a.dtype == c.dtype, name
+        c = c.cpu()
+        if name.endswith("ptr") or builder == "torch":
+            assert torch.equal(a, c), name
+        else:
+            assert c.numel() == host.n_segments and torch.equal(a, c[:n_valid]) and bool((c[n_valid:] == -1).all()), name
+
+
+def test_csr_builder_reports_malformed_endpoints(hip):
+    """gnn_csr_build skips a segment with an end outside [0, n_hits) or with exactly one negative end (no
+    out-of-range atomic or store) and says so in its status word; HitGraphBatch.validate_csr = True turns that into
+    the ValueError the host constructor raises for the same arrays."""
+    from gnn_fpga_amd import _lib
+    g = synth.layered_graph(500, 3000, 3, seed=11)
+    b = HitGraphBatch.from_graphs([g]).cuda()
+    good = _lib.csr_build(b.src, b.dst, b.n_hits)
+    assert int(good[6].item()) == 0
+    src, dst = b.src.clone(), b.dst.clone()
+    src[5] = 500                # one past the last hit
+    dst[9] = -1                 # exactly one end negative
+    src[11] = dst[11] = -1      # a padded segment: fine
+    bad = _lib.csr_build(src, dst, b.n_hits)
+    assert int(bad[6].item()) & 1
+    assert int(bad[0][-1]) == int(bad[3][-1]) == 3000 - 3            # the three segments are in neither list
+    eids = set(bad[1][:2997].tolist())
+    assert not eids & {5, 9, 11} and len(eids) == 2997
+    b2 = HitGraphBatch.from_graphs([g]).cuda()
+    b2.src, b2.validate_csr = src, True
+    with pytest.raises(ValueError):
+        b2.in_ptr
+
+
+def test_first_forward_of_a_never_seen_batch_needs_no_plan(hip):
+    """model.use_plan = "auto" (default): the FIRST inference forward of a never-seen detector-size batch runs the
+    per-module kernels on gnn_csr_build's lists (no plan: trigger-style use, gnn/Inference.ipynb cell 3), the second
+    forward of the same batch builds the plan and runs the fused tile kernels, a batch that brings a plan runs them
+    at once; all three agree within the score tolerance."""
+    from gnn_fpga_amd.model import SegmentClassifier
+    torch.manual_seed(3)
+    m = SegmentClassifier(input_dim=3, hidden_dim=8, n_iters=3).cuda().eval()
+    import conftest
+    assert conftest.DEFAULT_USE_PLAN == "auto"          # what a user gets (the test session runs with True)
+    m.use_plan = "auto"
+    g = synth.layered_graph(10000, 100000, 3, seed=21)
+    b = HitGraphBatch.from_graphs([g]).cuda()
+    with torch.no_grad():
+        with hip.profile(64) as p1:
+            e1 = m(b)
+        names1 = {k for k, _ in p1.records}
+        assert b.plan is None and "k_node" in names1 and "k_csr_rank" in names1 and not any("k_iter" in k for k in names1)
+        with hip.profile(64) as p2:
+            e2 = m(b)
+        names2 = {k for k, _ in p2.records}
+        assert b.plan is not None and any("k_iter" in k for k in names2) and "k_node" not in names2
+        b3 = HitGraphBatch.from_graphs([g]).cuda()
+        b3.build_plan(8)
+        with hip.profile(64) as p3:
+            e3 = m(b3)
+        assert any("k_iter" in k for k, _ in p3.records)
+    assert (e1 - e2).abs().max().item() < 1e-5 and torch.equal(e2, e3)
+    m.use_plan = True
+    b4 = HitGraphBatch.from_graphs([g]).cuda()
+    with torch.no_grad():
+        assert torch.equal(m(b4), e2) and b4.plan is not None
 
 
 @pytest.mark.parametrize("F,D,T", [(11, 8, 3), (3, 8, 2), (2, 16, 1), (3, 4, 0)])
