@@ -1131,14 +1131,16 @@ def _host_and_device_twins(graphs, knock_out=13):
 
 
 @pytest.mark.parametrize("builder", ["hip", "torch"])
-@pytest.mark.parametrize("case", ["ragged", "one_graph", "many_hits", "no_segments", "all_padded", "hub"])
+@pytest.mark.parametrize("case", ["ragged", "one_graph", "many_hits", "no_segments", "all_padded", "hub", "big_batch",
+                                  "big_wide"])
 def test_csr_built_on_the_gpu_equals_the_host_csr(hip, builder, case, monkeypatch):
     """The two segment lists of the per-module / training kernels are built where the batch lives - by
     gnn_csr_build (counting sort + rank: csrc/csr_build.hip) or, GNN_CSR_BUILDER=torch, by stable torch sorts - and
     must be the host version's arrays entry for entry (= the reference's on-disk order, `Ri.nonzero()` row-major,
     gnn/graph.py:20-26): padded segments (src = dst = -1) left out of both; the HIP builder keeps n_segments
     entries per array, -1 past the lists.  Cases: ragged graphs, one graph, more hits than one scan workgroup takes
-    (block sums path), a batch without segments, only padded segments, one hit with 3000 segments."""
+    (block sums path), a batch without segments, only padded segments, one hit with 3000 segments, and batches of
+    more than a million segments (LDS-private counting) with narrow and with wide endpoint ranges."""
     monkeypatch.setenv("GNN_CSR_BUILDER", builder)
     if case == "ragged":
         graphs = [synth.layered_graph(2000, 15000, 3, seed=400 + s) for s in range(6)] + \
@@ -1148,6 +1150,11 @@ def test_csr_built_on_the_gpu_equals_the_host_csr(hip, builder, case, monkeypatc
         host, dev = _host_and_device_twins([synth.layered_graph(10000, 100000, 3, seed=7)], knock_out=0)
     elif case == "many_hits":
         host, dev = _host_and_device_twins([synth.layered_graph(300000, 400000, 2, seed=8)], knock_out=17)
+    elif case == "big_batch":        # >= 1 M segments: LDS-private counting per 16 k segments (k_csr_*_wg), narrow ranges
+        host, dev = _host_and_device_twins([synth.layered_graph(9000 + 100 * s, 90000 + 1500 * s, 3, seed=70 + s)
+                                            for s in range(13)], knock_out=29)
+    elif case == "big_wide":         # the same kernels where a workgroup's endpoints span > 16 k hits: global claims
+        host, dev = _host_and_device_twins([synth.layered_graph(200000, 1100000, 2, seed=9)], knock_out=31)
     elif case == "no_segments":
         host, dev = _host_and_device_twins([synth.layered_graph(40, 0, 3, n_layers=3, seed=3)], knock_out=0)
     elif case == "all_padded":
