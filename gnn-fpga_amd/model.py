@@ -263,6 +263,16 @@ class SegmentClassifier(nn.Module):
         self._xp_cache = None     # (key, flag): the last exp-product decision (kept on the plan)
         self._w_cache = None      # (key, weights, GnnParams, D_run, info): rebuilt when a parameter changes
 
+    def __getstate__(self):
+        """copy.deepcopy(model) (gnn/estimator_maskedlinear.py:83, `load_weights`) and torch.save(model) go through
+        here: the caches - device workspace, the packed GnnParams (a ctypes struct of raw device pointers, which can be
+        neither pickled nor shared with a copy whose tensors live elsewhere), route decisions - stay behind and are
+        rebuilt by the copy's first forward."""
+        st = self.__dict__.copy()
+        st["_workspace"] = st["_xp_cache"] = st["_w_cache"] = None
+        st.pop("_layers5", None)
+        return st
+
     def effective_weights(self):
         """The ten tensors the kernels consume, in state_dict order, masks applied."""
         lin = self.input_network[0]

@@ -1301,3 +1301,24 @@ def test_one_launch_training_forward_keeps_the_same_tensors(hip):
     e2, H2, Q2 = _lib.segclf_forward_train(b, w, 11, 8, 3, layout=b.event_layout())
     assert Q1.shape == (3, b.n_hits, 8) and Q2.numel() == 0
     assert torch.equal(e1, e2) and torch.equal(H1, H2)
+
+
+def test_model_deep_copies_after_a_forward(hip):
+    """gnn/estimator_maskedlinear.py:83 deep-copies the model it holds: after forwards on every route (caches hold
+    a workspace, a packed-parameter struct of device pointers, an exp-product decision) the copy must come out with
+    its own parameters, no caches, and the same scores; editing the copy leaves the original alone."""
+    import copy
+    from gnn_fpga_amd.model import SegmentClassifier
+    torch.manual_seed(5)
+    m = SegmentClassifier(input_dim=3, hidden_dim=8, n_iters=2).cuda().eval()
+    b = HitGraphBatch.from_graphs([synth.layered_graph(3000, 20000, 3, seed=31)]).cuda()
+    with torch.no_grad():
+        e = m(b)
+        assert m._w_cache is not None and m._workspace is not None
+        c = copy.deepcopy(m)
+        assert c._w_cache is None and c._workspace is None
+        assert all(a.data_ptr() != p.data_ptr() for a, p in zip(c.parameters(), m.parameters()))
+        assert torch.equal(c(b), e)
+        for p in c.parameters():
+            p.mul_(0.5)
+        assert not torch.equal(c(b), e) and torch.equal(m(b), e)

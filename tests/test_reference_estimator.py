@@ -70,3 +70,51 @@ def test_reference_estimator_holds_the_dropin(ref, tmp_path):
         est.training_step([X, Ri, Ro], torch.from_numpy(g.y)[None])
     with pytest.raises(GnnHipError):
         est.model(HitGraphBatch.from_graphs([g]))
+
+
+def test_reference_pruning_estimator_deep_copies_and_reloads_the_dropin(tmp_path):
+    """gnn/estimator_maskedlinear.py:82-101 `load_weights` (the pruning notebooks' retraining step) deep-copies the
+    model, loads a checkpoint into the copy and assigns `weight.data = W * mask.data` layer by layer.  The drop-in must
+    survive that AFTER it has run a forward - its caches then hold a ctypes struct of device pointers, which neither
+    pickles nor deep-copies (simulated here: the build container has no GPU) - and must see the replaced `.data`."""
+    import copy
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    try:
+        import estimator_maskedlinear as ref_pruning
+    finally:
+        sys.path.remove(REF)
+    from gnn_fpga_amd import _lib
+    from gnn_fpga_amd.model import SegmentClassifier
+    torch.manual_seed(1)
+    D, C = 8, 11
+    me = [(torch.rand(D, 2 * C) > 0.4).float(), torch.ones(1, D)]
+    mn = [(torch.rand(D, 3 * C) > 0.4).float(), (torch.rand(D, D) > 0.4).float()]
+    m = SegmentClassifier(input_dim=3, hidden_dim=D, n_iters=2, masks_e=me, masks_n=mn)
+    with contextlib.redirect_stdout(io.StringIO()):
+        est = ref_pruning.Estimator(m, torch.nn.BCELoss(), opt="Adam", cuda=False)
+    # what a forward on the GPU leaves behind
+    key = m._param_key()
+    m._w_cache = (key, [p.detach() for p in m.parameters()], _lib.GnnParams(), D, None)
+    m._xp_cache = (key, 0)
+    c = copy.deepcopy(m)
+    assert c._w_cache is None and c._xp_cache is None and m._w_cache is not None
+    assert all(torch.equal(a, b) and a.data_ptr() != b.data_ptr() for a, b in zip(m.parameters(), c.parameters()))
+    # a dense checkpoint (trained without masks), reloaded into the masked model through the reference's own code
+    torch.manual_seed(2)
+    dense = SegmentClassifier(input_dim=3, hidden_dim=D, n_iters=2)
+    fn = str(tmp_path / "dense.pt")
+    torch.save({"state_dict": dense.state_dict()}, fn)
+    with contextlib.redirect_stdout(io.StringIO()):
+        est.load_weights(fn)
+    sd = dense.state_dict()
+    assert torch.equal(m.edge_network.network[0].weight.data, sd["edge_network.network.0.weight"] * me[0])
+    assert torch.equal(m.node_network.network[0].weight.data, sd["node_network.network.0.weight"] * mn[0])
+    assert torch.equal(m.node_network.network[2].weight.data, sd["node_network.network.2.weight"] * mn[1])
+    assert m._param_key() != key                      # the replaced .data is seen: the cached weights are rebuilt
+    # torch.save(model) / torch.load of the whole module, as notebooks do, drops the caches too
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    again = torch.load(buf, weights_only=False)       # (a file this test wrote itself)
+    assert again._w_cache is None and all(torch.equal(a, b) for a, b in zip(m.parameters(), again.parameters()))
