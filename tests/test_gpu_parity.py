@@ -1322,3 +1322,33 @@ def test_model_deep_copies_after_a_forward(hip):
         for p in c.parameters():
             p.mul_(0.5)
         assert not torch.equal(c(b), e) and torch.equal(m(b), e)
+
+
+@pytest.mark.parametrize("route", ["events", "plan", "modules"])
+def test_replaced_parameters_are_seen_like_in_the_pruning_notebooks(hip, route):
+    """gnn/MPNN_Seg_ACTS_maskedlinear.ipynb cell 34 / MPNN_Seg_ACTS.ipynb cell 33 prune by REPLACING the layers'
+    Parameter objects (`model.edge_network.network[0].weight = torch.nn.Parameter(weight * mask)`, all four layers)
+    between two evaluations: the inference caches (packed weights, exp-product decision) must follow - scores of the
+    second forward against the oracle on the pruned weights, on every route."""
+    from gnn_fpga_amd.model import SegmentClassifier
+    torch.manual_seed(11)
+    if route == "events":
+        graphs = [synth.layered_graph(60, 220, 3, n_layers=5, seed=80 + s) for s in range(6)]
+    else:
+        graphs = [synth.layered_graph(1500, 9000, 3, seed=80 + s) for s in range(2)]
+    b = HitGraphBatch.from_graphs(graphs).cuda()
+    m = SegmentClassifier(input_dim=3, hidden_dim=8, n_iters=2).cuda().eval()
+    m.use_events, m.use_plan = route == "events", route != "modules"
+    with torch.no_grad():
+        e0 = m(b)
+        for net in (m.edge_network, m.node_network):
+            for i in (0, 2):
+                w = net.network[i].weight
+                keep = (w.abs() > 0.5 * w.abs().mean()).float()      # |W| > threshold, the notebooks' rule (cell 21)
+                net.network[i].weight = torch.nn.Parameter(w * keep)
+        e1 = m(b)
+    assert not torch.equal(e0, e1)
+    params = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    for g, got in zip(graphs, b.split_scores(e1.cpu().numpy())):
+        ref = index_c.segment_classifier(g.X, g.src, g.dst, params, 2)
+        assert np.abs(got - ref).max() < TOL
