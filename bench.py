@@ -247,11 +247,29 @@ def fresh_single_graph(dev, model, graph, D, reps=5):
             t2 = time.perf_counter()
             if t2 - t0 < best[0]:
                 best = (t2 - t0, t1 - t0, t2 - t1)
+    # BASELINE configs[1]: one never-seen muon event (gnn/prepareMuonGraphs.py sizes, F = 11) to its scores - one
+    # k_event launch that builds the event's segment lists in LDS itself; median of 50 fresh batch objects
+    from gnn_fpga_amd import synth
+    from gnn_fpga_amd.model import SegmentClassifier
+    mm = SegmentClassifier(input_dim=11, hidden_dim=8, n_iters=3).to(dev).eval()
+    mg = synth.muon_graph(3)
+    ts = []
+    with torch.no_grad():
+        for _ in range(60):
+            b = HitGraphBatch.from_graphs([mg]).to(dev)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            mm(b)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+    muon_us = sorted(ts[10:])[25] * 1e6
     return {"ms": first * 1e3,
+            "c2_muon_event_us": muon_us,
             "plan_route": {"ms": best[0] * 1e3, "plan_ms": best[1] * 1e3, "forward_ms": best[2] * 1e3},
             "what": "one never-seen graph of the workload, resident on the device, to its scores: synchronised "
                     "wall clock, best of %d; ms = the default first-forward route (gnn_csr_build + per-module "
-                    "kernels, no plan), plan_route = plan build + fused forward" % reps}
+                    "kernels, no plan), plan_route = plan build + fused forward; c2_muon_event_us = one never-seen muon event "
+                    "(F = 11, ~20 hits) to its scores, one launch, median of 50" % reps}
 
 
 def free_port():
@@ -520,6 +538,19 @@ def run(args):
         elapsed = time_steps(step, args.steps, sync_all)
         # per-kernel durations (see event_medians): a pass of its own, first third dropped, medians
         seq = event_medians(lambda: model(batch), args.steps)
+        # A timed region that took much longer than its own kernels was not measuring them (seen once: 1.27 ms
+        # per step over kernels of 0.85 when another process had just left the box).  One more region of
+        # exactly K steps then, both on the record, the shorter one counts.  Every rank takes the same branch
+        # (the decision is all-reduced) because sync_all is a collective.
+        timed_regions = [elapsed]
+        retime = float(elapsed / args.steps * 1e3 > 1.15 * sum(ms for _, ms in seq) > 0.0)
+        if world > 1:
+            flag = torch.tensor([retime], dtype=torch.float64, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            retime = float(flag.item())
+        if retime:
+            timed_regions.append(time_steps(step, args.steps, sync_all))
+            elapsed = min(timed_regions)
         other = exact = None
         if args.workload == "c5":           # the other arithmetic beside it
             model.mlp_bf16 = not bf16
@@ -670,6 +701,7 @@ def run(args):
                 "other_kernels_ms": sum_k - sum(dom_pos),
                 "sum_kernel_ms": sum_k, "ms_per_step": ms_step,
                 "consistent": bool(sum_k <= 1.05 * ms_step),
+                "timed_regions_ms_per_step": [t / args.steps * 1e3 for t in timed_regions],
                 "timing": "HIP events on the launch stream, %d-step pass after the timed loop, first third "
                           "dropped, median per launch position" % min(max(3 * args.steps, 30), 600),
                 "traffic": traffic, "traffic_source": traffic_source,

@@ -227,6 +227,23 @@ def graph_struct(batch):
     return g
 
 
+def raw_graph_struct(batch):
+    """gnn_graph_t of a batch WITHOUT its segment lists (all six pointers NULL): what gnn_segclf_forward_events takes
+    for a never-seen batch - it builds the lists in LDS.  Cached on the batch like cached_graph_struct."""
+    dev = batch.X.device
+    g = getattr(batch, "_gstruct_raw", None)
+    if g is None or g._device != dev:
+        g = GnnGraph()
+        g.X = _dev(batch.X, torch.float32, "X")
+        g.src, g.dst = _dev(batch.src, torch.int32, "src"), _dev(batch.dst, torch.int32, "dst")
+        if batch.src.device != dev or batch.dst.device != dev:
+            raise GnnHipError("the arrays of a batch must live on one device")
+        g.n_hits, g.n_segments = batch.n_hits, batch.n_segments
+        g._device = dev
+        batch._gstruct_raw = g
+    return g
+
+
 def cached_graph_struct(batch):
     """graph_struct(batch), built once per (batch, device): the tensors of a batch are never
     replaced in place, so their device pointers are stable while the batch lives."""
@@ -374,12 +391,18 @@ def segclf_forward_events(batch, layout, weights, F, D, n_iters, out=None, param
     dev = batch.X.device
     if out is None:
         out = torch.empty(batch.n_segments, dtype=torch.float32, device=dev)
-    g = cached_graph_struct(batch)
+    # a batch nobody has asked the segment lists of (a never-seen event): the kernel builds them in LDS itself;
+    # one graph: no offset arrays either - nothing is prepared or uploaded for a single fresh event
+    g = cached_graph_struct(batch) if getattr(batch, "_csr", None) is not None else raw_graph_struct(batch)
     p = params if params is not None else params_struct(weights, F, D)
     with _on(batch.X, g, p) as st:
+        if batch.n_graphs == 1:
+            hp = sp = None
+        else:
+            hp, sp = layout.ptrs(dev)
+            hp, sp = _dev(hp, torch.int32, "hit_ptr"), _dev(sp, torch.int32, "seg_ptr")
         _check(load().gnn_segclf_forward_events(
-            ctypes.byref(g), ctypes.byref(p), _dev(layout.hit_ptr, torch.int32, "hit_ptr"),
-            _dev(layout.seg_ptr, torch.int32, "seg_ptr"), batch.n_graphs, layout.max_hits,
+            ctypes.byref(g), ctypes.byref(p), hp, sp, batch.n_graphs, layout.max_hits,
             layout.max_segments, n_iters, _dev(out, torch.float32, "out"), st))
     return out
 

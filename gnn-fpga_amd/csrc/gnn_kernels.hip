@@ -639,8 +639,9 @@ __global__ __launch_bounds__((EvCfg<D>::NT)) void k_event(
     extern __shared__ __attribute__((aligned(16))) float ev_lds[];
     float *H = ev_lds, *Hn = H + cap_hits * LDH, *PQ = Hn + cap_hits * LDH,
           *qb = PQ + cap_hits * 2 * D, *Mb = qb + cap_hits * D, *es = Mb + cap_hits * 2 * LDH;
-    const int h0 = hit_ptr[blockIdx.x], nh = hit_ptr[blockIdx.x + 1] - h0;
-    const int s0 = seg_ptr[blockIdx.x], ns = seg_ptr[blockIdx.x + 1] - s0;
+    // (hit_ptr == NULL: the batch is ONE graph - a never-seen single event needs no offset arrays on the device)
+    const int h0 = hit_ptr ? hit_ptr[blockIdx.x] : 0, nh = hit_ptr ? hit_ptr[blockIdx.x + 1] - h0 : (int)g.n_hits;
+    const int s0 = hit_ptr ? seg_ptr[blockIdx.x] : 0, ns = hit_ptr ? seg_ptr[blockIdx.x + 1] - s0 : (int)g.n_segments;
     const float *__restrict__ X = g.X;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // The weights (953 floats at F = 11, D = 8) are copied to LDS once and read from there with
@@ -666,7 +667,8 @@ __global__ __launch_bounds__((EvCfg<D>::NT)) void k_event(
     int32_t *ip = reinterpret_cast<int32_t *>(wl + W::total), *op = ip + cap_hits + 1,
             *ie = op + cap_hits + 1, *inb = ie + cap_segments, *oe = inb + cap_segments,
             *onb = oe + cap_segments, *sl = onb + cap_segments, *dl = sl + cap_segments;
-    if (nh > 0) {
+    const bool raw = g.in_ptr == nullptr;            // no segment lists from the caller: built below, in LDS
+    if (nh > 0 && !raw) {
         const int ib = g.in_ptr[h0], ob = g.out_ptr[h0];
         for (int n = threadIdx.x; n <= nh; n += NT) {
             ip[n] = g.in_ptr[h0 + n] - ib;
@@ -686,6 +688,65 @@ __global__ __launch_bounds__((EvCfg<D>::NT)) void k_event(
         const int sg = g.src[s0 + j];
         sl[j] = sg < 0 ? -1 : sg - h0;
         dl[j] = sg < 0 ? -1 : g.dst[s0 + j] - h0;
+    }
+    if (raw) {
+        // The two lists of a graph nobody has seen before (trigger-style use, gnn/Inference.ipynb cell 3: one event
+        // in, scores out), from its (src, dst) alone - what gnn_csr_build does with four launches, here inside the
+        // one launch: counts (LDS atomics) -> scan -> slots claimed in arrival order -> every entry's final slot
+        // = list base + the number of ids in its list below its own.  Ascending ids whatever the arrival order: the
+        // same lists as the caller-built ones, so the scores stay bit-identical to them (and to every other run).
+        int *cur_i = reinterpret_cast<int *>(Mb), *cur_o = cur_i + cap_hits, *tmp = reinterpret_cast<int *>(es);
+        for (int n = threadIdx.x; n <= nh; n += NT) ip[n] = op[n] = 0;
+        __syncthreads();
+        for (int j = threadIdx.x; j < ns; j += NT)
+            if (sl[j] >= 0) {
+                atomicAdd(&ip[dl[j] + 1], 1);
+                atomicAdd(&op[sl[j] + 1], 1);
+            }
+        __syncthreads();
+        if (wv < 2) {                                // wavefront 0 scans the in-counts, wavefront 1 the out-counts
+            int *ptr = wv ? op : ip;
+            const int per = (nh + 64) / 64, b = 1 + lane * per, e = min(b + per, nh + 1);
+            int sum = 0;
+            for (int n = b; n < e; ++n) sum += ptr[n];
+            int incl = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int u = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += u;
+            }
+            int run = incl - sum;
+            for (int n = b; n < e; ++n) {
+                run += ptr[n];
+                ptr[n] = run;
+            }
+        }
+        __syncthreads();
+        for (int n = threadIdx.x; n < nh; n += NT) { cur_i[n] = ip[n]; cur_o[n] = op[n]; }
+        __syncthreads();
+        for (int j = threadIdx.x; j < ns; j += NT)
+            if (sl[j] >= 0) tmp[atomicAdd(&cur_i[dl[j]], 1)] = j;
+        __syncthreads();
+        for (int j = threadIdx.x; j < ns; j += NT)
+            if (sl[j] >= 0) {
+                const int b = ip[dl[j]], e = ip[dl[j] + 1];
+                int r = 0;
+                for (int k = b; k < e; ++k) r += tmp[k] < j;
+                ie[b + r] = j;
+                inb[b + r] = sl[j];
+            }
+        __syncthreads();
+        for (int j = threadIdx.x; j < ns; j += NT)
+            if (sl[j] >= 0) tmp[atomicAdd(&cur_o[sl[j]], 1)] = j;
+        __syncthreads();
+        for (int j = threadIdx.x; j < ns; j += NT)
+            if (sl[j] >= 0) {
+                const int b = op[sl[j]], e = op[sl[j] + 1];
+                int r = 0;
+                for (int k = b; k < e; ++k) r += tmp[k] < j;
+                oe[b + r] = j;
+                onb[b + r] = dl[j];
+            }
     }
     // input rows: X into the skip columns of H (k_input), zero padding
     for (int i = threadIdx.x; i < nh * (LDH - D); i += NT) {
@@ -1064,9 +1125,14 @@ int gnn_segclf_forward_events(const gnn_graph_t *g, const gnn_params_t *p, const
 {
     if (!g || !p || n_iters < 0 || n_graphs < 0 || max_hits < 0 || max_segments < 0)
         return fail(GNN_ERR_BADARG, "gnn_segclf_forward_events: bad argument");
-    if (n_graphs > 0 && (!hit_ptr || !seg_ptr)) return fail(GNN_ERR_BADARG, "gnn_segclf_forward_events: graph offsets missing");
+    if (n_graphs > 1 && (!hit_ptr || !seg_ptr)) return fail(GNN_ERR_BADARG, "gnn_segclf_forward_events: graph offsets missing");
+    if (n_graphs == 1 && !hit_ptr != !seg_ptr) return fail(GNN_ERR_BADARG, "gnn_segclf_forward_events: one of hit_ptr / seg_ptr missing");
     if (g->n_segments > 0 && (!e_out || !g->src || !g->dst)) return fail(GNN_ERR_BADARG, "gnn_segclf_forward_events: segment arrays missing");
-    if (g->n_hits > 0 && (!g->X || !g->in_ptr || !g->out_ptr)) return fail(GNN_ERR_BADARG, "gnn_segclf_forward_events: hit arrays missing");
+    if (g->n_hits > 0 && !g->X) return fail(GNN_ERR_BADARG, "gnn_segclf_forward_events: hit features missing");
+    // the six list arrays come together or not at all (NULL: the kernel builds them in LDS)
+    if (g->in_ptr ? (!g->out_ptr || (g->n_segments > 0 && (!g->in_eid || !g->in_nbr || !g->out_eid || !g->out_nbr)))
+                  : (g->out_ptr || g->in_eid || g->in_nbr || g->out_eid || g->out_nbr) != 0)
+        return fail(GNN_ERR_BADARG, "gnn_segclf_forward_events: segment lists incomplete (all six arrays, or none)");
     if (!gnn_events_supported(p->F, p->D, max_hits, max_segments))
         return fail(GNN_ERR_UNSUPPORTED, "events of up to %d hits / %d segments do not fit one workgroup's LDS at input_dim=%d hidden_dim=%d",
                     max_hits, max_segments, p->F, p->D);

@@ -57,9 +57,25 @@ def _csr_by_device(key, other, n_hits):
 
 
 class _EventLayout:
-    """hit_ptr / seg_ptr [G+1] int32 tensors, max_hits, max_segments (HitGraphBatch.event_layout)."""
-    hit_ptr = seg_ptr = None
-    max_hits = max_segments = 0
+    """Per-graph offsets of a block-diagonal batch (HitGraphBatch.event_layout): max_hits, max_segments and - as
+    device tensors, uploaded at first use (one copy for both; a single-graph forward never needs them) -
+    hit_ptr / seg_ptr [G+1] int32."""
+
+    def __init__(self, hp, sp, device=None, sizes=None):
+        self._hp, self._sp = hp, sp
+        if sizes is None:
+            sizes = (int(np.diff(np.asarray(hp)).max(initial=0)), int(np.diff(np.asarray(sp)).max(initial=0)))
+        self.max_hits, self.max_segments = sizes
+        self._device, self._both = device, None
+
+    def ptrs(self, device=None):
+        device = self._device if device is None else device
+        if self._both is None or self._both.device != torch.device(device):
+            self._both = torch.from_numpy(np.stack([np.asarray(self._hp), np.asarray(self._sp)]).astype(_I32)).to(device)
+        return self._both[0], self._both[1]
+
+    hit_ptr = property(lambda self: self.ptrs()[0])
+    seg_ptr = property(lambda self: self.ptrs()[1])
 
 
 class HitGraphBatch:
@@ -227,6 +243,13 @@ class HitGraphBatch:
         not block-diagonal in the sense that kernel needs (every segment of graph i inside
         [seg_ptr[i], seg_ptr[i+1]) joins two hits of graph i; padded segments are fine).
         Checked once, on the host."""
+        if getattr(self, "_event", None) is None and self.n_graphs == 1:
+            # one graph (a single event through the model): nothing to check beyond what the constructor checked,
+            # and no numpy passes on the way to the first launch
+            hp, sp = self.hit_ptr, self.seg_ptr
+            ok = (hp[0] == 0 and sp[0] == 0 and hp[1] == self.n_hits and sp[1] == self.n_segments and
+                  self.n_hits < 2 ** 31 and self.n_segments < 2 ** 31)
+            self._event = (_EventLayout(hp, sp, sizes=(self.n_hits, self.n_segments)) if ok else None,)
         if getattr(self, "_event", None) is None:
             hp, sp = self.hit_ptr, self.seg_ptr
             ok = (hp[0] == 0 and sp[0] == 0 and hp[-1] == self.n_hits and
@@ -248,24 +271,10 @@ class HitGraphBatch:
                 lo, hi = hp[:-1][gseg], hp[1:][gseg]
                 pad = src < 0
                 ok = bool(np.all(pad | ((src >= lo) & (src < hi) & (dst >= lo) & (dst < hi))))
-            lay = None
-            if ok:
-                lay = _EventLayout()
-                both = torch.from_numpy(np.stack([hp, sp]).astype(_I32))     # one upload for the two pointers
-                lay._both = both
-                lay.hit_ptr, lay.seg_ptr = both[0], both[1]
-                lay.max_hits = int(np.diff(hp).max(initial=0))
-                lay.max_segments = int(np.diff(sp).max(initial=0))
-            self._event = (lay,)
+            self._event = (_EventLayout(hp, sp) if ok else None,)
         lay = self._event[0]
-        if lay is not None and lay.hit_ptr.device != self.X.device:
-            both = getattr(lay, "_both", None)
-            if both is not None:
-                both = lay._both = both.to(self.X.device)
-                lay.hit_ptr, lay.seg_ptr = both[0], both[1]
-            else:
-                lay.hit_ptr = lay.hit_ptr.to(self.X.device)
-                lay.seg_ptr = lay.seg_ptr.to(self.X.device)
+        if lay is not None:
+            lay._device = self.X.device          # where hit_ptr / seg_ptr are uploaded when somebody asks for them
         return lay
 
     # -- constructors ------------------------------------------------------------------
@@ -459,11 +468,7 @@ class HitGraphBatch:
                                          ).to(torch.float32).reshape(-1).to(Xt.device)
         self.plan = None
         # block-diagonal by construction: no host check of the endpoints
-        lay = _EventLayout()
-        lay.hit_ptr = torch.from_numpy(self.hit_ptr.astype(_I32)).to(Xt.device)
-        lay.seg_ptr = torch.from_numpy(self.seg_ptr.astype(_I32)).to(Xt.device)
-        lay.max_hits, lay.max_segments = N, E
-        self._event = (lay,)
+        self._event = (_EventLayout(self.hit_ptr, self.seg_ptr, Xt.device),)
         return self
 
     # -- device movement -----------------------------------------------------------------
@@ -477,6 +482,7 @@ class HitGraphBatch:
         if self.plan is not None:
             self.plan.to(device)
         self._gstruct = None         # cached C struct of raw device pointers (_lib.cached_graph_struct)
+        self._gstruct_raw = None
         self._twin = None            # the level-ordered twin lives on the old device
         return self
 

@@ -161,7 +161,12 @@ int gnn_segclf_forward(const gnn_graph_t *g, const gnn_params_t *p, int32_t n_it
  * are device arrays of the graphs' first hit / segment; every segment in
  * [seg_ptr[i], seg_ptr[i+1]) must join hits in [hit_ptr[i], hit_ptr[i+1]) (or be padded,
  * src = dst = -1); max_hits / max_segments bound the graph sizes.  Bit-identical to
- * gnn_segclf_forward.  gnn_events_supported: 1 if graphs of that size fit one workgroup. */
+ * gnn_segclf_forward.  gnn_events_supported: 1 if graphs of that size fit one workgroup.
+ * A never-seen event needs nothing prepared (gnn/Inference.ipynb cell 3: one graph in, scores out): with
+ * all six list pointers of `g` NULL the kernel builds the lists itself, in LDS, from (src, dst) - the lists
+ * gnn_csr_build makes, so the scores are the same bits -, and with n_graphs == 1 hit_ptr / seg_ptr may be
+ * NULL (the graph is [0, n_hits) x [0, n_segments)).  (gnn_segclf_forward only; the training entry points
+ * below take caller-built lists and offsets.) */
 int gnn_events_supported(int32_t F, int32_t D, int64_t max_hits, int64_t max_segments);
 int gnn_segclf_forward_events(const gnn_graph_t *g, const gnn_params_t *p, const int32_t *hit_ptr,
                               const int32_t *seg_ptr, int64_t n_graphs, int32_t max_hits,

@@ -278,9 +278,7 @@ def test_event_route_decision_is_pinned():
     from gnn_fpga_amd.hitgraph import _EventLayout
 
     def lay(h, s):
-        x = _EventLayout()
-        x.max_hits, x.max_segments = h, s
-        return x
+        return _EventLayout([0, h], [0, s])
 
     assert _lib.EVENTS_MAX_SEGMENTS == 1200
     assert _lib.events_preferred(3, 8, lay(150, 1000))

@@ -1352,3 +1352,49 @@ def test_replaced_parameters_are_seen_like_in_the_pruning_notebooks(hip, route):
     for g, got in zip(graphs, b.split_scores(e1.cpu().numpy())):
         ref = index_c.segment_classifier(g.X, g.src, g.dst, params, 2)
         assert np.abs(got - ref).max() < TOL
+
+
+@pytest.mark.parametrize("F,D,T", [(11, 8, 3), (3, 8, 2), (2, 16, 1), (3, 4, 3)])
+def test_event_kernel_builds_the_lists_of_a_never_seen_batch_itself(hip, F, D, T):
+    """gnn_segclf_forward_events with all six list pointers NULL (what the model passes for a batch whose lists nobody
+    has asked for): `k_event` builds them in LDS from (src, dst) - counts, scan, arrival-order slots, rank - and the
+    scores must be the SAME BITS as with gnn_csr_build's lists (same lists, same summation order), twice in a row
+    (no dependence on the order the LDS atomics arrive in); one graph also without offset arrays.  Muon events, graphs
+    close to the kernel's LDS limit, padded segments, isolated hits, a graph without segments, a 300-segment hub."""
+    from gnn_fpga_amd import _lib
+    from gnn_fpga_amd.model import SegmentClassifier
+    torch.manual_seed(F * D + T)
+    rng = np.random.default_rng(F + D)
+    if F == 11:
+        sets = [[synth.muon_graph(s) for s in range(64)], [synth.muon_graph(7)]]
+    else:
+        hub_src = np.concatenate([np.full(300, 5), rng.integers(0, 90, 200)]).astype(np.int32)
+        hub_dst = np.concatenate([rng.integers(0, 90, 300), np.full(150, 17), rng.integers(0, 90, 50)]).astype(np.int32)
+        hub = synth.HitGraph(rng.standard_normal((90, F)).astype(np.float32), hub_src, hub_dst,
+                             np.zeros(500, np.float32))
+        sets = [[synth.layered_graph(n, e, F, n_layers=L, seed=600 + i)
+                 for i, (n, e, L) in enumerate([(60, 200, 6), (3, 2, 2), (40, 0, 4), (150, 1100, 5), (2, 1, 2)])] + [hub],
+                [synth.layered_graph(140, 900, F, n_layers=6, seed=77)]]
+    m = SegmentClassifier(input_dim=F, hidden_dim=D, n_iters=T).cuda().eval()
+    w = [t.detach().contiguous() for t in m.effective_weights()]
+    for graphs in sets:
+        b = HitGraphBatch.from_graphs(graphs)
+        src, dst = b.src.numpy().copy(), b.dst.numpy().copy()
+        src[2::7] = -1
+        dst[2::7] = -1
+        mk = lambda: HitGraphBatch(b.X.numpy(), src, dst, hit_ptr=b.hit_ptr, seg_ptr=b.seg_ptr).cuda()  # noqa: E731
+        fresh, listed = mk(), mk()
+        lay = fresh.event_layout()
+        assert _lib.events_preferred(F, D, lay)
+        listed.in_ptr                                        # lists by gnn_csr_build
+        assert fresh._csr is None and listed._csr is not None
+        with hip.profile(16) as prof:
+            e_raw = _lib.segclf_forward_events(fresh, lay, w, F, D, T)
+        assert [k for k, _ in prof.records] == ["k_event"] and fresh._csr is None      # one launch, nothing else
+        e_raw2 = _lib.segclf_forward_events(fresh, lay, w, F, D, T)
+        e_listed = _lib.segclf_forward_events(listed, listed.event_layout(), w, F, D, T)
+        assert torch.equal(e_raw, e_listed) and torch.equal(e_raw, e_raw2)
+        # and through the model: the first forward of a never-seen batch of small graphs is that one launch
+        with torch.no_grad(), hip.profile(16) as prof:
+            e_model = m(mk())
+        assert [k for k, _ in prof.records] == ["k_event"] and torch.equal(e_model.reshape(-1), e_raw)
