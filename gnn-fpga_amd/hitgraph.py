@@ -179,6 +179,25 @@ class HitGraphBatch:
             self.plan.to(self.X.device)
         return self.plan
 
+    def with_features(self, X):
+        """The same graphs with other hit features (the same segments read out again: another calibration, another
+        feature scaling): a new batch object that SHARES the index arrays, the segment lists and - through
+        `SellPlan.with_features` - the structure of the execution plan; nothing is sorted or planned again."""
+        X = torch.as_tensor(X).to(torch.float32)
+        if tuple(X.shape) != tuple(self.X.shape):
+            raise ValueError("expected X of shape %s" % (tuple(self.X.shape),))
+        X = X.to(self.X.device).contiguous()
+        b = HitGraphBatch.__new__(HitGraphBatch)
+        b.__dict__.update(self.__dict__)
+        b.X = X
+        b._gstruct = b._gstruct_raw = None       # cached C structs hold the old X pointer
+        b._twin = None
+        b._forwards = getattr(self, "_forwards", 0)
+        if self.plan is not None:
+            b.plan = self.plan.with_features(X)
+            b.plan.hidden_dim = self.plan.hidden_dim
+        return b
+
     def level_ordered(self, hidden_dim=8):
         """The same batch in PLAN SPACE: hits numbered by the execution plan's padded ids - (graph, detector
         level), tiles, degree; `plan.n_pad` hits, the padding dummies without segments and with X = 0 - and

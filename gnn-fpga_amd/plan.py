@@ -429,6 +429,31 @@ class SellPlan:
         self._xp = None
         return self
 
+    def with_features(self, X):
+        """The same plan for OTHER hit features of the same graphs (a re-calibrated or re-scaled read-out of the same
+        segments): every structure array is shared, only the renumbered feature rows and their per-feature range
+        (the exp-product bound's input) are made anew - a handful of small torch ops instead of a plan build (5.7 ms
+        at c3 x 256).  X: [n_hits, F] in the caller's hit numbering, on this plan's device."""
+        import copy
+        X = torch.as_tensor(X).to(torch.float32)
+        if tuple(X.shape) != (self.n_hits, self.X.shape[1]):
+            raise ValueError("expected X of shape (%d, %d)" % (self.n_hits, self.X.shape[1]))
+        if X.device != self.X.device:
+            raise ValueError("X is on %s, the plan on %s" % (X.device, self.X.device))
+        new = copy.copy(self)
+        Xp = torch.zeros_like(self.X)
+        where = getattr(self, "_feature_rows", None)        # (structure: found once, shared by the copies)
+        if where is None or where[0].device != X.device:
+            perm = self.perm.to(torch.int64)                # padded id -> caller's hit id, -1 = dummy
+            slots = torch.nonzero(perm >= 0).reshape(-1)
+            where = self._feature_rows = (slots, perm[slots])
+        Xp[where[0]] = X[where[1]]
+        new.X = Xp
+        new.x_absmax = Xp.abs().max(dim=0).values if self.n_hits else torch.zeros_like(self.x_absmax)
+        new._struct = None               # cached C struct (raw pointers), exp-product decision: of the old features
+        new._xp = None
+        return new
+
     @property
     def device(self):
         return self.X.device

@@ -1398,3 +1398,28 @@ def test_event_kernel_builds_the_lists_of_a_never_seen_batch_itself(hip, F, D, T
         with torch.no_grad(), hip.profile(16) as prof:
             e_model = m(mk())
         assert [k for k, _ in prof.records] == ["k_event"] and torch.equal(e_model.reshape(-1), e_raw)
+
+
+def test_new_features_on_a_planned_batch_need_no_new_plan(hip):
+    """HitGraphBatch.with_features: other hit features on the same graphs reuse the plan's structure (VERDICT r2 item
+    4) - scores are the bits a from-scratch batch gives, no plan-builder kernel runs, the exp-product decision is
+    taken again for the new feature range (|X| x 400 makes the proven bound fail: exact kernels)."""
+    from gnn_fpga_amd.model import SegmentClassifier
+    torch.manual_seed(2)
+    graphs = [synth.layered_graph(4000, 30000, 3, seed=40 + s) for s in range(3)]
+    b = HitGraphBatch.from_graphs(graphs).cuda()
+    m = SegmentClassifier(input_dim=3, hidden_dim=8, n_iters=3).cuda().eval()
+    m.use_events = False
+    with torch.no_grad():
+        m(b)
+        assert m._xp_cache[1] == hip.GNN_FLAG_EXP_PRODUCT
+        for scale, want in ((0.5, hip.GNN_FLAG_EXP_PRODUCT), (400.0, 0)):
+            X2 = (torch.randn_like(b.X) * scale).contiguous()
+            with hip.profile(256) as prof:
+                b2 = b.with_features(X2)
+                e2 = m(b2)
+            assert not any(k.startswith("pb_") for k, _ in prof.records)          # no plan build
+            assert m._xp_cache[1] == want
+            ref = HitGraphBatch(X2.cpu().numpy(), b.src.cpu().numpy(), b.dst.cpu().numpy(),
+                                hit_ptr=b.hit_ptr, seg_ptr=b.seg_ptr).cuda()
+            assert torch.equal(e2, m(ref))

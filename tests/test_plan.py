@@ -211,3 +211,23 @@ def test_device_builder_builds_the_same_plan(case):
     lim = _lib.plan_limits(F, D)
     lim.update(lim_over)
     _same_plan(SellPlan(b, lim), DeviceSellPlan(b, lim))
+
+
+def test_plan_structure_is_reused_for_other_features():
+    """HitGraphBatch.with_features / SellPlan.with_features: the same graphs with other hit features share every
+    structure array of the plan (and the index arrays of the batch); the feature rows and their range come out as a
+    plan built from scratch has them."""
+    graphs = [synth.layered_graph(300, 1500, 3, seed=s) for s in range(3)] + [synth.layered_graph(7, 5, 3, n_layers=2, seed=9)]
+    b = HitGraphBatch.from_graphs(graphs)
+    lim = dict(tile_hits=64, iter_records=400, chunk_segments=500, edge_records=600)
+    b.build_plan(8, lim)
+    X2 = torch.randn_like(b.X) * 3.0
+    b2 = b.with_features(X2)
+    ref = HitGraphBatch(X2.numpy(), b.src.numpy(), b.dst.numpy(), hit_ptr=b.hit_ptr, seg_ptr=b.seg_ptr)
+    ref.build_plan(8, lim)
+    for k in ref.plan._TENSORS:
+        assert torch.equal(getattr(ref.plan, k), getattr(b2.plan, k)), k
+    assert b2.plan is not b.plan and b2.plan.in_nbr is b.plan.in_nbr and b2.src is b.src and b2.plan.hidden_dim == 8
+    assert torch.equal(b.plan.X[:b.plan.n_pad][b.plan.perm >= 0], b.X[b.plan.perm[b.plan.perm >= 0].long()])   # untouched
+    with pytest.raises(ValueError):
+        b.with_features(torch.zeros(5, 3))
