@@ -87,6 +87,9 @@ __device__ __forceinline__ void accum_outer(const float *L, const float *R, bool
                                             int ldg, int col0, float *gb, float *lds)
 {
     static_assert(NL + 1 < kOuterCap, "left factor too wide");
+#ifdef GNN_ABLATE_OUTER           // timing experiment (results invalid): what the outer-product sums cost
+    return;
+#endif
     // rows: L (NL) | this chunk of R (CH) | ones (the bias column, first chunk only)
     constexpr bool ONES = (C0 == 0);
     constexpr int ROOM = kOuterCap - NL - (ONES ? 1 : 0);
