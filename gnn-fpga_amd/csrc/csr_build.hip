@@ -50,11 +50,12 @@ __global__ __launch_bounds__(kBlock) void k_csr_degrees(const int32_t *__restric
     }
 }
 
-// inclusive scan of one value per thread over the workgroup (kBlock threads); returns the thread's inclusive sum,
+// inclusive scan of one value per thread over the workgroup (NT threads); returns the thread's inclusive sum,
 // *total = the workgroup's sum
+template <int NT = kBlock>
 __device__ __forceinline__ int block_scan_incl(int v, int *total)
 {
-    __shared__ int wsum[kBlock / 64];
+    __shared__ int wsum[NT / 64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -66,7 +67,7 @@ __device__ __forceinline__ int block_scan_incl(int v, int *total)
     __syncthreads();
     int before = 0, all = 0;
 #pragma unroll
-    for (int i = 0; i < kBlock / 64; ++i) {
+    for (int i = 0; i < NT / 64; ++i) {
         if (i < w) before += wsum[i];
         all += wsum[i];
     }
@@ -76,13 +77,15 @@ __device__ __forceinline__ int block_scan_incl(int v, int *total)
 
 // one workgroup per array (blockIdx.x: 0 = in, 1 = out): ptr[0 .. n] = exclusive scan of deg[0 .. n)
 // (no __restrict__: the block sums of a large array are scanned in place)
-__global__ __launch_bounds__(kBlock) void k_csr_scan_one(const int32_t *deg2, int32_t *in_ptr, int32_t *out_ptr, int64_t n,
-                                                         int64_t stride)
+// (1024 threads: a 10 k-hit graph is two passes of the loop, not five - this kernel is latency, not throughput)
+constexpr int kScanOneThreads = 1024, kScanOneTile = kScanOneThreads * kScanItems;
+__global__ __launch_bounds__(kScanOneThreads) void k_csr_scan_one(const int32_t *deg2, int32_t *in_ptr, int32_t *out_ptr,
+                                                                  int64_t n, int64_t stride)
 {
     const int32_t *deg = deg2 + blockIdx.x * stride;
     int32_t *ptr = blockIdx.x ? out_ptr : in_ptr;
     int carry = 0;
-    for (int64_t base = 0; base < n; base += kScanTile) {
+    for (int64_t base = 0; base < n; base += kScanOneTile) {
         const int64_t i0 = base + (int64_t)threadIdx.x * kScanItems;
         int v[kScanItems], sum = 0;
 #pragma unroll
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(kBlock) void k_csr_scan_one(const int32_t *deg2, in
             sum += v[k];
         }
         int total;
-        int run = carry + block_scan_incl(sum, &total) - sum;
+        int run = carry + block_scan_incl<kScanOneThreads>(sum, &total) - sum;
 #pragma unroll
         for (int k = 0; k < kScanItems; ++k) {
             if (i0 + k < n) ptr[i0 + k] = run;
@@ -293,10 +296,12 @@ __global__ __launch_bounds__(kBlock) void k_csr_rank(const int32_t *__restrict__
                                                      const int32_t *__restrict__ out_ptr, const int32_t *__restrict__ tmp_in,
                                                      const int32_t *__restrict__ tmp_out, int32_t *__restrict__ in_eid,
                                                      int32_t *__restrict__ in_nbr, int32_t *__restrict__ out_eid,
-                                                     int32_t *__restrict__ out_nbr)
+                                                     int32_t *__restrict__ out_nbr, const int32_t *__restrict__ bad_word,
+                                                     int32_t *__restrict__ status)
 {
     const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (j >= n_segments) return;
+    if (j == 0) *status = *bad_word;                   // (the degrees pass collected it next to the counts: one memset)
     if (j >= in_ptr[n_hits]) {                         // the tail past the valid entries: defined, never walked
         in_eid[j] = in_nbr[j] = out_eid[j] = out_nbr[j] = -1;
     }
@@ -317,6 +322,7 @@ __global__ __launch_bounds__(kBlock) void k_csr_rank(const int32_t *__restrict__
 }
 
 struct CsrWs {
+    int32_t *bad;            // the malformed-segment flag of the degrees pass (copied to the caller's status at the end)
     int32_t *deg;            // [2][stride]  counts, then countdown cursors
     int32_t *tmp_in, *tmp_out;   // [n_segments] each
     int32_t *sums;           // [2][n_blocks + 1]
@@ -331,7 +337,9 @@ CsrWs carve_csr(char *base, int64_t n_hits, int64_t n_segments)
     w.n_blocks = (n_hits + kScanTile - 1) / kScanTile;
     size_t off = 0;
     auto take = [&](size_t n) { char *p = base ? base + off : nullptr; off += align256(n); return p; };
-    w.deg = reinterpret_cast<int32_t *>(take((size_t)2 * w.stride * sizeof(int32_t)));
+    // [bad word + 63 pad | counts in | counts out]: cleared by ONE memset
+    w.bad = reinterpret_cast<int32_t *>(take((size_t)(64 + 2 * w.stride) * sizeof(int32_t)));
+    w.deg = w.bad ? w.bad + 64 : nullptr;
     w.tmp_in = reinterpret_cast<int32_t *>(take((size_t)n_segments * sizeof(int32_t)));
     w.tmp_out = reinterpret_cast<int32_t *>(take((size_t)n_segments * sizeof(int32_t)));
     w.sums = reinterpret_cast<int32_t *>(take((size_t)2 * (w.n_blocks + 1) * sizeof(int32_t)));
@@ -368,25 +376,27 @@ int gnn_csr_build(const int32_t *src, const int32_t *dst, int64_t n_hits, int64_
     if (!workspace || workspace_bytes < need) return fail(GNN_ERR_WORKSPACE, "workspace too small: need %zu bytes", need);
     char *base = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     CsrWs w = carve_csr(base, n_hits, n_segments);
-    hipError_t err = hipMemsetAsync(status, 0, sizeof(int32_t), s);
-    if (err == hipSuccess && w.stride > 0) err = hipMemsetAsync(w.deg, 0, (size_t)2 * w.stride * sizeof(int32_t), s);
+    hipError_t err = hipMemsetAsync(n_segments > 0 ? w.bad : status, 0,
+                                    n_segments > 0 ? (size_t)(64 + 2 * w.stride) * sizeof(int32_t) : sizeof(int32_t), s);
+    if (err == hipSuccess && n_segments == 0 && w.stride > 0)
+        err = hipMemsetAsync(w.deg, 0, (size_t)2 * w.stride * sizeof(int32_t), s);
     if (err != hipSuccess) return fail(-(int)err, "gnn_csr_build: memset failed: %s", hipGetErrorString(err));
     const unsigned gseg = (unsigned)((n_segments + kBlock - 1) / kBlock);
     const bool big = n_segments >= kWgMinSegments && !getenv("GNN_CSR_NO_LDS");
     const unsigned gwg = (unsigned)((n_segments + kWgSegs - 1) / kWgSegs);
     if (n_segments > 0 && big)
         GNN_LAUNCH("k_csr_degrees_wg", k_csr_degrees_wg, gwg, kWgThreads, s, src, dst, n_hits, n_segments, w.deg,
-                   w.deg + w.stride, status);
+                   w.deg + w.stride, w.bad);
     else if (n_segments > 0)
         GNN_LAUNCH("k_csr_degrees", k_csr_degrees, gseg, kBlock, s, src, dst, n_hits, n_segments, w.deg, w.deg + w.stride,
-                   status);
+                   w.bad);
     if (n_hits <= kOneBlockMax) {
-        GNN_LAUNCH("k_csr_scan", k_csr_scan_one, 2, kBlock, s, w.deg, in_ptr, out_ptr, n_hits, w.stride);
+        GNN_LAUNCH("k_csr_scan", k_csr_scan_one, 2, kScanOneThreads, s, w.deg, in_ptr, out_ptr, n_hits, w.stride);
     } else {
         const dim3 g((unsigned)w.n_blocks, 2);
         GNN_LAUNCH("k_csr_scan_sums", k_csr_scan_sums, g, kBlock, s, w.deg, n_hits, w.stride, w.sums, w.n_blocks);
         // the block sums of both arrays, scanned in place ([n_blocks + 1] each: the last entry = the total)
-        GNN_LAUNCH("k_csr_scan", k_csr_scan_one, 2, kBlock, s, w.sums, w.sums, w.sums + (w.n_blocks + 1), w.n_blocks,
+        GNN_LAUNCH("k_csr_scan", k_csr_scan_one, 2, kScanOneThreads, s, w.sums, w.sums, w.sums + (w.n_blocks + 1), w.n_blocks,
                    w.n_blocks + 1);
         GNN_LAUNCH("k_csr_scan_blocks", k_csr_scan_blocks, g, kBlock, s, w.deg, n_hits, w.stride, w.sums, w.n_blocks, in_ptr,
                    out_ptr);
@@ -399,7 +409,7 @@ int gnn_csr_build(const int32_t *src, const int32_t *dst, int64_t n_hits, int64_
             GNN_LAUNCH("k_csr_fill", k_csr_fill, gseg, kBlock, s, src, dst, n_hits, n_segments, in_ptr, out_ptr, w.deg,
                        w.deg + w.stride, w.tmp_in, w.tmp_out);
         GNN_LAUNCH("k_csr_rank", k_csr_rank, gseg, kBlock, s, src, dst, n_hits, n_segments, in_ptr, out_ptr, w.tmp_in,
-                   w.tmp_out, in_eid, in_nbr, out_eid, out_nbr);
+                   w.tmp_out, in_eid, in_nbr, out_eid, out_nbr, w.bad, status);
     }
     return 0;
 }
