@@ -452,12 +452,34 @@ def train_c3(dev, graphs, steps=30, warmup=8, hidden_dim=8, n_iters=3, n_graphs=
     dd = time_steps(step_direct, steps, sync)
     last = float(step().detach())
     n_seg = batch.n_segments
-    return {"workload": "%d graph(s) of the workload as one batch (%d hits, %d segments), F=%d, D=%d, T=%d, BCE, Adam"
-                        % (len(graphs), batch.n_hits, n_seg, F, hidden_dim, n_iters),
-            "ms_per_step": dt / steps * 1e3, "segments_per_s": n_seg * steps / dt,
-            "ms_per_step_direct": dd / steps * 1e3, "segments_per_s_direct": n_seg * steps / dd,
-            "direct": "GradBucket.step: same kernels, no autograd graph, loss in the twin's segment order",
-            "loss_first": first, "loss_last": last, "steps": steps}
+    rec = {"workload": "%d graph(s) of the workload as one batch (%d hits, %d segments), F=%d, D=%d, T=%d, BCE, Adam"
+                       % (len(graphs), batch.n_hits, n_seg, F, hidden_dim, n_iters),
+           "ms_per_step": dt / steps * 1e3, "segments_per_s": n_seg * steps / dt,
+           "ms_per_step_direct": dd / steps * 1e3, "segments_per_s_direct": n_seg * steps / dd,
+           "direct": "GradBucket.step: same kernels, no autograd graph, loss in the twin's segment order",
+           "loss_first": first, "loss_last": last, "steps": steps}
+    # the same step (GradBucket.step + Adam) captured once as a HIP graph and replayed: what its ~30 launches'
+    # gaps are worth; a capture that raises leaves the eager numbers
+    try:
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True, fused=True)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step_direct()
+        torch.cuda.current_stream().wait_stream(side)
+        sync()
+        cg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cg):
+            step_direct()
+        for _ in range(warmup):
+            cg.replay()
+        dg = time_steps(cg.replay, steps, sync)
+        rec["ms_per_step_hip_graph"] = dg / steps * 1e3
+        rec["segments_per_s_hip_graph"] = n_seg * steps / dg
+    except Exception as ex:       # noqa: BLE001
+        rec["hip_graph"] = "capture refused (%s: %s)" % (type(ex).__name__, str(ex)[:120])
+    return rec
 
 
 def run(args):

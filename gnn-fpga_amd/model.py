@@ -232,7 +232,8 @@ class SegmentClassifier(nn.Module):
     # forward of a never-seen batch: a stream of never-repeated graphs (trigger-style use, gnn/Inference.ipynb
     # cell 3) never pays a plan.  The two routes sum in different orders (scores differ by ~1e-7).
     use_plan = "auto"
-    first_forward_max_segments = 4_000_000      # "auto": larger never-seen batches build their plan at once
+    first_forward_max_segments = 4_000_000      # "auto": larger never-seen batches build their plan at once (hidden_dim
+                                                # <= 16; half of it at hidden_dim 32, 0.6 M at 64: tools/fresh_probe.py)
 
     def __init__(self, input_dim=2, hidden_dim=8, n_iters=3, hidden_activation=nn.Tanh,
                  masks_e=None, masks_n=None):
@@ -378,7 +379,11 @@ class SegmentClassifier(nn.Module):
             # first forward of a never-seen batch: no plan yet - up to the size where the plan pays for itself
             # at once (tools/fresh_probe.py: 32 c3 graphs 1.22 ms against 1.72 with the plan, 256 graphs 9.5
             # against 6.7: the crossover is near 6.5 M segments)
-            fused = seen > 0 or batch.n_segments > self.first_forward_max_segments
+            # (the wide shapes' per-module kernels are slower against their fused ones: hidden_dim 32 crosses near
+            # 3 M segments, hidden_dim 64 - T = 6 - near 0.7 M)
+            limit = self.first_forward_max_segments
+            limit = limit if D <= 16 else limit // 2 if D <= 32 else limit * 3 // 20
+            fused = seen > 0 or batch.n_segments > limit
         if fused:
             plan = batch.build_plan(D)
             need = _lib.plan_workspace_bytes(plan.n_pad, plan.n_segments, F, D)

@@ -57,3 +57,9 @@ one_shot("c2 one muon graph", [synth.muon_graph(3)], 11, 8, 3, events=True)
 one_shot("c5 single graph", [synth.layered_graph(50000, 500000, 3, seed=0)], 3, 64, 6)
 one_shot("c3 x 32", [synth.layered_graph(10000, 100000, 3, seed=s) for s in range(32)], 3, 8, 3, 5)
 one_shot("c3 x 256", [synth.layered_graph(10000, 100000, 3, seed=s) for s in range(256)], 3, 8, 3, 3)
+# wide shapes: where the per-module kernels stop answering a first forward faster than plan + fused pipeline
+one_shot("c5 x 2 (D = 64)", [synth.layered_graph(50000, 500000, 3, seed=s) for s in range(2)], 3, 64, 6, 5)
+one_shot("c3 x 8, D = 32", [synth.layered_graph(10000, 100000, 3, seed=s) for s in range(8)], 3, 32, 3, 5)
+one_shot("c3 x 16, D = 32", [synth.layered_graph(10000, 100000, 3, seed=s) for s in range(16)], 3, 32, 3, 5)
+one_shot("c3 x 16, D = 16", [synth.layered_graph(10000, 100000, 3, seed=s) for s in range(16)], 3, 16, 3, 5)
+one_shot("c3 x 32, D = 16", [synth.layered_graph(10000, 100000, 3, seed=s) for s in range(32)], 3, 16, 3, 5)
