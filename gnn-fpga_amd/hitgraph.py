@@ -266,8 +266,9 @@ class HitGraphBatch:
             # one graph (a single event through the model): nothing to check beyond what the constructor checked,
             # and no numpy passes on the way to the first launch
             hp, sp = self.hit_ptr, self.seg_ptr
+            from . import _lib
             ok = (hp[0] == 0 and sp[0] == 0 and hp[1] == self.n_hits and sp[1] == self.n_segments and
-                  self.n_hits < 2 ** 31 and self.n_segments < 2 ** 31)
+                  self.n_hits < 2 ** 31 and self.n_segments <= _lib.EVENTS_MAX_SEGMENTS)     # (larger: never a layout)
             self._event = (_EventLayout(hp, sp, sizes=(self.n_hits, self.n_segments)) if ok else None,)
         if getattr(self, "_event", None) is None:
             hp, sp = self.hit_ptr, self.seg_ptr
