@@ -119,6 +119,67 @@ __device__ __forceinline__ void accum_outer(const float *L, const float *R, bool
     if constexpr (C0 + CH < NR) accum_outer<NL, NR, C0 + CH>(L, R, active, g, ldg, col0, gb, lds);
 }
 
+// Several outer-product sums in ONE staging (two barriers instead of two per sum, the right factor staged once when
+// the sums share it, and all 256 threads busy: one sum of D x (C + 1) = 96 outputs keeps 96 of them): job j adds
+// sum_items L_j (x) [R_j | 1] into g_j[i * ldg_j + col0_j + k] (and, gb_j != null, the ones column into gb_j[i]).
+// The caller has parked its factors in LDS rows (stage_row) - L_j in rows [lrow_j, lrow_j + nl), R_j in
+// [rrow_j, rrow_j + nr_j), the ones row last; every output is the same 256-term dot product in item order as in
+// accum_outer: the sums come out bit-identical to separate calls.  k_seg_fin's four sums at D = 8 (44 rows, 46 KB)
+// would leave three workgroups per CU where the kernel wants five: the callers stage two sums at a time.
+constexpr int kOuterJobRows = 62;                  // 62 x 260 x 4 B = 64,480 B: what a static __shared__ array may hold
+struct OuterJob { int lrow, rrow, nr, ldg, col0; float *g, *gb; };
+__device__ __forceinline__ void stage_row(float *lds, int row, float v) { lds[row * kOuterStride + threadIdx.x] = v; }
+template <int NJ>
+__device__ __forceinline__ void accum_outer_jobs(const OuterJob (&jobs)[NJ], int nl, int ones_row, float *lds)
+{
+    constexpr int RS = kOuterStride;
+    __syncthreads();
+    int total = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) total += nl * (jobs[j].nr + (jobs[j].gb ? 1 : 0));
+    for (int o = threadIdx.x; o < total; o += kBlock) {
+        int oo = o, j = 0;
+#pragma unroll
+        for (int t = 0; t < NJ - 1; ++t) {
+            const int n = nl * (jobs[t].nr + (jobs[t].gb ? 1 : 0));
+            if (j == t && oo >= n) { oo -= n; j = t + 1; }
+        }
+        const OuterJob &J = jobs[j];
+        const int cols = J.nr + (J.gb ? 1 : 0), i = oo / cols, k = oo % cols;
+        const float4 *a = reinterpret_cast<const float4 *>(lds + (J.lrow + i) * RS);
+        const float4 *b = reinterpret_cast<const float4 *>(lds + (k < J.nr ? J.rrow + k : ones_row) * RS);
+        float acc = 0.0f;
+#pragma unroll 4
+        for (int t = 0; t < kBlock / 4; ++t) {
+            const float4 x = a[t], y = b[t];
+            acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc);
+            acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
+        }
+        float *dst = k < J.nr ? &J.g[i * J.ldg + J.col0 + k] : &J.gb[i];          // own row: the only writer
+        *dst += acc;
+    }
+    __syncthreads();
+}
+// two left factors against one right factor: (L0 (x) [R | 1]) -> g[.., col0a + k], gb;  (L1 (x) R) -> g[.., col0b + k]
+template <int NL, int NR>
+constexpr int outer2_lds_floats() { return kOuterStride * (2 * NL + NR + 1); }
+template <int NL, int NR>
+__device__ __forceinline__ void accum_outer2(const float *L0, const float *L1, const float *R, bool active, float *g,
+                                             int ldg, int col0a, int col0b, float *gb, float *lds)
+{
+    static_assert(2 * NL + NR + 1 <= kOuterJobRows, "two left factors and the right one must fit the static LDS array");
+#ifdef GNN_ABLATE_OUTER
+    return;
+#endif
+#pragma unroll
+    for (int i = 0; i < NL; ++i) { stage_row(lds, i, active ? L0[i] : 0.0f); stage_row(lds, NL + i, active ? L1[i] : 0.0f); }
+#pragma unroll
+    for (int k = 0; k < NR; ++k) stage_row(lds, 2 * NL + k, active ? R[k] : 0.0f);
+    stage_row(lds, 2 * NL + NR, active ? 1.0f : 0.0f);
+    const OuterJob jobs[2] = {{0, 2 * NL, NR, ldg, col0a, g, gb}, {NL, 2 * NL, NR, ldg, col0b, g, nullptr}};
+    accum_outer_jobs<2>(jobs, NL, 2 * NL + NR, lds);
+}
+
 // The same sums on the matrix cores for wide left factors (NL = 32 / 64): the outer-product sum over
 // the workgroup's 256 items is a [NL x 256] . [256 x NR] product.  v_mfma_f32_16x16x4_f32 multiplies
 // and accumulates in fp32 in k (= item) order: nothing is rounded, the order is fixed.  Lane l supplies
@@ -301,7 +362,9 @@ __global__ __launch_bounds__(kBlock) void k_pq_bwd(
     gW1 = my_replica(gW1, rep_stride);
     gb1 = my_replica(gb1, rep_stride);
     constexpr int C = F + D, LDH = Shape<F, D>::LDH;
-    __shared__ __attribute__((aligned(16))) float lds[outer_lds_floats<D, C>()];
+    constexpr int kLds = (2 * D + C + 1 <= kOuterJobRows && outer2_lds_floats<D, C>() > outer_lds_floats<D, C>())
+                             ? outer2_lds_floats<D, C>() : outer_lds_floats<D, C>();
+    __shared__ __attribute__((aligned(16))) float lds[kLds];
     const int64_t n = xcd_block() * kBlock + threadIdx.x;
     const bool active = n < n_hits;
     float gP[D], gQ[D], h[C];
@@ -355,8 +418,12 @@ __global__ __launch_bounds__(kBlock) void k_pq_bwd(
         }
         store_row4<LDH / 4>(gH + n * ldh, gh);
     }
-    accum_outer<D, C>(gP, h, active, gW1, 2 * C, 0, gb1, lds);
-    accum_outer<D, C>(gQ, h, active, gW1, 2 * C, C, nullptr, lds);
+    if constexpr (2 * D + C + 1 <= kOuterJobRows) {
+        accum_outer2<D, C>(gP, gQ, h, active, gW1, 2 * C, 0, C, gb1, lds);
+    } else {
+        accum_outer<D, C>(gP, h, active, gW1, 2 * C, 0, gb1, lds);
+        accum_outer<D, C>(gQ, h, active, gW1, 2 * C, C, nullptr, lds);
+    }
 }
 
 template <int F, int D>
@@ -822,7 +889,9 @@ __global__ __launch_bounds__(kBlock) void k_hit_bwd4(
     gW4 = my_replica(gW4, rep_stride);
     gb4 = my_replica(gb4, rep_stride);
     constexpr int C = Shape<F, D>::C, LDH = Shape<F, D>::LDH, DL = D / 4;
-    __shared__ __attribute__((aligned(16))) float lds[outer_lds_floats<D, C>()];
+    constexpr int kLds = (3 * D + C + 1 <= kOuterJobRows && kOuterStride * (3 * D + C + 1) > outer_lds_floats<D, C>())
+                             ? kOuterStride * (3 * D + C + 1) : outer_lds_floats<D, C>();
+    __shared__ __attribute__((aligned(16))) float lds[kLds];
     const int64_t n = xcd_block() * kBlock + threadIdx.x;
     const bool active = n < n_hits;
     float h[C], q[D], gr[D], gp[D];
@@ -877,8 +946,25 @@ __global__ __launch_bounds__(kBlock) void k_hit_bwd4(
         store_row4<3 * D / 4>(A + n * 3 * D, a);
         store_row4<3 * D / 4>(B + n * 3 * D, b);
     }
-    accum_outer<D, C>(gp, h, active, gW3, 3 * C, 2 * C, gb3, lds);
-    accum_outer<D, D>(gr, q, active, gW4, D, 0, gb4, lds);
+    if constexpr (3 * D + C + 1 <= kOuterJobRows) {
+        // both sums in one staging: rows gp | gr | h | q | ones
+#ifndef GNN_ABLATE_OUTER
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            stage_row(lds, i, active ? gp[i] : 0.0f);
+            stage_row(lds, D + i, active ? gr[i] : 0.0f);
+            stage_row(lds, 2 * D + C + i, active ? q[i] : 0.0f);
+        }
+#pragma unroll
+        for (int k = 0; k < C; ++k) stage_row(lds, 2 * D + k, active ? h[k] : 0.0f);
+        stage_row(lds, 3 * D + C, active ? 1.0f : 0.0f);
+        const OuterJob jobs[2] = {{0, 2 * D, C, 3 * C, 2 * C, gW3, gb3}, {D, 2 * D + C, D, D, 0, gW4, gb4}};
+        accum_outer_jobs<2>(jobs, D, 3 * D + C, lds);
+#endif
+    } else {
+        accum_outer<D, C>(gp, h, active, gW3, 3 * C, 2 * C, gb3, lds);
+        accum_outer<D, D>(gr, q, active, gW4, D, 0, gb4, lds);
+    }
 }
 
 // one direction of a hit's pull: REC = the far ends' records, own_pq / own_r / own_gp the hit's own
@@ -1000,7 +1086,7 @@ __global__ __launch_bounds__(kBlock) void k_seg_fin(
     gb1 = my_replica(gb1, rep_stride);
     gW3 = my_replica(gW3, rep_stride);
     constexpr int C = Shape<F, D>::C, LDH = Shape<F, D>::LDH, DL = D / 4;
-    __shared__ __attribute__((aligned(16))) float lds[outer_lds_floats<D, C>()];
+    __shared__ __attribute__((aligned(16))) float lds[outer2_lds_floats<D, C>()];
     const int64_t n = xcd_block() * kBlock + threadIdx.x;
     const bool active = n < n_hits;
     float gP[D], gQ[D], Gout[D], Gin[D], h[C];
@@ -1035,10 +1121,8 @@ __global__ __launch_bounds__(kBlock) void k_seg_fin(
         }
         store_row4<LDH / 4>(gH + n * ldh, gh);
     }
-    accum_outer<D, C>(gP, h, active, gW1, 2 * C, 0, gb1, lds);
-    accum_outer<D, C>(gQ, h, active, gW1, 2 * C, C, nullptr, lds);
-    accum_outer<D, C>(Gout, h, active, gW3, 3 * C, 0, nullptr, lds);
-    accum_outer<D, C>(Gin, h, active, gW3, 3 * C, C, nullptr, lds);
+    accum_outer2<D, C>(gP, gQ, h, active, gW1, 2 * C, 0, C, gb1, lds);
+    accum_outer2<D, C>(Gout, Gin, h, active, gW3, 3 * C, 0, C, nullptr, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
