@@ -876,24 +876,26 @@ __device__ __forceinline__ void store_vec(float *__restrict__ p, const float *v)
     }
 }
 
+// LDS floats of the per-hit kernels' outer-product stagings (hit: gp | gr | h | q | ones when that fits, fin: two left
+// factors | h | ones)
 template <int F, int D>
-__global__ __launch_bounds__(kBlock) void k_hit_bwd4(
-    const float *__restrict__ H, const float *__restrict__ Hn, const float *__restrict__ Qk, int ldh,
-    const float *__restrict__ W1, const float *__restrict__ b1, const float *__restrict__ W3,
-    const float *__restrict__ W4, const float *__restrict__ gHn, float *__restrict__ gH, float *__restrict__ A,
-    float *__restrict__ B, float *__restrict__ gW3, float *__restrict__ gb3, float *__restrict__ gW4,
-    float *__restrict__ gb4, int rep_stride, int64_t n_hits)
+constexpr int hit_lds_floats()
 {
-    gW3 = my_replica(gW3, rep_stride);
-    gb3 = my_replica(gb3, rep_stride);
-    gW4 = my_replica(gW4, rep_stride);
-    gb4 = my_replica(gb4, rep_stride);
+    constexpr int C = Shape<F, D>::C;
+    return (3 * D + C + 1 <= kOuterJobRows && kOuterStride * (3 * D + C + 1) > outer_lds_floats<D, C>())
+               ? kOuterStride * (3 * D + C + 1) : outer_lds_floats<D, C>();
+}
+
+// k_hit_bwd4's work for hit n, given the next pass's features hn[D] and their gradient gn[D] in registers
+// (gW3 .. gb4: the workgroup's own rows of the partial table)
+template <int F, int D>
+__device__ __forceinline__ void hit_bwd4_core(
+    int64_t n, bool active, const float *__restrict__ H, const float *__restrict__ Qk, int ldh, const float *hn,
+    const float *gn, const float *__restrict__ W1, const float *__restrict__ b1, const float *__restrict__ W3,
+    const float *__restrict__ W4, float *__restrict__ gH, float *__restrict__ A, float *__restrict__ B, float *gW3,
+    float *gb3, float *gW4, float *gb4, float *lds)
+{
     constexpr int C = Shape<F, D>::C, LDH = Shape<F, D>::LDH, DL = D / 4;
-    constexpr int kLds = (3 * D + C + 1 <= kOuterJobRows && kOuterStride * (3 * D + C + 1) > outer_lds_floats<D, C>())
-                             ? kOuterStride * (3 * D + C + 1) : outer_lds_floats<D, C>();
-    __shared__ __attribute__((aligned(16))) float lds[kLds];
-    const int64_t n = xcd_block() * kBlock + threadIdx.x;
-    const bool active = n < n_hits;
     float h[C], q[D], gr[D], gp[D];
 #pragma unroll
     for (int k = 0; k < C; ++k) h[k] = 0.0f;
@@ -905,9 +907,6 @@ __global__ __launch_bounds__(kBlock) void k_hit_bwd4(
 #pragma unroll
         for (int k = 0; k < C; ++k) h[k] = hp[k];
         load_row4<D / 4>(Qk + n * D, q);
-        float hn[D], gn[D];
-        load_row4<D / 4>(Hn + n * ldh, hn);
-        load_row4<D / 4>(gHn + n * ldh, gn);
 #pragma unroll
         for (int i = 0; i < D; ++i) gr[i] = gn[i] * (1.0f - hn[i] * hn[i]);
 #pragma unroll
@@ -965,6 +964,28 @@ __global__ __launch_bounds__(kBlock) void k_hit_bwd4(
         accum_outer<D, C>(gp, h, active, gW3, 3 * C, 2 * C, gb3, lds);
         accum_outer<D, D>(gr, q, active, gW4, D, 0, gb4, lds);
     }
+}
+
+template <int F, int D>
+__global__ __launch_bounds__(kBlock) void k_hit_bwd4(
+    const float *__restrict__ H, const float *__restrict__ Hn, const float *__restrict__ Qk, int ldh,
+    const float *__restrict__ W1, const float *__restrict__ b1, const float *__restrict__ W3,
+    const float *__restrict__ W4, const float *__restrict__ gHn, float *__restrict__ gH, float *__restrict__ A,
+    float *__restrict__ B, float *__restrict__ gW3, float *__restrict__ gb3, float *__restrict__ gW4,
+    float *__restrict__ gb4, int rep_stride, int64_t n_hits)
+{
+    __shared__ __attribute__((aligned(16))) float lds[hit_lds_floats<F, D>()];
+    const int64_t n = xcd_block() * kBlock + threadIdx.x;
+    const bool active = n < n_hits;
+    float hn[D], gn[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) hn[i] = gn[i] = 0.0f;
+    if (active) {
+        load_row4<D / 4>(Hn + n * ldh, hn);
+        load_row4<D / 4>(gHn + n * ldh, gn);
+    }
+    hit_bwd4_core<F, D>(n, active, H, Qk, ldh, hn, gn, W1, b1, W3, W4, gH, A, B, my_replica(gW3, rep_stride),
+                        my_replica(gb3, rep_stride), my_replica(gW4, rep_stride), my_replica(gb4, rep_stride), lds);
 }
 
 // one direction of a hit's pull: REC = the far ends' records, own_pq / own_r / own_gp the hit's own
@@ -1076,19 +1097,15 @@ __global__ __launch_bounds__(kQuadBlock) void k_seg_bwd4(
     }
 }
 
+// k_seg_fin's work for hit n: gh[LDH] comes in as the row k_hit_bwd4 initialised (gHself) and leaves as the complete
+// gradient of the hit's features; hr[LDH] = the hit's feature row (handed on to a fused next step)
 template <int F, int D>
-__global__ __launch_bounds__(kBlock) void k_seg_fin(
-    const float *__restrict__ H, int ldh, const float *__restrict__ G4, const float *__restrict__ W1,
-    const float *__restrict__ W3, float *__restrict__ gH, float *__restrict__ gW1, float *__restrict__ gb1,
-    float *__restrict__ gW3, int rep_stride, int64_t n_hits)
+__device__ __forceinline__ void seg_fin_core(int64_t n, bool active, const float *__restrict__ H, int ldh,
+                                             const float *__restrict__ G4, const float *__restrict__ W1,
+                                             const float *__restrict__ W3, float *gh, float *hr, float *gW1, float *gb1,
+                                             float *gW3, float *lds)
 {
-    gW1 = my_replica(gW1, rep_stride);
-    gb1 = my_replica(gb1, rep_stride);
-    gW3 = my_replica(gW3, rep_stride);
     constexpr int C = Shape<F, D>::C, LDH = Shape<F, D>::LDH, DL = D / 4;
-    __shared__ __attribute__((aligned(16))) float lds[outer2_lds_floats<D, C>()];
-    const int64_t n = xcd_block() * kBlock + threadIdx.x;
-    const bool active = n < n_hits;
     float gP[D], gQ[D], Gout[D], Gin[D], h[C];
 #pragma unroll
     for (int i = 0; i < D; ++i) gP[i] = gQ[i] = Gout[i] = Gin[i] = 0.0f;
@@ -1102,9 +1119,7 @@ __global__ __launch_bounds__(kBlock) void k_seg_fin(
             const int at = (i / DL) * 4 * DL + (i % DL);
             gP[i] = g4[at]; gQ[i] = g4[at + DL]; Gout[i] = g4[at + 2 * DL]; Gin[i] = g4[at + 3 * DL];
         }
-        float hr[LDH], gh[LDH];
         load_row4<LDH / 4>(H + n * ldh, hr);
-        load_row4<LDH / 4>(gH + n * ldh, gh);
 #pragma unroll
         for (int k = 0; k < C; ++k) h[k] = hr[k];
 #pragma unroll
@@ -1119,10 +1134,58 @@ __global__ __launch_bounds__(kBlock) void k_seg_fin(
             }
             gh[k] += s;
         }
-        store_row4<LDH / 4>(gH + n * ldh, gh);
     }
     accum_outer2<D, C>(gP, gQ, h, active, gW1, 2 * C, 0, C, gb1, lds);
     accum_outer2<D, C>(Gout, Gin, h, active, gW3, 3 * C, 0, C, nullptr, lds);
+}
+
+template <int F, int D>
+__global__ __launch_bounds__(kBlock) void k_seg_fin(
+    const float *__restrict__ H, int ldh, const float *__restrict__ G4, const float *__restrict__ W1,
+    const float *__restrict__ W3, float *__restrict__ gH, float *__restrict__ gW1, float *__restrict__ gb1,
+    float *__restrict__ gW3, int rep_stride, int64_t n_hits)
+{
+    constexpr int C = Shape<F, D>::C, LDH = Shape<F, D>::LDH;
+    __shared__ __attribute__((aligned(16))) float lds[outer2_lds_floats<D, C>()];
+    const int64_t n = xcd_block() * kBlock + threadIdx.x;
+    const bool active = n < n_hits;
+    float gh[LDH], hr[LDH];
+#pragma unroll
+    for (int k = 0; k < LDH; ++k) gh[k] = hr[k] = 0.0f;
+    if (active) load_row4<LDH / 4>(gH + n * ldh, gh);
+    seg_fin_core<F, D>(n, active, H, ldh, G4, W1, W3, gh, hr, my_replica(gW1, rep_stride), my_replica(gb1, rep_stride),
+                       my_replica(gW3, rep_stride), lds);
+    if (active) store_row4<LDH / 4>(gH + n * ldh, gh);
+}
+
+// k_seg_fin of iteration u and k_hit_bwd4 of iteration u - 1 in one launch: both are one lane per hit, and what the
+// first hands the second - the finished gradient row of H_{u-1} and that row itself - stays in registers (130 bytes
+// per hit less through memory, one launch less per iteration).  H = H_{u-1}, Hpp = H_{u-2}, Qk = the node network's
+// hidden layer of pass u - 2; gH = the row k_hit_bwd4 (u) initialised (read only), gHpp = the buffer the next
+// iteration accumulates into; A / B are rewritten for iteration u - 1 (k_seg_bwd4 (u) has finished with them).
+template <int F, int D>
+__global__ __launch_bounds__(kBlock) void k_fin_hit(
+    const float *__restrict__ H, const float *__restrict__ Hpp, const float *__restrict__ Qk, int ldh,
+    const float *__restrict__ G4, const float *__restrict__ W1, const float *__restrict__ b1,
+    const float *__restrict__ W3, const float *__restrict__ W4, const float *__restrict__ gH, float *__restrict__ gHpp,
+    float *__restrict__ A, float *__restrict__ B, float *__restrict__ gW1, float *__restrict__ gb1,
+    float *__restrict__ gW3, float *__restrict__ gb3, float *__restrict__ gW4, float *__restrict__ gb4, int rep_stride,
+    int64_t n_hits)
+{
+    constexpr int C = Shape<F, D>::C, LDH = Shape<F, D>::LDH;
+    constexpr int kLds = hit_lds_floats<F, D>() > outer2_lds_floats<D, C>() ? hit_lds_floats<F, D>() : outer2_lds_floats<D, C>();
+    __shared__ __attribute__((aligned(16))) float lds[kLds];
+    const int64_t n = xcd_block() * kBlock + threadIdx.x;
+    const bool active = n < n_hits;
+    float gh[LDH], hr[LDH];
+#pragma unroll
+    for (int k = 0; k < LDH; ++k) gh[k] = hr[k] = 0.0f;
+    if (active) load_row4<LDH / 4>(gH + n * ldh, gh);
+    float *const gW3r = my_replica(gW3, rep_stride);
+    seg_fin_core<F, D>(n, active, H, ldh, G4, W1, W3, gh, hr, my_replica(gW1, rep_stride), my_replica(gb1, rep_stride),
+                       gW3r, lds);
+    hit_bwd4_core<F, D>(n, active, Hpp, Qk, ldh, hr, gh, W1, b1, W3, W4, gHpp, A, B, gW3r, my_replica(gb3, rep_stride),
+                        my_replica(gW4, rep_stride), my_replica(gb4, rep_stride), lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1769,14 +1832,27 @@ int backward_t(const gnn_graph_t *g, const gnn_params_t *p, int T, const float *
                 const float *ep = e_all + (size_t)(u - 1) * E;
                 if (N > 0) {
                     if (Q_all) {
-                        GNN_LAUNCH("k_hit_bwd4", (k_hit_bwd4<F, D>), grid_for(N), kBlock, s, Hp, Hu,
-                                   Q_all + (size_t)(u - 1) * N * D, LDH, p->W1, p->b1, p->W3, p->W4, gH, gHprev, w.A, w.B,
-                                   rp + GL::oW3, rp + GL::ob3, rp + GL::oW4, rp + GL::ob4, RS, N);
+                        // k_hit_bwd4 (u) ran as the tail of the previous iteration's k_fin_hit, except for the first
+                        static const bool unfused = getenv("GNN_BWD_NO_FIN_HIT") != nullptr;      // A / B runs
+                        if (u == t || unfused)
+                            GNN_LAUNCH("k_hit_bwd4", (k_hit_bwd4<F, D>), grid_for(N), kBlock, s, Hp, Hu,
+                                       Q_all + (size_t)(u - 1) * N * D, LDH, p->W1, p->b1, p->W3, p->W4, gH, gHprev, w.A,
+                                       w.B, rp + GL::oW3, rp + GL::ob3, rp + GL::oW4, rp + GL::ob4, RS, N);
                         GNN_LAUNCH("k_seg_bwd4", (k_seg_bwd4<F, D>), grid_for(N), kQuadBlock, s, w.A, w.B, ep, g->in_ptr,
                                    g->in_eid, g->in_nbr, g->out_ptr, g->out_eid, g->out_nbr, p->W2, w.G4, rp + GL::oW2,
                                    rp + GL::ob2, RS, N);
-                        GNN_LAUNCH("k_seg_fin", (k_seg_fin<F, D>), grid_for(N), kBlock, s, Hp, LDH, w.G4, p->W1, p->W3, gHprev,
-                                   rp + GL::oW1, rp + GL::ob1, rp + GL::oW3, RS, N);
+                        if (u > 1 && !unfused) {
+                            // the gradient row of H_{u-1} is finished in registers and feeds iteration u - 1's per-hit
+                            // pass at once: gHprev (its initial row) is read, gH (free by now) takes iteration u - 1's
+                            // initial row - after the swap below the roles are as a separate k_hit_bwd4 leaves them
+                            GNN_LAUNCH("k_fin_hit", (k_fin_hit<F, D>), grid_for(N), kBlock, s, Hp,
+                                       H_all + (size_t)(u - 2) * N * LDH, Q_all + (size_t)(u - 2) * N * D, LDH, w.G4, p->W1,
+                                       p->b1, p->W3, p->W4, gHprev, gH, w.A, w.B, rp + GL::oW1, rp + GL::ob1, rp + GL::oW3,
+                                       rp + GL::ob3, rp + GL::oW4, rp + GL::ob4, RS, N);
+                        } else {
+                            GNN_LAUNCH("k_seg_fin", (k_seg_fin<F, D>), grid_for(N), kBlock, s, Hp, LDH, w.G4, p->W1, p->W3,
+                                       gHprev, rp + GL::oW1, rp + GL::ob1, rp + GL::oW3, RS, N);
+                        }
                         float *tmp = gH; gH = gHprev; gHprev = tmp;
                         continue;
                     }
