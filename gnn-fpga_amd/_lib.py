@@ -102,7 +102,7 @@ SIGNATURES = {
     "gnn_segclf_forward_plan": (ctypes.c_int, [ctypes.POINTER(GnnPlan), ctypes.POINTER(GnnParams),
                                                _i32, _f, _f, _sz, _f]),
     "gnn_segclf_forward_train_plan": (ctypes.c_int, [ctypes.POINTER(GnnPlan), ctypes.POINTER(GnnParams), _i32, _f, _f, _f,
-                                                     _f, _f, _f, _sz, _f]),
+                                                     _f, _f, _f, _f, _f, _sz, _f]),
     "gnn_plan_shape_supported": (ctypes.c_int, [_i32, _i32]),
     "gnn_plan_limits": (ctypes.c_int, [_i32, _i32, ctypes.POINTER(_i32)]),
     "gnn_exp_product_bound": (ctypes.c_int, [ctypes.POINTER(GnnParams), _f, _f, _f]),
@@ -438,11 +438,12 @@ def segclf_forward_train(batch, weights, F, D, n_iters, layout=None):
     return e_all, H_all, Q_all
 
 
-def segclf_forward_train_fused(batch, weights, F, D, n_iters):
+def segclf_forward_train_fused(batch, weights, F, D, n_iters, want_out=True):
     """The training forward of a PLAN-SPACE batch (HitGraphBatch.level_ordered) on the fused tile kernels of the
     plan it was made from.  Returns (e_all, H_all, Q_all, e_out) - the first three as segclf_forward_train gives
-    them for this batch, e_out the final scores in the CALLER's segment order - or None when this batch or
-    shape has no fused training forward (GNN_NO_FUSED_TRAIN=1 also says no: A / B runs)."""
+    them for this batch (row T of e_all by k_edge_tw, in this batch's segment order), e_out the final scores in the
+    CALLER's segment order (None with want_out=False: a loss taken in this batch's order needs no second copy) - or
+    None when this batch or shape has no fused training forward (GNN_NO_FUSED_TRAIN=1 also says no: A / B runs)."""
     plan = getattr(batch, "_fused", None)
     if plan is None or getattr(batch, "_fused_dim", None) != D or os.environ.get("GNN_NO_FUSED_TRAIN"):
         return None
@@ -451,12 +452,8 @@ def segclf_forward_train_fused(batch, weights, F, D, n_iters):
     n_valid = getattr(batch, "_n_valid", None)
     if n_valid is None:
         n_valid = batch._n_valid = int((batch.src >= 0).sum().item())          # once per batch
-    res = segclf_forward_train_plan(plan, batch.in_ptr, n_valid, weights, F, D, n_iters)
-    if res is None:
-        return None
-    e_all, H_all, Q_all, e_out = res
-    torch.index_select(e_out, 0, batch.seg_order, out=e_all[n_iters])           # the final scores in this batch's order
-    return e_all, H_all, Q_all, e_out
+    return segclf_forward_train_plan(plan, batch.in_ptr, n_valid, weights, F, D, n_iters, tw_src=batch.src,
+                                     tw_dst=batch.dst, want_out=want_out)
 
 
 def segclf_backward(batch, weights, F, D, n_iters, e_all, H_all, grad_out, into=None, Q_all=None):
@@ -673,24 +670,28 @@ def segclf_forward_plan(plan, weights, F, D, n_iters, out=None, workspace=None, 
     return out
 
 
-def segclf_forward_train_plan(plan, seg_ptr, n_segments_valid, weights, F, D, n_iters, flags=0, workspace=None):
+def segclf_forward_train_plan(plan, seg_ptr, n_segments_valid, weights, F, D, n_iters, flags=0, workspace=None,
+                              tw_src=None, tw_dst=None, want_out=True):
     """The training forward on a planned batch (fused tile kernels; gnn_segclf_forward_train_plan).
-    `seg_ptr` int32 [n_pad + 1]: CSR pointer over end hits of the plan-space batch the backward runs on.
-    Returns (e_all [(T + 1), E] with rows 0 .. T-1 filled in that batch's segment order - row T is the caller's
-    to fill from e_out -, H_all [(T + 1), n_pad, ldh], Q_all [T, n_pad, D], e_out [E] in the plan's segment
-    order) or None when the shape has no fused training forward."""
+    `seg_ptr` int32 [n_pad + 1]: CSR pointer over end hits of the plan-space batch the backward runs on;
+    `tw_src` / `tw_dst` int32 [E]: that batch's segment endpoints (plan hit ids, -1 = padded).
+    Returns (e_all [(T + 1), E] in that batch's segment order - row T filled when tw_src / tw_dst are given, else
+    the caller's to fill from e_out -, H_all [(T + 1), n_pad, ldh], Q_all [T, n_pad, D], e_out [E] in the plan's
+    segment order or None with want_out=False) or None when the shape has no fused training forward."""
     dev = plan.X.device
     E, Np = plan.n_segments, plan.n_pad
     ldh = h_stride(F, D)
     need = plan_workspace_bytes(Np, E, F, D)
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+    if tw_src is None and not want_out:
+        raise GnnHipError("segclf_forward_train_plan: the final scores are wanted in at least one order")
     # (padded segments are in no hit's list: their entries of rows 0 .. T-1 are never written nor read by the
     # backward's walks; zeros keep them defined)
     e_all = (torch.zeros if n_segments_valid < E else torch.empty)((n_iters + 1, E), dtype=torch.float32, device=dev)
     H_all = torch.empty((n_iters + 1, Np, ldh), dtype=torch.float32, device=dev)
     Q_all = torch.empty((n_iters, Np, D), dtype=torch.float32, device=dev)
-    e_out = torch.empty(E, dtype=torch.float32, device=dev)
+    e_out = torch.empty(E, dtype=torch.float32, device=dev) if want_out else None
     g = getattr(plan, "_struct", None)
     if g is None or plan._struct_dev != dev:
         g = plan._struct = plan_struct(plan)
@@ -698,9 +699,12 @@ def segclf_forward_train_plan(plan, seg_ptr, n_segments_valid, weights, F, D, n_
     p = params_struct(weights, F, D, flags)
     with _on(plan.X, g, p) as st:
         rc = load().gnn_segclf_forward_train_plan(ctypes.byref(g), ctypes.byref(p), n_iters,
-                                                  _dev(seg_ptr, torch.int32, "seg_ptr"), e_all.data_ptr(), H_all.data_ptr(),
-                                                  Q_all.data_ptr(), e_out.data_ptr(), workspace.data_ptr(),
-                                                  workspace.numel(), st)
+                                                  _dev(seg_ptr, torch.int32, "seg_ptr"),
+                                                  None if tw_src is None else _dev(tw_src, torch.int32, "tw_src"),
+                                                  None if tw_dst is None else _dev(tw_dst, torch.int32, "tw_dst"),
+                                                  e_all.data_ptr(), H_all.data_ptr(),
+                                                  Q_all.data_ptr(), None if e_out is None else e_out.data_ptr(),
+                                                  workspace.data_ptr(), workspace.numel(), st)
     if rc == GNN_ERR_UNSUPPORTED:
         return None
     _check(rc)

@@ -156,8 +156,9 @@ __device__ __forceinline__ void csr_walk(int k0, int k1, RowOf row_of, WOf w_of,
 // forward of the plan-based pipeline (sell_pipeline.hip)
 int sell_forward(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e_out, void *ws,
                  size_t ws_bytes, hipStream_t s);
-int sell_forward_train(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, const int32_t *seg_ptr, float *e_all,
-                       float *H_all, float *Q_all, int ldh, float *e_out, void *ws, size_t ws_bytes, hipStream_t s);
+int sell_forward_train(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, const int32_t *seg_ptr,
+                       const int32_t *tw_src, const int32_t *tw_dst, float *e_all, float *H_all, float *Q_all, int ldh,
+                       float *e_out, void *ws, size_t ws_bytes, hipStream_t s);
 size_t sell_workspace_bytes(int64_t n_hits, int64_t n_segments, int F, int D);
 int sell_shape_supported(int F, int D);
 int sell_limits(int F, int D, int32_t *out4);

@@ -1436,23 +1436,26 @@ int gnn_segclf_forward_plan(const gnn_plan_t *pl, const gnn_params_t *p, int32_t
 }
 
 int gnn_segclf_forward_train_plan(const gnn_plan_t *pl, const gnn_params_t *p, int32_t n_iters,
-                                  const int32_t *seg_ptr, float *e_all, float *H_all, float *Q_all,
-                                  float *e_out, void *workspace, size_t workspace_bytes, void *stream)
+                                  const int32_t *seg_ptr, const int32_t *tw_src, const int32_t *tw_dst, float *e_all,
+                                  float *H_all, float *Q_all, float *e_out, void *workspace, size_t workspace_bytes,
+                                  void *stream)
 {
     if (!pl || !p || n_iters < 0 || pl->n_pad < 0 || pl->n_segments < 0 || pl->n_tiles < 0 ||
         pl->n_chunks < 0 || (pl->n_pad & 15) || pl->iter_lds_records < 0 || pl->edge_lds_rows < 0)
         return fail(GNN_ERR_BADARG, "gnn_segclf_forward_train_plan: bad argument");
     if (!pl->X || !pl->in_off || !pl->out_off || !pl->in_nbr || !pl->out_nbr || (pl->n_tiles > 0 && !pl->tiles) ||
-        (pl->n_segments > 0 && (!pl->src || !pl->dst || !pl->sd16 || !pl->chunks || !e_out || !e_all)))
+        (pl->n_segments > 0 && (!pl->src || !pl->dst || !pl->sd16 || !pl->chunks || !e_all)))
         return fail(GNN_ERR_BADARG, "gnn_segclf_forward_train_plan: plan array missing");
+    if (pl->n_segments > 0 && ((!tw_src != !tw_dst) || (!e_out && !tw_src)))
+        return fail(GNN_ERR_BADARG, "gnn_segclf_forward_train_plan: e_out or the (tw_src, tw_dst) pair is needed");
     if (pl->n_pad > 0 && (!seg_ptr || !H_all || (n_iters > 0 && !Q_all)))
         return fail(GNN_ERR_BADARG, "gnn_segclf_forward_train_plan: output array missing");
     if (!p->Win || !p->bin || !p->W1 || !p->b1 || !p->W2 || !p->b2 || !p->W3 || !p->b3 || !p->W4 || !p->b4)
         return fail(GNN_ERR_BADARG, "gnn_segclf_forward_train_plan: weight pointer missing");
     const int ldh = gnn_h_stride(p->F, p->D);
     if (ldh <= 0) return fail(GNN_ERR_UNSUPPORTED, "no HIP kernel for input_dim=%d hidden_dim=%d", p->F, p->D);
-    return sell_forward_train(pl, p, n_iters, seg_ptr, e_all, H_all, Q_all, ldh, e_out, workspace, workspace_bytes,
-                              static_cast<hipStream_t>(stream));
+    return sell_forward_train(pl, p, n_iters, seg_ptr, tw_src, tw_dst, e_all, H_all, Q_all, ldh, e_out, workspace,
+                              workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
 int gnn_exp_product_bound(const gnn_params_t *p, const float *x_absmax, float *bound_out,

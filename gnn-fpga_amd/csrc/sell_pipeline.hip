@@ -3016,6 +3016,32 @@ __global__ __launch_bounds__((Cfg<F, D>::NT)) void k_edge(
     }
 }
 
+// The final scores once more, in the order of the plan-space batch the backward runs on (gnn_segclf_forward_train_plan:
+// row T of e_all): one lane per segment of THAT batch, endpoints = plan hit ids (-1: padded -> the NULL rows), the same
+// arithmetic as k_edge in the same order (the same bits for the same segment).  Its segments are sorted by end hit, so
+// the Q rows stream and the P rows stay L2-local - 22 us at c3 x 32 where gathering k_edge's output into that order by
+// a 4-byte permutation cost 35.
+template <int F, int D, bool XP>
+__global__ __launch_bounds__(256) void k_edge_tw(const int32_t *__restrict__ src, const int32_t *__restrict__ dst,
+                                                 const float *__restrict__ Pc, const float *__restrict__ Qc,
+                                                 const float *__restrict__ table, float *__restrict__ e, int64_t n_pad,
+                                                 int64_t n_segments)
+{
+    const float *__restrict__ W2 = table + TL<F, D>::o_flat;   // wave-uniform: scalar loads
+    const int64_t j = xcd_block() * 256 + threadIdx.x;
+    if (j >= n_segments) return;
+    int s = src[j], d = dst[j];
+    if (s < 0) s = d = (int)n_pad;
+    float p[D], qq[D];
+    load_vec<D>(Pc + (int64_t)s * D, p);
+    load_vec<D>(Qc + (int64_t)d * D, qq);
+    float acc = W2[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+        acc = fmaf(W2[k], XP ? __builtin_amdgcn_rcpf(fmaf(p[k], qq[k], 1.0f)) : r_f(p[k] + qq[k]), acc);
+    e[j] = r_f(acc);
+}
+
 // final edge pass for wide hidden layers (no LDS windows): 16 lanes per segment, lane p owns dims
 // DL p .. of the start hit's P row and the end hit's Q row - a row is read as whole 128-byte lines
 // by the 16 lanes (one lane per segment made every load instruction touch 64 different rows:
@@ -3415,8 +3441,9 @@ int forward_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, float *e
 // order).  H_all [(T + 1), n_pad, ldh], Q_all [T, n_pad, D].  Shapes on the general tile kernel only (D <= 16
 // without the wide route); others: GNN_ERR_UNSUPPORTED (the caller keeps the per-module route).
 template <int F, int D, bool XP>
-int forward_train_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, const int32_t *seg_ptr, float *e_all,
-                    float *H_all, float *Q_all, int ldh, float *e_out, char *ws, hipStream_t s)
+int forward_train_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, const int32_t *seg_ptr,
+                    const int32_t *tw_src, const int32_t *tw_dst, float *e_all, float *H_all, float *Q_all, int ldh,
+                    float *e_out, char *ws, hipStream_t s)
 {
     using L = TL<F, D>;
     using G = Cfg<F, D>;
@@ -3461,7 +3488,7 @@ int forward_train_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, co
                 float *t2 = QS; QS = QSn; QSn = t2;
             }
         }
-        if (E > 0) {
+        if (E > 0 && e_out) {
             const int nc = (int)pl->n_chunks;
             const int cpx = (nc + 7) / 8;
             const size_t ed_lds = (size_t)((G::ed_rec > 0 ? pl->edge_lds_rows : 0) * D + 4) * sizeof(float);
@@ -3471,6 +3498,9 @@ int forward_train_t(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, co
             GNN_LAUNCH_SH("k_edge", (k_edge<F, D, XP>), 8 * cpx, G::NT, ed_lds, s, pl->chunks, pl->src, pl->dst, pl->sd16, w.Pc,
                           w.Qc, w.table, e_out, Np, cpx, nc);
         }
+        if (E > 0 && tw_src)      // row T of e_all: the final scores in the backward's own segment order
+            GNN_LAUNCH("k_edge_tw", (k_edge_tw<F, D, XP>), grid_for(E), 256, s, tw_src, tw_dst, w.Pc, w.Qc, w.table,
+                       e_all + (size_t)n_iters * E, Np, E);
         return 0;
     }
 }
@@ -3525,8 +3555,9 @@ size_t sell_workspace_bytes(int64_t n_pad, int64_t n_segments, int F, int D)
     return 0;
 }
 
-int sell_forward_train(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, const int32_t *seg_ptr, float *e_all,
-                       float *H_all, float *Q_all, int ldh, float *e_out, void *ws, size_t ws_bytes, hipStream_t s)
+int sell_forward_train(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters, const int32_t *seg_ptr,
+                       const int32_t *tw_src, const int32_t *tw_dst, float *e_all, float *H_all, float *Q_all, int ldh,
+                       float *e_out, void *ws, size_t ws_bytes, hipStream_t s)
 {
     ProfChain chain_;
     const size_t need = sell_workspace_bytes(pl->n_pad, pl->n_segments, p->F, p->D);
@@ -3536,8 +3567,8 @@ int sell_forward_train(const gnn_plan_t *pl, const gnn_params_t *p, int n_iters,
 #define X_(F_, D_)                                                                                        \
     if (p->F == F_ && p->D == D_)                                                                        \
         return (p->flags & GNN_FLAG_EXP_PRODUCT)                                                         \
-                   ? forward_train_t<F_, D_, true>(pl, p, n_iters, seg_ptr, e_all, H_all, Q_all, ldh, e_out, base, s)  \
-                   : forward_train_t<F_, D_, false>(pl, p, n_iters, seg_ptr, e_all, H_all, Q_all, ldh, e_out, base, s);
+                   ? forward_train_t<F_, D_, true>(pl, p, n_iters, seg_ptr, tw_src, tw_dst, e_all, H_all, Q_all, ldh, e_out, base, s)  \
+                   : forward_train_t<F_, D_, false>(pl, p, n_iters, seg_ptr, tw_src, tw_dst, e_all, H_all, Q_all, ldh, e_out, base, s);
     SELL_FOR_EACH_SHAPE(X_)
 #undef X_
     return fail(GNN_ERR_UNSUPPORTED, "unreachable");

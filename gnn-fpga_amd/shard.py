@@ -124,7 +124,8 @@ class GradBucket:
             if lay is None:
                 from .autograd import training_batch
                 batch = training_batch(model, batch, False)      # level-ordered twin: L2-local gathers
-            fused = _lib.segclf_forward_train_fused(batch, w, F, D, T) if lay is None else None
+            # (the loss below is taken in the twin's segment order: no copy of the scores in the caller's order)
+            fused = _lib.segclf_forward_train_fused(batch, w, F, D, T, want_out=False) if lay is None else None
             if fused is not None:
                 e_all, H_all, Q_all, _ = fused
             else:

@@ -237,13 +237,16 @@ int gnn_segclf_forward_plan(const gnn_plan_t *plan, const gnn_params_t *p, int32
  * (in_ptr).  Written: e_all rows 0 .. n_iters-1 ([n_iters + 1, n_segments]; the scores of every pass
  * in THAT segment order, valid segments only - padded ones are never read by the backward's list
  * walks), H_all [(n_iters + 1), n_pad, ldh] (ldh = gnn_h_stride), Q_all [n_iters, n_pad, D] and the
- * final scores e_out [n_segments] in the PLAN's segment order (the caller's); row n_iters of e_all is
- * the caller's to fill (a gather of e_out).  Shapes on the general tile kernel only (hidden_dim <= 16
- * without the 16-lanes-per-hit route): GNN_ERR_UNSUPPORTED otherwise.  Workspace as
- * gnn_segclf_forward_plan. */
+ * final scores e_out [n_segments] in the PLAN's segment order (the caller's; NULL: not wanted).  Row
+ * n_iters of e_all - the final scores in the backward's order - is written when tw_src / tw_dst
+ * [n_segments] are given: that batch's segment endpoints as plan hit ids, -1 = padded (same bits as
+ * e_out for the same segment); with NULL the row is the caller's to fill (a gather of e_out).  Shapes
+ * on the general tile kernel only (hidden_dim <= 16 without the 16-lanes-per-hit route):
+ * GNN_ERR_UNSUPPORTED otherwise.  Workspace as gnn_segclf_forward_plan. */
 int gnn_segclf_forward_train_plan(const gnn_plan_t *plan, const gnn_params_t *p, int32_t n_iters,
-                                  const int32_t *seg_ptr, float *e_all, float *H_all, float *Q_all,
-                                  float *e_out, void *workspace, size_t workspace_bytes, void *stream);
+                                  const int32_t *seg_ptr, const int32_t *tw_src, const int32_t *tw_dst,
+                                  float *e_all, float *H_all, float *Q_all, float *e_out /* or NULL */,
+                                  void *workspace, size_t workspace_bytes, void *stream);
 /* 1 if the fused pipeline has kernels for this (input_dim, hidden_dim). */
 int gnn_plan_shape_supported(int32_t F, int32_t D);
 /* Plan-building limits for a shape: out4 = { tile_hits, iter_records, chunk_segments,

@@ -890,6 +890,11 @@ def test_fused_training_forward_keeps_what_the_per_module_one_keeps(hip, F, D, T
         assert (Q_f - Q_p).abs().max().item() < 2e-6
     # final scores in the caller's order: the twin's, gathered back
     assert (out_f - e_p[T].index_select(0, twin.seg_rank)).abs().max().item() < 2e-6
+    # row T of e_all (k_edge_tw, the twin's order) holds the same bits as e_out (k_edge, the caller's order), padded
+    # segments included; without e_out (a loss taken in the twin's order) it is still written
+    assert torch.equal(e_f[T], out_f.index_select(0, twin.seg_order))
+    e_f2, _, _, none = _lib.segclf_forward_train_fused(twin, w, F, D, T, want_out=False)
+    assert none is None and torch.equal(e_f2[T], e_f[T])
     go = torch.rand(b.n_segments, device="cuda")
     g_f = _lib.segclf_backward(twin, w, F, D, T, e_f, H_f, go, Q_all=Q_f)
     g_p = _lib.segclf_backward(twin, w, F, D, T, e_p, H_p, go, Q_all=Q_p)
