@@ -13,7 +13,7 @@ import torch  # imported first: its bundled libamdhip64.so.7 is the one HIP runt
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgnn_hip.so")
 
-GNN_ABI_VERSION = 4
+GNN_ABI_VERSION = 5
 GNN_ERR_UNSUPPORTED = -10001
 GNN_ERR_BADARG = -10002
 GNN_ERR_WORKSPACE = -10003
@@ -111,6 +111,8 @@ SIGNATURES = {
     "gnn_plan_build_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "gnn_plan_build_sizes": (ctypes.c_int, [_f, _f, _f, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _f, _sz,
                                             _f, _f]),
+    "gnn_plan_build_sizes_graphs": (ctypes.c_int, [_f, _f, _f, _f, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32,
+                                                   _f, _sz, _f, _f]),
     "gnn_plan_build_fill": (ctypes.c_int, [_f, _i32, _f, _f, _i64, _i64, _i32, ctypes.POINTER(GnnPlanSizes),
                                            _f, _sz, ctypes.POINTER(GnnPlanOut), _f]),
     "gnn_profile_begin": (ctypes.c_int, [_i32]),
@@ -715,16 +717,28 @@ def plan_build_workspace_bytes(n_hits, n_segments, chunk_segments):
     return int(load().gnn_plan_build_workspace_bytes(n_hits, n_segments, chunk_segments))
 
 
+PLAN_GRAPH_CAP_HITS = 16384      # csrc/plan_build.hip kGraphCapHits: LDS tables and sort keys of the graph-local stage 1
+PLAN_STATUS_FAST_MISS = 128
+
+
 def plan_build_sizes(src, dst, hit_ptr, n_hits, n_segments, n_graphs, tile_hits, iter_records,
-                     chunk_segments, edge_records, workspace):
+                     chunk_segments, edge_records, workspace, seg_ptr=None, max_graph_hits=0, max_graph_segments=0):
     """Stage 1 of the GPU plan builder (csrc/plan_build.hip).  Returns a GnnPlanSizes read back from
-    the device - the ONE host synchronisation of a plan build."""
+    the device - the ONE host synchronisation of a plan build.  With `seg_ptr` (device int64 [G+1]) the
+    graph-local form runs (gnn_plan_build_sizes_graphs); status bit PLAN_STATUS_FAST_MISS = call again without."""
     sizes = torch.zeros(ctypes.sizeof(GnnPlanSizes) // 8, dtype=torch.int64, device=src.device)
     with _on(src) as st:
-        _check(load().gnn_plan_build_sizes(
-            _dev(src, torch.int32, "src"), _dev(dst, torch.int32, "dst"), _dev(hit_ptr, torch.int64, "hit_ptr"),
-            n_hits, n_segments, n_graphs, tile_hits, iter_records, chunk_segments, edge_records,
-            workspace.data_ptr(), workspace.numel(), sizes.data_ptr(), st))
+        if seg_ptr is not None:
+            _check(load().gnn_plan_build_sizes_graphs(
+                _dev(src, torch.int32, "src"), _dev(dst, torch.int32, "dst"), _dev(hit_ptr, torch.int64, "hit_ptr"),
+                _dev(seg_ptr, torch.int64, "seg_ptr"), int(max_graph_hits), int(max_graph_segments),
+                n_hits, n_segments, n_graphs, tile_hits, iter_records, chunk_segments, edge_records,
+                workspace.data_ptr(), workspace.numel(), sizes.data_ptr(), st))
+        else:
+            _check(load().gnn_plan_build_sizes(
+                _dev(src, torch.int32, "src"), _dev(dst, torch.int32, "dst"), _dev(hit_ptr, torch.int64, "hit_ptr"),
+                n_hits, n_segments, n_graphs, tile_hits, iter_records, chunk_segments, edge_records,
+                workspace.data_ptr(), workspace.numel(), sizes.data_ptr(), st))
     host = sizes.cpu()
     out = GnnPlanSizes()
     ctypes.memmove(ctypes.byref(out), host.data_ptr(), ctypes.sizeof(GnnPlanSizes))

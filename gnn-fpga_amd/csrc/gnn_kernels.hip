@@ -51,8 +51,19 @@ struct Profiler {
 };
 Profiler g_prof;
 
+// GNN_DEBUG_SYNC=1: every launch is named on stderr and waited for - the last name printed before a GPU fault is
+// the kernel that raised it (a debugging switch; never set in measurements)
+static const char *g_dbg_name = nullptr;
+static bool debug_sync()
+{
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("GNN_DEBUG_SYNC"); on = (e && e[0] == '1') ? 1 : 0; }
+    return on == 1;
+}
+
 void prof_pre(const char *name, hipStream_t s)
 {
+    if (debug_sync()) g_dbg_name = name;
     if (g_prof.on && g_prof.n < g_prof.cap) {
         g_prof.name[g_prof.n] = name;
         if (g_prof.chain && g_prof.have_prev && g_prof.n > 0) {
@@ -65,6 +76,11 @@ void prof_pre(const char *name, hipStream_t s)
 }
 void prof_post(hipStream_t s)
 {
+    if (debug_sync()) {
+        fprintf(stderr, "[gnn] %s\n", g_dbg_name ? g_dbg_name : "?");
+        fflush(stderr);
+        (void)hipStreamSynchronize(s);
+    }
     if (g_prof.on && g_prof.n < g_prof.cap) {
         (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], s);
         g_prof.n++;

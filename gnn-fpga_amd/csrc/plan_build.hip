@@ -88,9 +88,11 @@ struct Ws {
     // padded hits / slices
     I2 *degn, *ptr;                            // (in, out) degree and CSR pointer per new id
     I4 *sl4, *off4;                            // per slice: (16 steps_in, 16 steps_out, 16 ceil8 in, 16 ceil8 out), scanned
+    int *slice_tile;                           // tile of a slice (pb_tile_windows -> pb_fill_lists)
     // segments
     int *src_new, *dst_new, *kscr, *sv_in, *sv_out, *c_scan, *rb;
     int *mscan, *marks, *parts, *pscan, *cb, *c_desc;  // c_desc: [c_max][8]
+    I2 *pin, *pout;                            // graph-local form: (segment, other end) pairs in list places
     void *temp;
     size_t temp_bytes;
     size_t bytes;
@@ -147,11 +149,14 @@ Ws carve(char *p, int64_t n, int64_t E, int CH)
     w.ptr = reinterpret_cast<I2 *>(take((size_t)(b.np_max + 1) * sizeof(I2)));
     w.sl4 = reinterpret_cast<I4 *>(take((size_t)(b.ns_max + 1) * sizeof(I4)));
     w.off4 = reinterpret_cast<I4 *>(take((size_t)(b.ns_max + 1) * sizeof(I4)));
+    w.slice_tile = ints(b.ns_max + 1);
     w.src_new = ints(E); w.dst_new = ints(E); w.kscr = ints(E + 1); w.sv_in = ints(E); w.sv_out = ints(E);
     w.c_scan = ints(E + 1); w.rb = ints(E + 2);
     w.mscan = ints(E + 1);
     w.marks = ints(b.m_max + 2); w.parts = ints(b.m_max + 2); w.pscan = ints(b.m_max + 2);
     w.cb = ints(b.c_max + 2); w.c_desc = ints((b.c_max + 1) * 8);
+    w.pin = reinterpret_cast<I2 *>(take((size_t)E * sizeof(I2)));
+    w.pout = reinterpret_cast<I2 *>(take((size_t)E * sizeof(I2)));
     w.temp_bytes = rocprim_temp_bytes(n, E, b);
     w.temp = take(w.temp_bytes);
     w.bytes = off;
@@ -361,6 +366,307 @@ __global__ __launch_bounds__(1024) void pb_levels_small(const int *__restrict__ 
     }
 }
 
+// ---- graph-local stage 1 (ABI 5: gnn_plan_build_sizes_graphs) -------------------------------------------
+// When the caller names the graphs' segment ranges (seg_ptr: graph g owns segments [seg_ptr[g], seg_ptr[g+1]) and
+// they join hits of [hit_ptr[g], hit_ptr[g+1]) only - what merge_graphs' block-diagonal batches are,
+// gnn/trainSegmentClassifier.py:66-95), degrees, levels and the first sort key are ONE launch: a workgroup per
+// graph keeps the graph's levels and degree counters in LDS (8 bytes per hit) and walks the graph's segments a few
+// times - where the global form above walks ALL segments once per level (12 launches for a 10-layer detector) after
+// a pass of global atomics for the degrees: 1.6 of the 5.7 ms of a c3 x 256 plan.
+//   round 1: degrees (LDS atomics; in | out counts share a word, a half that would wrap reports FAST_MISS) and a
+//            first asynchronous relaxation  level[d] = max(level[d], level[s] + 1)  (LDS atomicMax);
+//   round r >= 2: the same relaxation until a round raises nothing.  The fixpoint of the asynchronous iteration is
+//            the longest walk ending at each hit - the Jacobi iterate of plan.topological_levels once it has
+//            converged, whatever the order of the updates.  A level above kMaxLevelIters (a deeper graph or a
+//            cycle: the capped Jacobi iterate is something else there) reports FAST_MISS.  Segments grouped by layer
+//            pair in ascending order (gnn/graph.py:80-93) converge in round 1 or 2; one more round sees no change.
+//   the "one below the nearest end hit" rule for hits without incoming segments (pb_down / pb_key1) rides in the
+//            same rounds: such a hit's level is 0 by definition, so its LDS word is free to hold
+//            min(level[d]) over its outgoing segments; it is reset before every round and only the last round's
+//            value - taken from levels that no longer moved - is used.
+// The workgroup checks what it was told: a valid segment with an end outside its graph's hit range, hit / segment
+// ranges that do not tile [0, n) / [0, E), a graph larger than the LDS capacity: FAST_MISS, and the caller runs the
+// global form (every output of this kernel is rewritten there).
+constexpr int ST_FAST_MISS = 128;
+constexpr int kGraphLdsBytes = 152 * 1024;
+constexpr int kGraphCapHits = 16384;                       // hits per graph: 8 bytes of tables, then 8-byte sort keys
+__host__ __device__ inline int pow2_ceil(int v) { int p = 2; while (p < v) p <<= 1; return p; }
+
+// bitonic sort of M (a power of two) 64-bit words in LDS, ascending; every thread of the workgroup calls.
+// A step costs an LDS round trip whatever the number of compare-exchanges, and a workgroup barrier on top of it
+// costs several times that (16 waves: ~0.4 us per step, 105 steps for 16 k words).  Wave w therefore owns the pairs
+// [w PW, (w + 1) PW) of a step: for strides j <= PW both words of its pairs lie in its own 2 PW words, and such steps
+// need no workgroup barrier - the wave's LDS operations complete in order (a wave-level fence keeps the compiler from
+// moving them).  Only the strides above PW (10 of the 105 steps at 16 k words and 16 waves) meet at __syncthreads().
+__device__ __forceinline__ void bitonic_sort_lds(unsigned long long *a, int M)
+{
+    const int nw = (int)(blockDim.x >> 6), w = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    const int PW = (M >> 1) / nw;                       // pairs per wave (0 for tiny M: every step at the barrier)
+    for (int k = 2; k <= M; k <<= 1) {
+        __syncthreads();                                // (the wave-local steps of the k before)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const bool local = PW >= 64 && j <= PW;
+            const int i0 = local ? w * PW + lane : (int)threadIdx.x, i1 = local ? (w + 1) * PW : (M >> 1);
+            const int st = local ? 64 : (int)blockDim.x;
+            for (int i = i0; i < i1; i += st) {
+                const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo | j;
+                const bool up = (lo & k) == 0;
+                const unsigned long long x = a[lo], y = a[hi];
+                if ((x > y) == up) { a[lo] = y; a[hi] = x; }
+            }
+            if (local) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            } else {
+                __syncthreads();
+            }
+        }
+    }
+    __syncthreads();
+}
+constexpr int kFastMaxDegree = 1024;                       // pb_sort_lists ranks a list in O(deg^2 / 16)
+
+__global__ __launch_bounds__(1024) void pb_graph_levels(const int *__restrict__ src, const int *__restrict__ dst,
+                                                        const int64_t *__restrict__ hit_ptr,
+                                                        const int64_t *__restrict__ seg_ptr, int64_t G, int64_t n, int64_t E,
+                                                        int cap, int *deg_in, int *deg_out, int *gid, int *level,
+                                                        unsigned long long *key, int *iota, int *hkey, int *run_flag,
+                                                        int *base, int *uflag, int64_t *hdr)
+{
+    extern __shared__ int lds[];
+    int *lvl = lds;                                              // [cap]
+    unsigned *dio = reinterpret_cast<unsigned *>(lds + cap);     // [cap]  in-degree | out-degree << 16
+    __shared__ int red[16];
+    const int B = (int)blockDim.x;
+    int cnt = 0, bad = 0, miss = 0, lmax = 0;
+    for (int64_t g = blockIdx.x; g < G; g += gridDim.x) {
+        const int64_t h0 = hit_ptr[g], h1 = hit_ptr[g + 1], e0 = seg_ptr[g], e1 = seg_ptr[g + 1];
+        bool ok = h0 <= h1 && e0 <= e1 && h1 - h0 <= cap && h0 >= 0 && h1 <= n && e0 >= 0 && e1 <= E;
+        if (g == 0 && (h0 != 0 || e0 != 0)) ok = false;
+        if (g == G - 1 && (h1 != n || e1 != E)) ok = false;
+        if (!ok) { miss = 1; continue; }                         // (workgroup-uniform)
+        const int nh = (int)(h1 - h0), lo = (int)h0, hi = (int)h1;
+        __syncthreads();
+        for (int i = threadIdx.x; i < nh; i += B) { lvl[i] = 0; dio[i] = 0u; }
+        __syncthreads();
+        // (four segments per thread in flight: one workgroup per CU has only its own loads to hide their latency)
+        for (int64_t jb = e0 + threadIdx.x; jb < e1; jb += 4 * (int64_t)B) {
+            int sv[4], dv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t j = jb + (int64_t)u * B;
+                sv[u] = j < e1 ? src[j] : -1;
+                dv[u] = j < e1 ? dst[j] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int s = sv[u], d = dv[u];
+                if (s < 0 && d < 0) continue;
+                if (!seg_ok(s, d, (int)n)) { bad = 1; continue; }
+                if (s < lo || s >= hi || d < lo || d >= hi) { miss = 1; continue; }
+                ++cnt;
+                const unsigned a = atomicAdd(&dio[d - lo], 1u), b = atomicAdd(&dio[s - lo], 0x10000u);
+                if ((a & 0xFFFFu) == 0xFFFFu || (b >> 16) == 0xFFFFu) miss = 1;
+                atomicMax(&lvl[d - lo], lvl[s - lo] + 1);
+            }
+        }
+        __syncthreads();
+        int round = 2;
+        bool over = false;
+        for (; round <= kMaxLevelIters + 2; ++round) {
+            for (int i = threadIdx.x; i < nh; i += B) {
+                const unsigned w = dio[i];
+                if ((w & 0xFFFFu) == 0u && (w >> 16) != 0u) lvl[i] = 0x7FFFFFFF;
+            }
+            __syncthreads();
+            int changed = 0, deep = 0;
+            for (int64_t jb = e0 + threadIdx.x; jb < e1; jb += 4 * (int64_t)B) {
+                int sv[4], dv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t j = jb + (int64_t)u * B;
+                    sv[u] = j < e1 ? src[j] : -1;
+                    dv[u] = j < e1 ? dst[j] : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int s = sv[u], d = dv[u];
+                    if (s < lo || s >= hi || d < lo || d >= hi) continue;
+                    const bool root = (dio[s - lo] & 0xFFFFu) == 0u;
+                    const int v = (root ? 0 : lvl[s - lo]) + 1;
+                    const int old = atomicMax(&lvl[d - lo], v);
+                    if (old < v) { changed = 1; if (v > kMaxLevelIters) deep = 1; }
+                    if (root) atomicMin(&lvl[s - lo], old > v ? old : v);
+                }
+            }
+            over = __syncthreads_or(deep) != 0;
+            if (over || !__syncthreads_or(changed)) break;
+        }
+        if (over || round > kMaxLevelIters + 2) { miss = 1; continue; }
+        for (int i = threadIdx.x; i < nh; i += B) {
+            const unsigned w = dio[i];
+            const int di = (int)(w & 0xFFFFu), dout = (int)(w >> 16);
+            int lv = lvl[i];
+            if (di == 0) { lv = dout > 0 ? lv - 1 : 0; if (lv < 0) lv = 0; }
+            if (di > kFastMaxDegree || dout > kFastMaxDegree) miss = 1;
+            lmax = lv > lmax ? lv : lmax;
+            const int h = lo + i;
+            deg_in[h] = di; deg_out[h] = dout; level[h] = lv; gid[h] = (int)g; iota[h] = h;
+            hkey[h] = (int)g * 128 + (lv & 127);
+            key[h] = ((unsigned long long)(unsigned)g << 39) | ((unsigned long long)(lv & 127) << 32) |
+                     ((unsigned long long)(0xFFFF - di) << 16) | (unsigned long long)(0xFFFF - dout);
+            lvl[i] = lv;
+        }
+        __syncthreads();
+        // run starts of the (graph, start level) key for the edge chunks (pb_seg_keys + carry scan + pb_run_flags of
+        // the global form): segment 0, and every valid segment whose start hit's level differs from that of the
+        // valid segment before it - the first valid segment of a graph always does (its key names another graph).
+        for (int64_t j = e0 + threadIdx.x; j < e1; j += B) {
+            const int s = src[j];
+            int f = 0;
+            if (j == 0) f = 1;
+            else if (s >= lo && s < hi) {
+                int64_t q = j - 1;
+                int ps = -1;
+                for (; q >= e0; --q) { ps = src[q]; if (ps >= 0) break; }
+                f = q < e0 ? 1 : ((ps >= lo && ps < hi) ? (lvl[ps - lo] != lvl[s - lo] ? 1 : 0) : 1);
+            }
+            run_flag[j] = f;
+        }
+        if (g == G - 1 && threadIdx.x == 0) { run_flag[E] = 0; uflag[n] = 0; }
+        // The first hit sort of the global form - (graph, level, -in degree, -out degree), stable in the hit id - is
+        // local to the graph: the keys this workgroup just wrote, with the hit's local id below them, sorted in LDS
+        // (the level / degree tables are done with).  Rank r of the graph is rank hit_ptr[g] + r of the batch; a
+        // (graph, level) unit starts where the level changes (pb_unit_flags).
+        __syncthreads();
+        if (nh > 0) {
+            unsigned long long *a = reinterpret_cast<unsigned long long *>(lds);
+            const int M = pow2_ceil(nh);
+            for (int i = threadIdx.x; i < M; i += B)
+                a[i] = i < nh ? ((key[lo + i] & ((1ull << 39) - 1ull)) << 15) | (unsigned long long)i : ~0ull;
+            __syncthreads();
+            bitonic_sort_lds(a, M);
+            for (int r = threadIdx.x; r < nh; r += B) {
+                const unsigned long long e = a[r];
+                base[lo + r] = lo + (int)(e & 0x7FFFull);
+                uflag[lo + r] = (r == 0 || (a[r - 1] >> 47) != (e >> 47)) ? 1 : 0;
+            }
+        }
+    }
+    cnt = block_reduce_i(cnt, red, OpAdd());
+    bad = block_reduce_i(bad, red, OpOr());
+    miss = block_reduce_i(miss, red, OpOr());
+    lmax = block_reduce_i(lmax, red, OpMax());
+    if (threadIdx.x == 0) {
+        if (cnt) hdr_add(hdr, H_NVALID, cnt);
+        if (bad) set_status(hdr, ST_ENDPOINT);
+        if (miss) set_status(hdr, ST_FAST_MISS);
+        hdr_max(hdr, H_MAXLEVEL, lmax);
+    }
+}
+
+// Renumbered endpoints and both neighbour lists of a graph without a device-wide sort: the lists' places are known
+// (ptr = scan of the degrees in new ids), a workgroup per graph keeps one cursor per hit in LDS (and the graph's new
+// ids, when they fit) and drops (segment, other end) pairs into the lists in whatever order its atomics come;
+// pb_sort_lists then puts every list into ascending segment order - what the two stable radix sorts of (end hit,
+// other end) pairs delivered (1.2 ms + pb_renumber's 0.3 at c3 x 256; this pair of kernels: 0.6-0.77 + 0.37 ms).
+// Status 0 here means every segment with src >= 0 is valid and graph-local (pb_graph_levels).
+// One direction per pass: the 8-byte pairs land at random places of the lists of one detector level at a time (80 KB
+// per direction for the 10 k segments of a layer pair); the streams bypass the cache (nontemporal), the second pass
+// reads src / dst once more.  What bounds it (rocprofv3 TCC_EA0_WRREQ: 46 M write requests, 31 M of them partial, 1.9
+// GB for 0.6 GB of payload): the L2 hands most pairs on as writes of their own.  Measured and dropped: every chunk of
+// 4096 segments sorted in LDS by (hit, position) so that places come in segment order and no list needs sorting
+// afterwards - bit-identical lists, but 78 barrier steps per chunk: 1.7-1.9 ms.
+template <bool INV_LDS>
+__global__ __launch_bounds__(1024) void pb_graph_lists(const int *__restrict__ src, const int *__restrict__ dst,
+                                                       const int64_t *__restrict__ hit_ptr,
+                                                       const int64_t *__restrict__ seg_ptr, int64_t G, int n, int cap,
+                                                       const int *__restrict__ inv, const I2 *__restrict__ ptr, int *src_new,
+                                                       int *dst_new, I2 *pin, I2 *pout, const int64_t *__restrict__ hdr)
+{
+    if (hdr[H_STATUS]) return;
+    extern __shared__ int lds[];
+    int *cin = lds, *cout = lds + cap, *linv = lds + 2 * cap;      // linv: new ids of the graph's hits (INV_LDS)
+    const int B = (int)blockDim.x;
+    const int npad = inv[n];
+    for (int64_t g = blockIdx.x; g < G; g += gridDim.x) {
+        const int64_t e0 = seg_ptr[g], e1 = seg_ptr[g + 1];
+        const int lo = (int)hit_ptr[g], nh = (int)(hit_ptr[g + 1] - hit_ptr[g]);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nh; i += B) {
+            const int nw = inv[lo + i];
+            const I2 p = ptr[nw];
+            cin[i] = p.a;
+            cout[i] = p.b;
+            if (INV_LDS) linv[i] = nw;
+        }
+        __syncthreads();
+        // (four segments per thread in flight; with the new ids in LDS the only global latency left is src / dst)
+        for (int pass = 0; pass < 2; ++pass)
+            for (int64_t jb = e0 + threadIdx.x; jb < e1; jb += 4 * (int64_t)B) {
+                int sv[4], dv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t j = jb + (int64_t)u * B;
+                    sv[u] = j < e1 ? __builtin_nontemporal_load(src + j) : -1;
+                    dv[u] = j < e1 ? __builtin_nontemporal_load(dst + j) : -1;
+                }
+                int sn[4], dn[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool ok = sv[u] >= 0;
+                    sn[u] = ok ? (INV_LDS ? linv[sv[u] - lo] : inv[sv[u]]) : npad;
+                    dn[u] = ok ? (INV_LDS ? linv[dv[u] - lo] : inv[dv[u]]) : npad;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t j = jb + (int64_t)u * B;
+                    if (j >= e1) continue;
+                    if (pass == 0) {
+                        __builtin_nontemporal_store(sn[u], src_new + j);
+                        __builtin_nontemporal_store(dn[u], dst_new + j);
+                    }
+                    if (sv[u] < 0) continue;
+                    if (pass == 0) pin[atomicAdd(&cin[dv[u] - lo], 1)] = I2{(int)j, sn[u]};
+                    else pout[atomicAdd(&cout[sv[u] - lo], 1)] = I2{(int)j, dn[u]};
+                }
+            }
+    }
+}
+
+// 16 lanes per padded hit: every lane takes one (segment, other end) pair of the hit's list, counts the pairs with a
+// smaller segment id (16 pairs at a time, passed round the group) and stores the other end at that rank.
+__global__ __launch_bounds__(TB) void pb_sort_lists(const I2 *__restrict__ degn, const I2 *__restrict__ ptr,
+                                                    const I2 *__restrict__ pin, const I2 *__restrict__ pout, int *sv_in,
+                                                    int *sv_out, const int64_t *__restrict__ hdr)
+{
+    if (hdr[H_STATUS]) return;
+    const int64_t n_pad = hdr[H_NPAD];
+    const int l = threadIdx.x & 15;
+    const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4, ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    for (int64_t h = grp; h < n_pad; h += ngrp) {
+        const I2 dg = degn[h], p = ptr[h];
+#pragma unroll
+        for (int dir = 0; dir < 2; ++dir) {
+            const int deg = dir ? dg.b : dg.a, p0 = dir ? p.b : p.a;
+            const I2 *__restrict__ pr = dir ? pout : pin;
+            int *sv = dir ? sv_out : sv_in;
+            for (int base = 0; base < deg; base += 16) {
+                const bool have = base + l < deg;
+                const I2 e = have ? pr[p0 + base + l] : I2{0x7FFFFFFF, 0};
+                int rank = 0;
+                for (int ob = 0; ob < deg; ob += 16) {
+                    const int oj = ob == base ? e.a : (ob + l < deg ? pr[p0 + ob + l].a : 0x7FFFFFFF);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) rank += __shfl(oj, k, 16) < e.a ? 1 : 0;
+                }
+                if (have) sv[p0 + rank] = e.b;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(TB) void pb_fill_i32(int *a, int64_t n, int v) { GS_LOOP(i, n) a[i] = v; }
 
 // (only hits without incoming segments use it: one segment in ten of a layered graph)
@@ -410,6 +716,9 @@ __global__ __launch_bounds__(TB) void pb_unit_flags(int64_t n, const unsigned lo
 __global__ __launch_bounds__(TB) void pb_compact(int64_t n, const int *__restrict__ flag, const int *__restrict__ scan,
                                                  int *out, int64_t *hdr, int slot)
 {
+    // a status set upstream (FAST_MISS: pb_graph_levels left a graph's keys / run flags unwritten) means flags and
+    // scan may hold anything: nothing is compacted, the count is 0 and the kernels behind see empty lists
+    if (hdr[H_STATUS]) { if (blockIdx.x == 0 && threadIdx.x == 0) hdr[slot] = 0; return; }
     GS_LOOP(p, n + 1) {
         if (p < n) {
             if (flag[p]) out[scan[p]] = (int)p;
@@ -520,6 +829,7 @@ __global__ __launch_bounds__(TB) void pb_key2(int64_t n, const int *__restrict__
                                               const int *__restrict__ deg_out, const int *__restrict__ tile_bounds,
                                               const int64_t *__restrict__ hdr, int *tpos, unsigned long long *key)
 {
+    if (hdr[H_STATUS]) return;             // (base[] may be the sorted image of unwritten ids)
     const int nt = (int)hdr[H_NTILES];
     GS_LOOP(p, n) {
         const int old = base[p];
@@ -527,6 +837,36 @@ __global__ __launch_bounds__(TB) void pb_key2(int64_t n, const int *__restrict__
         tpos[p] = t;
         key[p] = ((unsigned long long)(unsigned)t << 32) |
                  ((unsigned long long)(0xFFFF - ((deg_in[old] + 3) >> 2)) << 16) | (unsigned long long)(0xFFFF - deg_out[old]);
+    }
+}
+
+// The second hit sort of the global form - (tile, -ceil(in / 4), -out), stable in the first sort's order - is local
+// to a tile of at most kMaxSlicesPerTile * SLICE hits: one workgroup per tile sorts (key, position) words in LDS.
+__global__ __launch_bounds__(TB) void pb_tile_sort(int64_t n, const int *__restrict__ base, const int *__restrict__ deg_in,
+                                                   const int *__restrict__ deg_out, const int *__restrict__ tile_bounds,
+                                                   const int64_t *__restrict__ hdr, int *tpos, int *oor)
+{
+    __shared__ unsigned long long a[kMaxSlicesPerTile * SLICE];
+    if (hdr[H_STATUS]) return;
+    const int nt = (int)hdr[H_NTILES];
+    for (int t = blockIdx.x; t < nt; t += gridDim.x) {
+        const int p0 = tile_bounds[t], cnt = tile_bounds[t + 1] - p0;
+        if (cnt <= 0 || cnt > kMaxSlicesPerTile * SLICE) continue;      // (pb_cut_tiles never makes one)
+        const int M = pow2_ceil(cnt);
+        __syncthreads();
+        for (int i = threadIdx.x; i < M; i += TB) {
+            unsigned long long k = ~0ull;
+            if (i < cnt) {
+                const int old = base[p0 + i];
+                k = ((unsigned long long)(0xFFFF - ((deg_in[old] + 3) >> 2)) << 28) |
+                    ((unsigned long long)(0xFFFF - deg_out[old]) << 12) | (unsigned long long)i;
+                tpos[p0 + i] = t;
+            }
+            a[i] = k;
+        }
+        __syncthreads();
+        bitonic_sort_lds(a, M);
+        for (int r = threadIdx.x; r < cnt; r += TB) oor[p0 + r] = base[p0 + (int)(a[r] & 0xFFFull)];
     }
 }
 
@@ -631,7 +971,7 @@ __global__ __launch_bounds__(TB) void pb_slices(int64_t ns_max, const I2 *__rest
 __global__ __launch_bounds__(TB) void pb_tile_windows(const int *__restrict__ tpad_off, const int *__restrict__ sbase,
                                                       const I2 *__restrict__ degn, const I2 *__restrict__ ptr,
                                                       const int *__restrict__ sv_in, const int *__restrict__ sv_out,
-                                                      int iter_records, int *t_desc, int64_t *hdr)
+                                                      int iter_records, int *t_desc, int *slice_tile, int64_t *hdr)
 {
     if (hdr[H_STATUS]) return;
     const int nt = (int)hdr[H_NTILES];
@@ -639,6 +979,8 @@ __global__ __launch_bounds__(TB) void pb_tile_windows(const int *__restrict__ tp
     int m_rec = 0, m_in = 0, m_out = 0, n_lds = 0;      // (thread 0: this workgroup's tiles; one set of atomics at the end)
     for (int t = blockIdx.x; t < nt; t += gridDim.x) {
         const int h0 = tpad_off[t], h1 = tpad_off[t + 1];
+        // (pb_fill_lists finds a hit's tile here instead of a 12-step binary search over the tile offsets per hit)
+        for (int sl = h0 / SLICE + threadIdx.x; sl < h1 / SLICE; sl += TB) slice_tile[sl] = t;
         int ilo = 0x7FFFFFFF, ihi = -1, olo = 0x7FFFFFFF, ohi = -1;
         for (int h = h0 + threadIdx.x; h < h1; h += TB) {
             const I2 d = degn[h], p = ptr[h];
@@ -744,6 +1086,51 @@ __global__ __launch_bounds__(TB) void pb_marks(const int *__restrict__ rb, int64
             hdr[H_NMARKS] = nm;
         }
     }
+}
+
+// The marks of the graph-local form, one workgroup: runs in order, 1024 at a time, flagged ones compacted behind a
+// running count (a ballot prefix per wave, wave totals through LDS) - instead of a flag array and a scan over E + 1
+// entries for what are a few thousand runs.  More than kFastMaxRuns runs (shuffled segments): FAST_MISS.
+constexpr int64_t kFastMaxRuns = 1 << 18;
+__global__ __launch_bounds__(1024) void pb_marks_fast(const int *__restrict__ rb, int64_t E, int CH, int *marks, int64_t m_max,
+                                                      int64_t *hdr)
+{
+    __shared__ int wtot[16];
+    if (hdr[H_STATUS]) { if (threadIdx.x == 0) hdr[H_NMARKS] = 0; return; }
+    const int64_t nr = hdr[H_NRUNS];
+    if (nr > kFastMaxRuns) { if (threadIdx.x == 0) { set_status(hdr, ST_FAST_MISS); hdr[H_NMARKS] = 0; } return; }
+    const int thr = CH / 4 > 1 ? CH / 4 : 1;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int64_t carry = 0;
+    bool over = false;
+    for (int64_t r0 = 0; r0 < nr; r0 += 1024) {
+        const int64_t r = r0 + threadIdx.x;
+        int f = 0, pos = 0;
+        if (r < nr) {
+            pos = rb[r];
+            const bool big = rb[r + 1] - pos >= thr;
+            const bool big_prev = r > 0 && pos - rb[r - 1] >= thr;
+            f = (r == 0 || big || big_prev) ? 1 : 0;
+        }
+        const unsigned long long m = __ballot(f);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        __syncthreads();
+        if (lane == 0) wtot[wv] = __popcll(m);
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const int t = wtot[w]; if (w < wv) woff += t; tot += t; }
+        if (f) {
+            const int64_t at = carry + woff + before;
+            if (at < m_max) marks[at] = pos; else over = true;
+        }
+        carry += tot;
+    }
+    if (__syncthreads_or(over ? 1 : 0) || carry + 1 > m_max) {
+        if (threadIdx.x == 0) { set_status(hdr, ST_CHUNKS); hdr[H_NMARKS] = 0; }
+        return;
+    }
+    if (threadIdx.x == 0) { marks[carry] = (int)E; hdr[H_NMARKS] = carry; }
 }
 
 // one workgroup: parts per mark interval, their scan, the chunk bounds (equal parts of <= CH)
@@ -906,12 +1293,12 @@ template <bool IN>
 __global__ __launch_bounds__(TB) void pb_fill_lists(int64_t n_pad, const I2 *__restrict__ degn, const I2 *__restrict__ ptr,
                                                     const I4 *__restrict__ sl4, const I4 *__restrict__ off4,
                                                     const int *__restrict__ sv, const int *__restrict__ t_desc,
-                                                    const int *__restrict__ tpad_off, int nt, int *nbr, int *nbr16)
+                                                    const int *__restrict__ slice_tile, int *nbr, int *nbr16)
 {
     GS_LOOP(h, n_pad) {
         const int64_t s = h / SLICE;
         const int i = (int)(h % SLICE);
-        const int t = tile_of(tpad_off, nt, (int)h);
+        const int t = slice_tile[s];
         const int *td = t_desc + (int64_t)t * 8;
         const bool lds = td[6] != 0;
         const int lo = IN ? td[2] : td[4], cnt = IN ? td[3] : td[5];
@@ -1073,15 +1460,22 @@ size_t gnn_plan_build_workspace_bytes(int64_t n_hits, int64_t n_segments, int32_
     return carve(nullptr, n_hits, n_segments, chunk_segments).bytes + 256;
 }
 
-int gnn_plan_build_sizes(const int32_t *src, const int32_t *dst, const int64_t *hit_ptr, int64_t n_hits,
-                         int64_t n_segments, int64_t n_graphs, int32_t tile_hits, int32_t iter_records,
-                         int32_t chunk_segments, int32_t edge_records, void *workspace, size_t workspace_bytes,
-                         gnn_plan_sizes_t *sizes_out, void *stream)
+// seg_ptr != nullptr: the graph-local form (pb_graph_levels, pb_graph_lists); its FAST_MISS status sends the caller
+// back here with seg_ptr = nullptr
+static int plan_sizes_impl(const int32_t *src, const int32_t *dst, const int64_t *hit_ptr, const int64_t *seg_ptr,
+                           int64_t max_graph_hits, int64_t max_graph_segments, int64_t n_hits,
+                           int64_t n_segments, int64_t n_graphs, int32_t tile_hits, int32_t iter_records,
+                           int32_t chunk_segments, int32_t edge_records, void *workspace, size_t workspace_bytes,
+                           gnn_plan_sizes_t *sizes_out, void *stream)
 {
     const int64_t n = n_hits, E = n_segments, G = n_graphs;
     if (!src || !dst || !hit_ptr || !workspace || !sizes_out || n <= 0 || E <= 0 || G <= 0 || tile_hits < SLICE ||
         tile_hits > kMaxSlicesPerTile * SLICE || chunk_segments <= 0 || iter_records < 0 || edge_records < 0)
         return fail(GNN_ERR_BADARG, "gnn_plan_build_sizes: bad argument");
+    const bool fast = seg_ptr != nullptr;
+    if (fast && (max_graph_hits <= 0 || max_graph_hits > kGraphCapHits || max_graph_segments < 0))
+        return fail(GNN_ERR_UNSUPPORTED, "gnn_plan_build_sizes_graphs: a graph of %lld hits does not fit the graph-local form "
+                    "(<= %d)", (long long)max_graph_hits, kGraphCapHits);
     if (n >= (1ll << 30) || E >= (1ll << 30) || G >= (1ll << 24))
         return fail(GNN_ERR_UNSUPPORTED, "gnn_plan_build_sizes: batch too large for 32-bit plan indices");
     if (workspace_bytes < gnn_plan_build_workspace_bytes(n, E, chunk_segments))
@@ -1090,6 +1484,28 @@ int gnn_plan_build_sizes(const int32_t *src, const int32_t *dst, const int64_t *
     char *wb = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     const Ws w = carve(wb, n, E, chunk_segments);
     const Bounds b = bounds_of(n, E, chunk_segments);
+    int *level = w.lvA;
+    // the cap of the LDS tables: the largest graph, rounded (a fresh opt-in per size would cost more than it saves)
+    const int cap = (int)((max_graph_hits + 1023) / 1024 * 1024 < kGraphCapHits ? (max_graph_hits + 1023) / 1024 * 1024
+                                                                                : kGraphCapHits);
+    const unsigned gthreads = max_graph_segments > 8192 ? 1024u : 256u;
+    const unsigned ggrid = (unsigned)(G < 16384 ? G : 16384);
+    if (fast) {
+        static DevOnce attr_done;     // dynamic LDS above 64 KB must be opted into, once per device
+        if (attr_done.need()) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pb_graph_levels),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kGraphLdsBytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pb_graph_lists<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kGraphLdsBytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pb_graph_lists<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kGraphLdsBytes);
+        }
+        HIP_OK(hipMemsetAsync(w.hdr, 0, (size_t)(reinterpret_cast<char *>(w.deg_in) - reinterpret_cast<char *>(w.hdr)), s),
+               "memset");
+        HIP_OK(hipMemsetAsync(w.degn, 0, (size_t)(b.np_max + 1) * sizeof(I2), s), "memset");
+        GNN_LAUNCH_SH("pb_graph_levels", pb_graph_levels, ggrid, gthreads, (size_t)pow2_ceil(cap) * 8, s, src, dst, hit_ptr, seg_ptr, G, n,
+                      E, cap, w.deg_in, w.deg_out, w.gid, level, w.k64a, w.iota, w.hkey, w.mscan, w.base, w.uflag, w.hdr);
+    } else {
     // header, sweep flags, degrees and both level buffers start at zero (adjacent in the workspace)
     HIP_OK(hipMemsetAsync(w.hdr, 0, (size_t)(reinterpret_cast<char *>(w.gid) - reinterpret_cast<char *>(w.hdr)), s), "memset");
     HIP_OK(hipMemsetAsync(w.degn, 0, (size_t)(b.np_max + 1) * sizeof(I2), s), "memset");
@@ -1099,7 +1515,6 @@ int gnn_plan_build_sizes(const int32_t *src, const int32_t *dst, const int64_t *
                    w.deg_out, w.hdr);
     }
     GNN_LAUNCH("pb_gid", pb_gid, gs(n), TB, s, hit_ptr, G, n, w.gid);
-    int *level = w.lvA;
     if (E <= kSmallSweepSegments)
         GNN_LAUNCH("pb_levels_small", pb_levels_small, 1, 1024, s, src, dst, (int)E, (int)n, level);
     else
@@ -1127,60 +1542,103 @@ int gnn_plan_build_sizes(const int32_t *src, const int32_t *dst, const int64_t *
     GNN_LAUNCH("pb_fill_i32", pb_fill_i32, gs(n), TB, s, w.down, n, 0x7FFFFFFF);
     GNN_LAUNCH("pb_down", pb_down, gs(E), TB, s, src, dst, E, (int)n, level, w.deg_in, w.down);
     GNN_LAUNCH("pb_key1", pb_key1, gs(n), TB, s, n, w.deg_in, w.deg_out, w.gid, level, w.down, w.k64a, w.iota, w.hkey, w.hdr);
+    }
     size_t tb = w.temp_bytes;
-    HIP_OK(rocprim::radix_sort_pairs(w.temp, tb, (const unsigned long long *)w.k64a, w.k64b, (const int *)w.iota, w.base,
-                                     (size_t)n, 0u, 39u + bit_width((uint64_t)G), s, false), "hit sort 1");
-    GNN_LAUNCH("pb_unit_flags", pb_unit_flags, gs(n + 1), TB, s, n, w.k64b, w.uflag);
+    if (!fast) {                          // (graph-local form: pb_graph_levels sorted each graph's hits in LDS)
+        HIP_OK(rocprim::radix_sort_pairs(w.temp, tb, (const unsigned long long *)w.k64a, w.k64b, (const int *)w.iota, w.base,
+                                         (size_t)n, 0u, 39u + bit_width((uint64_t)G), s, false), "hit sort 1");
+        GNN_LAUNCH("pb_unit_flags", pb_unit_flags, gs(n + 1), TB, s, n, w.k64b, w.uflag);
+    }
     tb = w.temp_bytes;
     HIP_OK(rocprim::exclusive_scan(w.temp, tb, (const int *)w.uflag, w.uscan, 0, (size_t)n + 1, rocprim::plus<int>(), s, false),
            "unit scan");
     GNN_LAUNCH("pb_compact", pb_compact, gs(n + 1), TB, s, n, w.uflag, w.uscan, w.ustart, w.hdr, (int)H_NUNITS);
     GNN_LAUNCH("pb_cut_tiles", pb_cut_tiles, 1, 1024, s, w.ustart, (int)n, (int)tile_hits, w.tile_bounds, w.hdr,
                (int)b.nt_max);
-    GNN_LAUNCH("pb_key2", pb_key2, gs(n), TB, s, n, w.base, w.deg_in, w.deg_out, w.tile_bounds, w.hdr, w.tpos, w.k64a);
-    tb = w.temp_bytes;
-    HIP_OK(rocprim::radix_sort_pairs(w.temp, tb, (const unsigned long long *)w.k64a, w.k64b, (const int *)w.base, w.oor,
-                                     (size_t)n, 0u, 32u + bit_width((uint64_t)b.nt_max), s, false), "hit sort 2");
+    if (fast) {
+        GNN_LAUNCH("pb_tile_sort", pb_tile_sort, 4096, TB, s, n, w.base, w.deg_in, w.deg_out, w.tile_bounds, w.hdr, w.tpos, w.oor);
+    } else {
+        GNN_LAUNCH("pb_key2", pb_key2, gs(n), TB, s, n, w.base, w.deg_in, w.deg_out, w.tile_bounds, w.hdr, w.tpos, w.k64a);
+        tb = w.temp_bytes;
+        HIP_OK(rocprim::radix_sort_pairs(w.temp, tb, (const unsigned long long *)w.k64a, w.k64b, (const int *)w.base, w.oor,
+                                         (size_t)n, 0u, 32u + bit_width((uint64_t)b.nt_max), s, false), "hit sort 2");
+    }
     GNN_LAUNCH("pb_tile_offsets", pb_tile_offsets, 1, 1024, s, w.tile_bounds, w.tpad_off, w.sbase, w.hdr, b.np_max);
     GNN_LAUNCH("pb_new_ids", pb_new_ids, gs(n + 1), TB, s, n, w.oor, w.tpos, w.tile_bounds, w.tpad_off, w.deg_in, w.deg_out,
                w.inv, w.degn, w.hdr);
-    GNN_LAUNCH("pb_renumber", pb_renumber, gs(E), TB, s, src, dst, E, w.inv, (int)n, w.src_new, w.dst_new, w.hdr);
-    const unsigned idbits = bit_width((uint64_t)b.np_max);
-    tb = w.temp_bytes;
-    HIP_OK(rocprim::radix_sort_pairs(w.temp, tb, (const int *)w.dst_new, w.kscr, (const int *)w.src_new, w.sv_in, (size_t)E, 0u,
-                                     idbits, s, false), "segment sort (in)");
-    tb = w.temp_bytes;
-    HIP_OK(rocprim::radix_sort_pairs(w.temp, tb, (const int *)w.src_new, w.kscr, (const int *)w.dst_new, w.sv_out, (size_t)E, 0u,
-                                     idbits, s, false), "segment sort (out)");
     tb = w.temp_bytes;
     HIP_OK(rocprim::exclusive_scan(w.temp, tb, (const I2 *)w.degn, w.ptr, I2{0, 0}, (size_t)b.np_max + 1, PlusI2(), s, false),
            "degree scan");
+    if (fast) {
+        if ((size_t)cap * 12 <= (size_t)kGraphLdsBytes)
+            GNN_LAUNCH_SH("pb_graph_lists", pb_graph_lists<true>, ggrid, gthreads, (size_t)cap * 12, s, src, dst, hit_ptr, seg_ptr,
+                          G, (int)n, cap, w.inv, w.ptr, w.src_new, w.dst_new, w.pin, w.pout, w.hdr);
+        else
+            GNN_LAUNCH_SH("pb_graph_lists", pb_graph_lists<false>, ggrid, gthreads, (size_t)cap * 8, s, src, dst, hit_ptr, seg_ptr,
+                          G, (int)n, cap, w.inv, w.ptr, w.src_new, w.dst_new, w.pin, w.pout, w.hdr);
+        GNN_LAUNCH("pb_sort_lists", pb_sort_lists, 4096, TB, s, w.degn, w.ptr, w.pin, w.pout, w.sv_in, w.sv_out, w.hdr);
+    } else {
+        GNN_LAUNCH("pb_renumber", pb_renumber, gs(E), TB, s, src, dst, E, w.inv, (int)n, w.src_new, w.dst_new, w.hdr);
+        const unsigned idbits = bit_width((uint64_t)b.np_max);
+        tb = w.temp_bytes;
+        HIP_OK(rocprim::radix_sort_pairs(w.temp, tb, (const int *)w.dst_new, w.kscr, (const int *)w.src_new, w.sv_in, (size_t)E,
+                                         0u, idbits, s, false), "segment sort (in)");
+        tb = w.temp_bytes;
+        HIP_OK(rocprim::radix_sort_pairs(w.temp, tb, (const int *)w.src_new, w.kscr, (const int *)w.dst_new, w.sv_out, (size_t)E,
+                                         0u, idbits, s, false), "segment sort (out)");
+    }
     GNN_LAUNCH("pb_slices", pb_slices, gs(b.ns_max + 1), TB, s, b.ns_max, w.degn, w.sl4, w.hdr);
     tb = w.temp_bytes;
     HIP_OK(rocprim::exclusive_scan(w.temp, tb, (const I4 *)w.sl4, w.off4, I4{0, 0, 0, 0}, (size_t)b.ns_max + 1, PlusI4(), s, false),
            "slice scan");
     GNN_LAUNCH("pb_tile_windows", pb_tile_windows, 2048, TB, s, w.tpad_off, w.sbase, w.degn, w.ptr, w.sv_in, w.sv_out,
-               (int)iter_records, w.t_desc, w.hdr);
+               (int)iter_records, w.t_desc, w.slice_tile, w.hdr);
     // edge chunks
-    GNN_LAUNCH("pb_seg_keys", pb_seg_keys, gs(E), TB, s, src, E, (int)n, w.hkey, w.kscr);
-    tb = w.temp_bytes;
-    HIP_OK(rocprim::inclusive_scan(w.temp, tb, (const int *)w.kscr, w.rb, (size_t)E, CarryKey(), s, false), "key carry scan");
-    GNN_LAUNCH("pb_run_flags", pb_run_flags, gs(E + 1), TB, s, E, w.rb, w.mscan);
+    if (!fast) {
+        GNN_LAUNCH("pb_seg_keys", pb_seg_keys, gs(E), TB, s, src, E, (int)n, w.hkey, w.kscr);
+        tb = w.temp_bytes;
+        HIP_OK(rocprim::inclusive_scan(w.temp, tb, (const int *)w.kscr, w.rb, (size_t)E, CarryKey(), s, false), "key carry scan");
+        GNN_LAUNCH("pb_run_flags", pb_run_flags, gs(E + 1), TB, s, E, w.rb, w.mscan);
+    }                                     // (graph-local form: pb_graph_levels wrote the run flags)
     tb = w.temp_bytes;
     HIP_OK(rocprim::exclusive_scan(w.temp, tb, (const int *)w.mscan, w.c_scan, 0, (size_t)E + 1, rocprim::plus<int>(), s, false),
            "run scan");
     GNN_LAUNCH("pb_compact", pb_compact, gs(E + 1), TB, s, E, w.mscan, w.c_scan, w.rb, w.hdr, (int)H_NRUNS);
-    GNN_LAUNCH("pb_mark_flags", pb_mark_flags, gs(E + 1), TB, s, w.rb, E, (int)chunk_segments, w.mscan, w.hdr);
-    tb = w.temp_bytes;
-    HIP_OK(rocprim::exclusive_scan(w.temp, tb, (const int *)w.mscan, w.c_scan, 0, (size_t)E + 1, rocprim::plus<int>(), s, false),
-           "mark scan");
-    GNN_LAUNCH("pb_marks", pb_marks, gs(E + 1), TB, s, w.rb, E, w.mscan, w.c_scan, w.marks, b.m_max, w.hdr);
+    if (fast) {
+        GNN_LAUNCH("pb_marks_fast", pb_marks_fast, 1, 1024, s, w.rb, E, (int)chunk_segments, w.marks, b.m_max, w.hdr);
+    } else {
+        GNN_LAUNCH("pb_mark_flags", pb_mark_flags, gs(E + 1), TB, s, w.rb, E, (int)chunk_segments, w.mscan, w.hdr);
+        tb = w.temp_bytes;
+        HIP_OK(rocprim::exclusive_scan(w.temp, tb, (const int *)w.mscan, w.c_scan, 0, (size_t)E + 1, rocprim::plus<int>(), s,
+                                       false), "mark scan");
+        GNN_LAUNCH("pb_marks", pb_marks, gs(E + 1), TB, s, w.rb, E, w.mscan, w.c_scan, w.marks, b.m_max, w.hdr);
+    }
     GNN_LAUNCH("pb_chunk_bounds", pb_chunk_bounds, 1, 1024, s, w.marks, (int)chunk_segments, w.parts, w.pscan, w.cb, b.c_max,
                w.hdr);
     GNN_LAUNCH("pb_chunk_windows", pb_chunk_windows, 2048, TB, s, w.cb, src, w.src_new, w.dst_new, (int)edge_records, w.c_desc,
                w.hdr);
     GNN_LAUNCH("pb_sizes", pb_sizes, 1, 64, s, w.hdr, w.off4, sizes_out, b.np_max, b.ns_max);
     return 0;
+}
+
+int gnn_plan_build_sizes(const int32_t *src, const int32_t *dst, const int64_t *hit_ptr, int64_t n_hits,
+                         int64_t n_segments, int64_t n_graphs, int32_t tile_hits, int32_t iter_records,
+                         int32_t chunk_segments, int32_t edge_records, void *workspace, size_t workspace_bytes,
+                         gnn_plan_sizes_t *sizes_out, void *stream)
+{
+    return plan_sizes_impl(src, dst, hit_ptr, nullptr, 0, 0, n_hits, n_segments, n_graphs, tile_hits, iter_records,
+                           chunk_segments, edge_records, workspace, workspace_bytes, sizes_out, stream);
+}
+
+int gnn_plan_build_sizes_graphs(const int32_t *src, const int32_t *dst, const int64_t *hit_ptr, const int64_t *seg_ptr,
+                                int64_t max_graph_hits, int64_t max_graph_segments, int64_t n_hits, int64_t n_segments,
+                                int64_t n_graphs, int32_t tile_hits, int32_t iter_records, int32_t chunk_segments,
+                                int32_t edge_records, void *workspace, size_t workspace_bytes, gnn_plan_sizes_t *sizes_out,
+                                void *stream)
+{
+    if (!seg_ptr) return fail(GNN_ERR_BADARG, "gnn_plan_build_sizes_graphs: seg_ptr missing");
+    return plan_sizes_impl(src, dst, hit_ptr, seg_ptr, max_graph_hits, max_graph_segments, n_hits, n_segments, n_graphs,
+                           tile_hits, iter_records, chunk_segments, edge_records, workspace, workspace_bytes, sizes_out, stream);
 }
 
 int gnn_plan_build_fill(const float *X, int32_t F, const int32_t *src, const int32_t *dst, int64_t n_hits,
@@ -1216,9 +1674,9 @@ int gnn_plan_build_fill(const float *X, int32_t F, const int32_t *src, const int
     GNN_LAUNCH("pb_fill_offsets", pb_fill_offsets, gs(ns + 1), TB, s, ns, w.off4, out->in_off, out->out_off, out->in_off16,
                out->out_off16);
     GNN_LAUNCH("pb_fill_lists", (pb_fill_lists<true>), gs(n_pad), TB, s, n_pad, w.degn, w.ptr, w.sl4, w.off4, w.sv_in, w.t_desc,
-               w.tpad_off, nt, out->in_nbr, out->in_nbr16);
+               w.slice_tile, out->in_nbr, out->in_nbr16);
     GNN_LAUNCH("pb_fill_lists", (pb_fill_lists<false>), gs(n_pad), TB, s, n_pad, w.degn, w.ptr, w.sl4, w.off4, w.sv_out,
-               w.t_desc, w.tpad_off, nt, out->out_nbr, out->out_nbr16);
+               w.t_desc, w.slice_tile, out->out_nbr, out->out_nbr16);
     if (nt > 0) {
         GNN_LAUNCH("pb_copy_i32", pb_copy_i32, gs((int64_t)nt * 8), TB, s, w.t_desc, out->tiles, (int64_t)nt * 8);
         GNN_LAUNCH("pb_schedule", pb_schedule, (unsigned)(nt < 4096 ? nt : 4096), 64, s, nt, w.t_desc, w.sl4, out->sched_a,

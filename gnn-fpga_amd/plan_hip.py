@@ -10,6 +10,8 @@ Batches outside the builder's static bounds (`sizes.status != 0`: a hit with >= 
 more than n/16 + 1024 tiles, ...) and empty batches raise `PlanBuilderUnsupported`; the caller
 (`HitGraphBatch.build_plan`) then uses the torch builder.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -22,7 +24,7 @@ class PlanBuilderUnsupported(RuntimeError):
 
 
 class HipSellPlan(SellPlan):
-    def __init__(self, batch, limits, debug=False):   # noqa: C901
+    def __init__(self, batch, limits, debug=False, graph_local=None):   # noqa: C901
         dev = batch.X.device
         n, E, G = batch.n_hits, batch.n_segments, batch.n_graphs
         if n <= 0 or E <= 0 or G <= 0:
@@ -40,10 +42,29 @@ class HipSellPlan(SellPlan):
         src = batch.src.to(dev).to(torch.int32).contiguous()
         dst = batch.dst.to(dev).to(torch.int32).contiguous()
         X = batch.X.to(dev).to(torch.float32).contiguous()
-        hit_ptr = torch.from_numpy(np.ascontiguousarray(batch.hit_ptr, dtype=np.int64)).to(dev)
+        hp = np.ascontiguousarray(batch.hit_ptr, dtype=np.int64)
+        sp = np.ascontiguousarray(batch.seg_ptr, dtype=np.int64)
+        # the graph-local stage 1 (one workgroup per graph, LDS tables) when the batch names its graphs' segment
+        # ranges and the largest graph fits; the kernels check the layout themselves (status 128 -> the global form)
+        local = graph_local if graph_local is not None else os.environ.get("GNN_PLAN_GRAPH_LOCAL", "1") != "0"
+        if graph_local is None and G < 4:
+            local = False       # (one workgroup per graph: 0.70 against 0.60 ms for a single detector graph, 1.2 / 1.4 at 32)
+        local = bool(local and len(sp) == G + 1 and int(sp[0]) == 0 and int(sp[-1]) == E
+                     and int(np.diff(hp).max()) <= _lib.PLAN_GRAPH_CAP_HITS)
+        ptrs = torch.from_numpy(np.concatenate([hp, sp]) if local else hp).to(dev)       # one upload
+        hit_ptr = ptrs[:G + 1]
         ws = torch.empty(_lib.plan_build_workspace_bytes(n, E, CH), dtype=torch.uint8, device=dev)
-        sz = _lib.plan_build_sizes(src, dst, hit_ptr, n, E, G, tile_hits, int(limits["iter_records"]), CH,
-                                   int(limits["edge_records"]), ws)
+        sz = None
+        if local:
+            sz = _lib.plan_build_sizes(src, dst, hit_ptr, n, E, G, tile_hits, int(limits["iter_records"]), CH,
+                                       int(limits["edge_records"]), ws, seg_ptr=ptrs[G + 1:],
+                                       max_graph_hits=int(np.diff(hp).max()), max_graph_segments=int(np.diff(sp).max()))
+            if sz.status & _lib.PLAN_STATUS_FAST_MISS:
+                local, sz = False, None
+        if sz is None:
+            sz = _lib.plan_build_sizes(src, dst, hit_ptr, n, E, G, tile_hits, int(limits["iter_records"]), CH,
+                                       int(limits["edge_records"]), ws)
+        self.graph_local = local
         if sz.status & 64:      # ST_ENDPOINT: the numpy builder's ValueError, not a fallback
             raise ValueError("segment endpoint out of range, or a segment with exactly one padded end "
                              "(a padded segment must have src = dst = -1)")

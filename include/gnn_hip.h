@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNN_ABI_VERSION 4
+#define GNN_ABI_VERSION 5
 
 #define GNN_ERR_UNSUPPORTED (-10001) /* (F, D) has no kernel instantiation            */
 #define GNN_ERR_BADARG      (-10002) /* null pointer, negative size, bad stride ...   */
@@ -323,6 +323,20 @@ int gnn_plan_build_sizes(const int32_t *src, const int32_t *dst, const int64_t *
                          int64_t n_segments, int64_t n_graphs, int32_t tile_hits, int32_t iter_records,
                          int32_t chunk_segments, int32_t edge_records, void *workspace,
                          size_t workspace_bytes, gnn_plan_sizes_t *sizes_out, void *stream);
+/* ABI 5: the same stage 1 for a batch whose graphs are laid out one after the other, as merge_graphs' block-diagonal
+ * batches are (gnn/trainSegmentClassifier.py:66-95): seg_ptr [n_graphs+1] int64 on the DEVICE, graph g owns segments
+ * [seg_ptr[g], seg_ptr[g+1]) and they join hits of [hit_ptr[g], hit_ptr[g+1]) only; max_graph_hits /
+ * max_graph_segments = the largest graph (host values).  Degrees, levels, renumbered endpoints and both neighbour
+ * lists are then built by one workgroup per graph in LDS instead of device-wide sweeps and sorts (same arrays, entry
+ * for entry).  The kernels CHECK the layout they were told: status bit 128 = it does not hold for this batch (an end
+ * outside its graph's hit range, ranges that do not tile [0, n_hits) / [0, n_segments), a level above 64, a hit with
+ * more than 1024 segments in one direction) - call gnn_plan_build_sizes instead.  max_graph_hits > 16384:
+ * GNN_ERR_UNSUPPORTED. */
+int gnn_plan_build_sizes_graphs(const int32_t *src, const int32_t *dst, const int64_t *hit_ptr, const int64_t *seg_ptr,
+                                int64_t max_graph_hits, int64_t max_graph_segments, int64_t n_hits,
+                                int64_t n_segments, int64_t n_graphs, int32_t tile_hits, int32_t iter_records,
+                                int32_t chunk_segments, int32_t edge_records, void *workspace,
+                                size_t workspace_bytes, gnn_plan_sizes_t *sizes_out, void *stream);
 int gnn_plan_build_fill(const float *X, int32_t F, const int32_t *src, const int32_t *dst, int64_t n_hits,
                         int64_t n_segments, int32_t chunk_segments, const gnn_plan_sizes_t *sizes,
                         void *workspace, size_t workspace_bytes, const gnn_plan_out_t *out, void *stream);

@@ -83,9 +83,45 @@ def test_hip_builder_builds_the_same_plan(hip, case):
     lim = hip.plan_limits(F, D)
     lim.update(lim_over)
     host = SellPlan(b, lim)
-    dev = HipSellPlan(b.cuda(), lim, debug=True)
+    # (batches of fewer than four graphs take the global form by default: ask for the graph-local one)
+    dev = HipSellPlan(b.cuda(), lim, debug=True, graph_local=True if len(graphs) < 4 else None)
     assert dev.X.is_cuda
     _same_plan(host, dev)
+    # which stage 1 built it: the graph-local form (one workgroup per graph, LDS tables) wherever a batch's graphs
+    # fit its tables and its layout checks hold; random graphs have cycles (levels above the 64-sweep cap -> status
+    # 128 -> the global form), 20 k / 40 k-hit graphs exceed the tables
+    assert dev.graph_local == (case not in ("one_graph_big_levels", "cyclic", "big_shuffled")), case
+    if dev.graph_local:     # and the global form of the same batch, still array for array
+        glob = HipSellPlan(b.cuda(), lim, debug=True, graph_local=False)
+        assert not glob.graph_local
+        _same_plan(host, glob)
+
+
+def test_graph_local_builder_checks_the_layout_it_is_told(hip):
+    """seg_ptr / hit_ptr that do not describe the batch (a segment joining hits of another graph's range, segment
+    ranges that leave segments out) must not change the plan: the graph-local kernels report status 128 and the
+    global form builds it."""
+    from gnn_fpga_amd.plan import SellPlan
+    from gnn_fpga_amd.plan_hip import HipSellPlan
+    graphs = [synth.layered_graph(600, 4000, 3, seed=s) for s in range(4)]
+    b = HitGraphBatch.from_graphs(graphs)
+    lim = hip.plan_limits(3, 8)
+    # (a) the same arrays described as ONE graph's hits but four segment ranges: still consistent -> local
+    # (b) a segment of graph 1 rewired to a hit of graph 2
+    src, dst = b.src.numpy().copy(), b.dst.numpy().copy()
+    j = int(b.seg_ptr[1]) + 5
+    dst[j] = int(b.hit_ptr[2]) + 3
+    crossed = HitGraphBatch(b.X.numpy(), src, dst, hit_ptr=b.hit_ptr, seg_ptr=b.seg_ptr)
+    dev = HipSellPlan(crossed.cuda(), lim, debug=True)
+    assert not dev.graph_local
+    _same_plan(SellPlan(crossed, lim), dev)
+    # (c) segment ranges shifted by one: graph 0 claims a segment of graph 1
+    sp = b.seg_ptr.copy()
+    sp[1] += 1
+    shifted = HitGraphBatch(b.X.numpy(), b.src.numpy(), b.dst.numpy(), hit_ptr=b.hit_ptr, seg_ptr=sp)
+    dev = HipSellPlan(shifted.cuda(), lim, debug=True)
+    assert not dev.graph_local
+    _same_plan(SellPlan(shifted, lim), dev)
 
 
 def test_hip_builder_is_the_default_and_declines_what_it_cannot_hold(hip, monkeypatch):
