@@ -54,7 +54,7 @@ class GnnPlanSizes(ctypes.Structure):
                                     "in16_words", "out16_words", "n_sched", "iter_lds_records",
                                     "edge_lds_rows", "n_lds_tiles", "n_lds_chunks", "iter_lds_in",
                                     "iter_lds_out", "tile_hits_max", "max_list_steps", "n_valid",
-                                    "max_level", "status")]
+                                    "max_level", "status", "list_mode")]
 
 
 class GnnPlanOut(ctypes.Structure):

@@ -48,7 +48,7 @@ inline unsigned gs(int64_t n)
 // device header (int64 slots) - counts that later kernels read and the final sizes are made from
 enum Hdr {
     H_NVALID, H_NUNITS, H_NTILES, H_NPAD, H_TILEMAX, H_NSCHED, H_NRUNS, H_NMARKS, H_NCHUNKS, H_STATUS,
-    H_LDSREC, H_NLDSTILES, H_LDSIN, H_LDSOUT, H_EDGEROWS, H_NLDSCHUNKS, H_MAXSTEPS, H_MAXLEVEL, H_COUNT = 32
+    H_LDSREC, H_NLDSTILES, H_LDSIN, H_LDSOUT, H_EDGEROWS, H_NLDSCHUNKS, H_MAXSTEPS, H_MAXLEVEL, H_LISTMODE, H_COUNT = 32
 };
 enum Status { ST_OK = 0, ST_DEGREE = 1, ST_TILES = 2, ST_PAD = 4, ST_CHUNKS = 8, ST_SLICES = 16, ST_I32 = 32,
               ST_ENDPOINT = 64 };   // ST_ENDPOINT: a segment end outside [0, n_hits), or exactly one end negative
@@ -88,7 +88,8 @@ struct Ws {
     // padded hits / slices
     I2 *degn, *ptr;                            // (in, out) degree and CSR pointer per new id
     I4 *sl4, *off4;                            // per slice: (16 steps_in, 16 steps_out, 16 ceil8 in, 16 ceil8 out), scanned
-    int *slice_tile;                           // tile of a slice (pb_tile_windows -> pb_fill_lists)
+    int *slice_tile;                           // tile of a slice (pb_new_ids -> pb_graph_renumber, pb_fill_lists)
+    int *trange;                               // [nt_max + 1][4] segment range of a tile's in / out lists (lo, -hi)
     // segments
     int *src_new, *dst_new, *kscr, *sv_in, *sv_out, *c_scan, *rb;
     int *mscan, *marks, *parts, *pscan, *cb, *c_desc;  // c_desc: [c_max][8]
@@ -150,6 +151,7 @@ Ws carve(char *p, int64_t n, int64_t E, int CH)
     w.sl4 = reinterpret_cast<I4 *>(take((size_t)(b.ns_max + 1) * sizeof(I4)));
     w.off4 = reinterpret_cast<I4 *>(take((size_t)(b.ns_max + 1) * sizeof(I4)));
     w.slice_tile = ints(b.ns_max + 1);
+    w.trange = ints((b.nt_max + 1) * 4);
     w.src_new = ints(E); w.dst_new = ints(E); w.kscr = ints(E + 1); w.sv_in = ints(E); w.sv_out = ints(E);
     w.c_scan = ints(E + 1); w.rb = ints(E + 2);
     w.mscan = ints(E + 1);
@@ -585,7 +587,7 @@ __global__ __launch_bounds__(1024) void pb_graph_lists(const int *__restrict__ s
                                                        const int *__restrict__ inv, const I2 *__restrict__ ptr, int *src_new,
                                                        int *dst_new, I2 *pin, I2 *pout, const int64_t *__restrict__ hdr)
 {
-    if (hdr[H_STATUS]) return;
+    if (hdr[H_STATUS] || hdr[H_LISTMODE]) return;           // (LISTMODE 1: pb_tile_lists builds the lists)
     extern __shared__ int lds[];
     int *cin = lds, *cout = lds + cap, *linv = lds + 2 * cap;      // linv: new ids of the graph's hits (INV_LDS)
     const int B = (int)blockDim.x;
@@ -641,7 +643,7 @@ __global__ __launch_bounds__(TB) void pb_sort_lists(const I2 *__restrict__ degn,
                                                     const I2 *__restrict__ pin, const I2 *__restrict__ pout, int *sv_in,
                                                     int *sv_out, const int64_t *__restrict__ hdr)
 {
-    if (hdr[H_STATUS]) return;
+    if (hdr[H_STATUS] || hdr[H_LISTMODE]) return;
     const int64_t n_pad = hdr[H_NPAD];
     const int l = threadIdx.x & 15;
     const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4, ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
@@ -662,6 +664,193 @@ __global__ __launch_bounds__(TB) void pb_sort_lists(const I2 *__restrict__ degn,
                     for (int k = 0; k < 16; ++k) rank += __shfl(oj, k, 16) < e.a ? 1 : 0;
                 }
                 if (have) sv[p0 + rank] = e.b;
+            }
+        }
+    }
+}
+
+// ---- tile-local neighbour lists ---------------------------------------------------------------------------
+// The scattered pairs of pb_graph_lists are what is left of a sort's cost.  They are not needed when the segments
+// of a tile's lists lie together in the caller's order - and the reference emits segments per layer pair
+// (gnn/graph.py:80-93): the incoming segments of the hits of one detector level ARE one contiguous block.  So:
+//   pb_graph_renumber (a workgroup per graph, the graph's new ids in LDS): src_new / dst_new, and for every tile the
+//       range of segment ids that end (start) at one of its hits - min / max by one atomic pair per wave when all 64
+//       consecutive segments of a wave instruction go to one tile, which is the normal case;
+//   pb_lists_mode (one workgroup): LISTMODE 1 when the ranges of all tiles together are at most 16 E segments long (a
+//       level cut into several tiles is read once per tile and direction: 4 bytes per segment, coalesced) and no
+//       tile's lists exceed the LDS staging; otherwise (shuffled segments, hubs) pb_graph_lists / pb_sort_lists
+//       run as before - both sets of kernels are launched, the wrong one returns at once;
+//   pb_tile_lists (a workgroup per tile): walks the tile's range, keeps the segments that end (start) in the tile,
+//       drops (segment, other end) into an LDS image of the tile's lists (LDS cursors), sorts every list by segment
+//       id (16 lanes per hit, ranks by counting) and streams the other ends out to their final places: the only
+//       global traffic is src_new / dst_new once per direction and the lists once.
+constexpr int kTileListEntries = 16384;               // staged (segment, other end) pairs per tile and direction: 128 KB
+struct TR { int in_lo, in_nhi, out_lo, out_nhi; };    // (nhi = -max: one memset to 0x7F.. initialises all four for atomicMin)
+
+template <bool INV_LDS>
+__global__ __launch_bounds__(1024) void pb_graph_renumber(const int *__restrict__ src, const int *__restrict__ dst,
+                                                          const int64_t *__restrict__ hit_ptr,
+                                                          const int64_t *__restrict__ seg_ptr, int64_t G, int n, int cap,
+                                                          const int *__restrict__ inv, const int *__restrict__ slice_tile,
+                                                          int *src_new, int *dst_new, TR *trange,
+                                                          const int64_t *__restrict__ hdr)
+{
+    if (hdr[H_STATUS]) return;
+    extern __shared__ int lds[];
+    int *linv = lds;
+    const int B = (int)blockDim.x;
+    const int npad = inv[n];
+    for (int64_t g = blockIdx.x; g < G; g += gridDim.x) {
+        const int64_t e0 = seg_ptr[g], e1 = seg_ptr[g + 1];
+        const int lo = (int)hit_ptr[g], nh = (int)(hit_ptr[g + 1] - hit_ptr[g]);
+        __syncthreads();
+        if (INV_LDS)
+            for (int i = threadIdx.x; i < nh; i += B) linv[i] = inv[lo + i];
+        __syncthreads();
+        const int64_t span = 4 * (int64_t)B;
+        for (int64_t jb = e0 + (threadIdx.x & ~63) * 4 + (threadIdx.x & 63); jb - (threadIdx.x & 63) < e1;
+             jb += span) {                        // a wave takes 4 x 64 consecutive segments
+            int sv[4], dv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t j = jb + 64 * u;
+                sv[u] = j < e1 ? __builtin_nontemporal_load(src + j) : -1;
+                dv[u] = j < e1 ? __builtin_nontemporal_load(dst + j) : -1;
+            }
+            int sn[4], dn[4], t_out[4], t_in[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool ok = sv[u] >= 0;
+                sn[u] = ok ? (INV_LDS ? linv[sv[u] - lo] : inv[sv[u]]) : npad;
+                dn[u] = ok ? (INV_LDS ? linv[dv[u] - lo] : inv[dv[u]]) : npad;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {                 // (all eight tile look-ups in flight before anything waits)
+                const bool ok = sv[u] >= 0;
+                t_out[u] = ok ? slice_tile[sn[u] / SLICE] : -1;
+                t_in[u] = ok ? slice_tile[dn[u] / SLICE] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t j = jb + 64 * u;
+                if (j < e1) {
+                    __builtin_nontemporal_store(sn[u], src_new + j);
+                    __builtin_nontemporal_store(dn[u], dst_new + j);
+                }
+            }
+            // one pair of atomics per DISTINCT tile among a wave instruction's 64 consecutive segments (one tile in the
+            // normal case, two or three where a level is cut into several tiles; per-lane atomics on those few words
+            // serialised at the L2: 4 ms for c3 x 32)
+            const int lane = (int)(threadIdx.x & 63);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int jj = (int)(jb + 64 * u);
+                const bool ok = sv[u] >= 0;
+#pragma unroll
+                for (int dir = 0; dir < 2; ++dir) {
+                    const int t = dir ? t_out[u] : t_in[u];
+                    unsigned long long rem = __ballot(ok);
+                    while (rem) {                                             // (wave-uniform)
+                        const int leader = __ffsll((long long)rem) - 1;
+                        const int tl = __shfl(t, leader, 64);
+                        const unsigned long long same = __ballot(ok && t == tl);
+                        const int jf = __shfl(jj, __ffsll((long long)same) - 1, 64);
+                        const int jl = __shfl(jj, 63 - __clzll((long long)same), 64);
+                        if (lane == leader) {
+                            atomicMin(dir ? &trange[tl].out_lo : &trange[tl].in_lo, jf);
+                            atomicMin(dir ? &trange[tl].out_nhi : &trange[tl].in_nhi, -jl);
+                        }
+                        rem &= ~same;
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void pb_lists_mode(const TR *__restrict__ trange, const int *__restrict__ tpad_off,
+                                                      const I2 *__restrict__ ptr, int64_t E, int force_scatter, int64_t *hdr)
+{
+    __shared__ int red[16];
+    if (hdr[H_STATUS]) return;
+    const int nt = (int)hdr[H_NTILES];
+    long long len = 0;
+    int big = 0;
+    for (int t = threadIdx.x; t < nt; t += 1024) {
+        const TR r = trange[t];
+        if (r.in_lo <= -r.in_nhi) len += (long long)(-r.in_nhi) - r.in_lo + 1;
+        if (r.out_lo <= -r.out_nhi) len += (long long)(-r.out_nhi) - r.out_lo + 1;
+        const I2 a = ptr[tpad_off[t]], b = ptr[tpad_off[t + 1]];
+        if (b.a - a.a > kTileListEntries || b.b - a.b > kTileListEntries) big = 1;
+    }
+    // (sum in units of 64 segments so that it fits the int reduction: E < 2^30)
+    const int tot = block_reduce_i((int)((len + 63) >> 6), red, OpAdd());
+    big = block_reduce_i(big, red, OpOr());
+    if (threadIdx.x == 0)
+        hdr[H_LISTMODE] = (!force_scatter && !big && (long long)tot * 64 <= 16 * (long long)E + 64ll * nt + 65536) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(1024) void pb_tile_lists(const int *__restrict__ src_new, const int *__restrict__ dst_new,
+                                                      const TR *__restrict__ trange, const int *__restrict__ tpad_off,
+                                                      const I2 *__restrict__ degn, const I2 *__restrict__ ptr, int *sv_in,
+                                                      int *sv_out, const int64_t *__restrict__ hdr)
+{
+    if (hdr[H_STATUS] || !hdr[H_LISTMODE]) return;
+    extern __shared__ int lds[];
+    I2 *stage = reinterpret_cast<I2 *>(lds);                         // [kTileListEntries]
+    int *cur = lds + 2 * kTileListEntries;                           // [kMaxSlicesPerTile * SLICE]
+    int *start = cur + kMaxSlicesPerTile * SLICE;                    // [kMaxSlicesPerTile * SLICE]
+    const int nt = (int)hdr[H_NTILES];
+    const int l = threadIdx.x & 15, grp = threadIdx.x >> 4, ngrp = (int)(blockDim.x >> 4);
+    for (int t = blockIdx.x; t < nt; t += gridDim.x) {
+        const int h0 = tpad_off[t], h1 = tpad_off[t + 1], nh = h1 - h0;
+        const TR r = trange[t];
+#pragma unroll
+        for (int dir = 0; dir < 2; ++dir) {
+            const int j0 = dir ? r.out_lo : r.in_lo, j1 = dir ? -r.out_nhi : -r.in_nhi;     // inclusive
+            if (j0 > j1) continue;                                   // (workgroup-uniform: no segment ends / starts here)
+            const int *__restrict__ key = dir ? src_new : dst_new;
+            const int *__restrict__ oth = dir ? dst_new : src_new;
+            int *sv = dir ? sv_out : sv_in;
+            const int P0 = dir ? ptr[h0].b : ptr[h0].a;
+            __syncthreads();
+            const int Lt = (dir ? ptr[h1].b : ptr[h1].a) - P0;         // entries of the tile's lists
+            for (int i = threadIdx.x; i < nh; i += blockDim.x) {
+                const int p = (dir ? ptr[h0 + i].b : ptr[h0 + i].a) - P0;
+                cur[i] = p;
+                start[i] = p;
+            }
+            __syncthreads();
+            const bool dense = j1 - j0 < 2 * Lt;                       // most segments of the range belong here
+            for (int jb = j0 + (int)threadIdx.x; jb <= j1; jb += 4 * (int)blockDim.x) {
+                int kv[4], ov[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = jb + u * (int)blockDim.x;
+                    kv[u] = j <= j1 ? key[j] : -1;
+                    ov[u] = (dense && j <= j1) ? oth[j] : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (kv[u] >= h0 && kv[u] < h1) {
+                        const int j = jb + u * (int)blockDim.x;
+                        stage[atomicAdd(&cur[kv[u] - h0], 1)] = I2{j, dense ? ov[u] : oth[j]};
+                    }
+            }
+            __syncthreads();
+            for (int i = grp; i < nh; i += ngrp) {
+                const int p0 = start[i], deg = cur[i] - p0;          // (the cursor stands behind the hit's list now)
+                for (int base = 0; base < deg; base += 16) {
+                    const bool have = base + l < deg;
+                    const I2 e = have ? stage[p0 + base + l] : I2{0x7FFFFFFF, 0};
+                    int rank = 0;
+                    for (int ob = 0; ob < deg; ob += 16) {
+                        const int oj = ob == base ? e.a : (ob + l < deg ? stage[p0 + ob + l].a : 0x7FFFFFFF);
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) rank += __shfl(oj, k, 16) < e.a ? 1 : 0;
+                    }
+                    if (have) sv[P0 + p0 + rank] = e.b;
+                }
             }
         }
     }
@@ -919,7 +1108,7 @@ __global__ __launch_bounds__(1024) void pb_tile_offsets(const int *__restrict__ 
 __global__ __launch_bounds__(TB) void pb_new_ids(int64_t n, const int *__restrict__ oor, const int *__restrict__ tpos,
                                                  const int *__restrict__ tile_bounds, const int *__restrict__ tpad_off,
                                                  const int *__restrict__ deg_in, const int *__restrict__ deg_out,
-                                                 int *inv, I2 *degn, const int64_t *__restrict__ hdr)
+                                                 int *inv, I2 *degn, int *slice_tile, const int64_t *__restrict__ hdr)
 {
     if (hdr[H_STATUS]) return;
     GS_LOOP(r, n + 1) {
@@ -928,6 +1117,8 @@ __global__ __launch_bounds__(TB) void pb_new_ids(int64_t n, const int *__restric
         const int nw = tpad_off[t] + ((int)r - tile_bounds[t]);
         inv[old] = nw;
         degn[nw] = I2{deg_in[old], deg_out[old]};
+        // tile of a slice: a tile is padded to whole slices, so every slice holds a real hit (its first one writes)
+        if ((nw & (SLICE - 1)) == 0) slice_tile[nw / SLICE] = t;
     }
 }
 
@@ -971,7 +1162,7 @@ __global__ __launch_bounds__(TB) void pb_slices(int64_t ns_max, const I2 *__rest
 __global__ __launch_bounds__(TB) void pb_tile_windows(const int *__restrict__ tpad_off, const int *__restrict__ sbase,
                                                       const I2 *__restrict__ degn, const I2 *__restrict__ ptr,
                                                       const int *__restrict__ sv_in, const int *__restrict__ sv_out,
-                                                      int iter_records, int *t_desc, int *slice_tile, int64_t *hdr)
+                                                      int iter_records, int *t_desc, int64_t *hdr)
 {
     if (hdr[H_STATUS]) return;
     const int nt = (int)hdr[H_NTILES];
@@ -979,8 +1170,6 @@ __global__ __launch_bounds__(TB) void pb_tile_windows(const int *__restrict__ tp
     int m_rec = 0, m_in = 0, m_out = 0, n_lds = 0;      // (thread 0: this workgroup's tiles; one set of atomics at the end)
     for (int t = blockIdx.x; t < nt; t += gridDim.x) {
         const int h0 = tpad_off[t], h1 = tpad_off[t + 1];
-        // (pb_fill_lists finds a hit's tile here instead of a 12-step binary search over the tile offsets per hit)
-        for (int sl = h0 / SLICE + threadIdx.x; sl < h1 / SLICE; sl += TB) slice_tile[sl] = t;
         int ilo = 0x7FFFFFFF, ihi = -1, olo = 0x7FFFFFFF, ohi = -1;
         for (int h = h0 + threadIdx.x; h < h1; h += TB) {
             const I2 d = degn[h], p = ptr[h];
@@ -1246,6 +1435,7 @@ __global__ void pb_sizes(const int64_t *__restrict__ hdr, const I4 *__restrict__
     s.tile_hits_max = hdr[H_TILEMAX]; s.max_list_steps = hdr[H_MAXSTEPS];
     s.n_valid = hdr[H_NVALID]; s.max_level = hdr[H_MAXLEVEL];
     s.status = st;
+    s.list_mode = hdr[H_LISTMODE];
     *out = s;
 }
 
@@ -1499,6 +1689,10 @@ static int plan_sizes_impl(const int32_t *src, const int32_t *dst, const int64_t
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kGraphLdsBytes);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pb_graph_lists<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kGraphLdsBytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pb_graph_renumber<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kGraphLdsBytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pb_tile_lists),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kGraphLdsBytes);
         }
         HIP_OK(hipMemsetAsync(w.hdr, 0, (size_t)(reinterpret_cast<char *>(w.deg_in) - reinterpret_cast<char *>(w.hdr)), s),
                "memset");
@@ -1565,11 +1759,25 @@ static int plan_sizes_impl(const int32_t *src, const int32_t *dst, const int64_t
     }
     GNN_LAUNCH("pb_tile_offsets", pb_tile_offsets, 1, 1024, s, w.tile_bounds, w.tpad_off, w.sbase, w.hdr, b.np_max);
     GNN_LAUNCH("pb_new_ids", pb_new_ids, gs(n + 1), TB, s, n, w.oor, w.tpos, w.tile_bounds, w.tpad_off, w.deg_in, w.deg_out,
-               w.inv, w.degn, w.hdr);
+               w.inv, w.degn, w.slice_tile, w.hdr);
     tb = w.temp_bytes;
     HIP_OK(rocprim::exclusive_scan(w.temp, tb, (const I2 *)w.degn, w.ptr, I2{0, 0}, (size_t)b.np_max + 1, PlusI2(), s, false),
            "degree scan");
     if (fast) {
+        HIP_OK(hipMemsetAsync(w.trange, 0x7F, (size_t)(b.nt_max + 1) * sizeof(TR), s), "memset");
+        if ((size_t)cap * 4 <= (size_t)kGraphLdsBytes / 2)
+            GNN_LAUNCH_SH("pb_graph_renumber", pb_graph_renumber<true>, ggrid, gthreads, (size_t)cap * 4, s, src, dst, hit_ptr,
+                          seg_ptr, G, (int)n, cap, w.inv, w.slice_tile, w.src_new, w.dst_new, reinterpret_cast<TR *>(w.trange),
+                          w.hdr);
+        else
+            GNN_LAUNCH_SH("pb_graph_renumber", pb_graph_renumber<false>, ggrid, gthreads, 0, s, src, dst, hit_ptr, seg_ptr, G,
+                          (int)n, cap, w.inv, w.slice_tile, w.src_new, w.dst_new, reinterpret_cast<TR *>(w.trange), w.hdr);
+        const char *fs = getenv("GNN_PLAN_SCATTER_LISTS");       // (tests and A / B timing: the scattered-pairs form)
+        GNN_LAUNCH("pb_lists_mode", pb_lists_mode, 1, 1024, s, reinterpret_cast<const TR *>(w.trange), w.tpad_off, w.ptr, E,
+                   (fs && fs[0] == '1') ? 1 : 0, w.hdr);
+        GNN_LAUNCH_SH("pb_tile_lists", pb_tile_lists, 4096, 1024, (size_t)(2 * kTileListEntries + 2 * kMaxSlicesPerTile * SLICE) * 4, s,
+                      w.src_new, w.dst_new, reinterpret_cast<const TR *>(w.trange), w.tpad_off, w.degn, w.ptr, w.sv_in, w.sv_out,
+                      w.hdr);
         if ((size_t)cap * 12 <= (size_t)kGraphLdsBytes)
             GNN_LAUNCH_SH("pb_graph_lists", pb_graph_lists<true>, ggrid, gthreads, (size_t)cap * 12, s, src, dst, hit_ptr, seg_ptr,
                           G, (int)n, cap, w.inv, w.ptr, w.src_new, w.dst_new, w.pin, w.pout, w.hdr);
@@ -1592,7 +1800,7 @@ static int plan_sizes_impl(const int32_t *src, const int32_t *dst, const int64_t
     HIP_OK(rocprim::exclusive_scan(w.temp, tb, (const I4 *)w.sl4, w.off4, I4{0, 0, 0, 0}, (size_t)b.ns_max + 1, PlusI4(), s, false),
            "slice scan");
     GNN_LAUNCH("pb_tile_windows", pb_tile_windows, 2048, TB, s, w.tpad_off, w.sbase, w.degn, w.ptr, w.sv_in, w.sv_out,
-               (int)iter_records, w.t_desc, w.slice_tile, w.hdr);
+               (int)iter_records, w.t_desc, w.hdr);
     // edge chunks
     if (!fast) {
         GNN_LAUNCH("pb_seg_keys", pb_seg_keys, gs(E), TB, s, src, E, (int)n, w.hkey, w.kscr);

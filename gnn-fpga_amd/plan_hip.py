@@ -65,6 +65,7 @@ class HipSellPlan(SellPlan):
             sz = _lib.plan_build_sizes(src, dst, hit_ptr, n, E, G, tile_hits, int(limits["iter_records"]), CH,
                                        int(limits["edge_records"]), ws)
         self.graph_local = local
+        self.list_mode = int(sz.list_mode) if local else 0    # 1: neighbour lists built per tile in LDS
         if sz.status & 64:      # ST_ENDPOINT: the numpy builder's ValueError, not a fallback
             raise ValueError("segment endpoint out of range, or a segment with exactly one padded end "
                              "(a padded segment must have src = dst = -1)")

@@ -302,6 +302,8 @@ typedef struct gnn_plan_sizes {
     int64_t n_sched;                    /* entries of sched_a, sched_b                              */
     int64_t iter_lds_records, edge_lds_rows, n_lds_tiles, n_lds_chunks, iter_lds_in, iter_lds_out;
     int64_t tile_hits_max, max_list_steps, n_valid, max_level, status;
+    int64_t list_mode;                  /* ABI 5, graph-local form: 1 = neighbour lists built per tile in LDS, 0 = by scattered
+                                           pairs and a sort per list (segments of a tile's lists not contiguous, hub hits) */
 } gnn_plan_sizes_t;
 
 typedef struct gnn_plan_out {           /* device arrays gnn_plan_build_fill writes (sizes: gnn_plan_t) */

@@ -26,7 +26,7 @@ CASES = ["layered", "ragged", "padded", "global", "wide", "one_graph_big_levels"
 
 
 @pytest.mark.parametrize("case", CASES)
-def test_hip_builder_builds_the_same_plan(hip, case):
+def test_hip_builder_builds_the_same_plan(hip, case, monkeypatch):
     from gnn_fpga_amd.plan import SellPlan
     from gnn_fpga_amd.plan_hip import HipSellPlan
     F, D, lim_over = 3, 8, {}
@@ -95,6 +95,16 @@ def test_hip_builder_builds_the_same_plan(hip, case):
         glob = HipSellPlan(b.cuda(), lim, debug=True, graph_local=False)
         assert not glob.graph_local
         _same_plan(host, glob)
+        # neighbour lists: per tile in LDS when the segments of a tile's lists lie together (the reference's layer-pair
+        # order), by scattered pairs + a sort per list otherwise (a graph's segments shuffled) - and on request
+        # (one c3 graph: 64-hit tiles cut every level into 16 - its layer-pair block would be read 16 times)
+        assert dev.list_mode == (0 if case in ("shuffled", "c3") else 1), (case, dev.list_mode)
+        if dev.list_mode:
+            monkeypatch.setenv("GNN_PLAN_SCATTER_LISTS", "1")
+            scat = HipSellPlan(b.cuda(), lim, debug=True, graph_local=True)
+            monkeypatch.delenv("GNN_PLAN_SCATTER_LISTS")
+            assert scat.graph_local and scat.list_mode == 0
+            _same_plan(host, scat)
 
 
 def test_graph_local_builder_checks_the_layout_it_is_told(hip):
