@@ -22,7 +22,7 @@ def _random_graph(n, e, F, seed):
 
 
 CASES = ["layered", "ragged", "padded", "global", "wide", "one_graph_big_levels", "muon", "cyclic",
-         "shuffled", "big_shuffled", "c3", "many_c3", "leading_pads", "tiny_tiles"]
+         "shuffled", "big_shuffled", "c3", "many_c3", "leading_pads", "tiny_tiles", "many_muon"]
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -53,6 +53,9 @@ def test_hip_builder_builds_the_same_plan(hip, case, monkeypatch):
     elif case == "muon":
         F = 11
         graphs = [synth.muon_graph(s) for s in range(700)]
+    elif case == "many_muon":   # > 8192 (graph, level) units: the sequential tile cut (pb_cut_tiles), not the parallel one
+        F = 11
+        graphs = [synth.muon_graph(s) for s in range(2600)]
     elif case == "cyclic":
         graphs = [_random_graph(400, 3000, 3, 1), _random_graph(37, 90, 3, 2),
                   synth.layered_graph(600, 5000, 3, seed=3), _random_graph(5, 40, 3, 4)]
