@@ -757,6 +757,9 @@ def run(args):
             "roofline": roof,
             "plan_ms": {"cold": t_plan * 1e3, "warm": t_plan_warm * 1e3, "warm_runs": warm_runs,
                         "builder": type(plan).__name__,
+                        "stage1": ("graph-local (one workgroup per graph / per tile, LDS tables; neighbour lists %s)"
+                                   % ("per tile in LDS" if getattr(plan, "list_mode", 0) else "by scattered pairs + a sort per list")
+                                   if getattr(plan, "graph_local", False) else "global (device-wide sweeps and radix sorts)"),
                         "fresh_batch_forward_ms": t_fresh_fwd * 1e3},
             "value_fresh_batch": e_tot / t_first,
             "fresh_batch_ms": t_first * 1e3,
