@@ -452,15 +452,21 @@ __global__ __launch_bounds__(1024) void pb_graph_levels(const int *__restrict__ 
         __syncthreads();
         for (int i = threadIdx.x; i < nh; i += B) { lvl[i] = 0; dio[i] = 0u; }
         __syncthreads();
-        // (four segments per thread in flight: one workgroup per CU has only its own loads to hide their latency)
-        for (int64_t jb = e0 + threadIdx.x; jb < e1; jb += 4 * (int64_t)B) {
-            int sv[4], dv[4];
+        // (four segments per thread in flight and the next four requested before these are worked on: one
+        // workgroup per CU has only its own loads to hide their latency)
+        auto load4 = [&](int64_t jb, int *sv, int *dv) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int64_t j = jb + (int64_t)u * B;
                 sv[u] = j < e1 ? src[j] : -1;
                 dv[u] = j < e1 ? dst[j] : -1;
             }
+        };
+        int sv[4], dv[4];
+        load4(e0 + threadIdx.x, sv, dv);
+        for (int64_t jb = e0 + threadIdx.x; jb < e1; jb += 4 * (int64_t)B) {
+            int sn_[4], dn_[4];
+            load4(jb + 4 * (int64_t)B, sn_, dn_);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int s = sv[u], d = dv[u];
@@ -472,6 +478,8 @@ __global__ __launch_bounds__(1024) void pb_graph_levels(const int *__restrict__ 
                 if ((a & 0xFFFFu) == 0xFFFFu || (b >> 16) == 0xFFFFu) miss = 1;
                 atomicMax(&lvl[d - lo], lvl[s - lo] + 1);
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { sv[u] = sn_[u]; dv[u] = dn_[u]; }
         }
         __syncthreads();
         int round = 2;
@@ -483,14 +491,10 @@ __global__ __launch_bounds__(1024) void pb_graph_levels(const int *__restrict__ 
             }
             __syncthreads();
             int changed = 0, deep = 0;
+            load4(e0 + threadIdx.x, sv, dv);
             for (int64_t jb = e0 + threadIdx.x; jb < e1; jb += 4 * (int64_t)B) {
-                int sv[4], dv[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int64_t j = jb + (int64_t)u * B;
-                    sv[u] = j < e1 ? src[j] : -1;
-                    dv[u] = j < e1 ? dst[j] : -1;
-                }
+                int sn_[4], dn_[4];
+                load4(jb + 4 * (int64_t)B, sn_, dn_);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int s = sv[u], d = dv[u];
@@ -501,6 +505,8 @@ __global__ __launch_bounds__(1024) void pb_graph_levels(const int *__restrict__ 
                     if (old < v) { changed = 1; if (v > kMaxLevelIters) deep = 1; }
                     if (root) atomicMin(&lvl[s - lo], old > v ? old : v);
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { sv[u] = sn_[u]; dv[u] = dn_[u]; }
             }
             over = __syncthreads_or(deep) != 0;
             if (over || !__syncthreads_or(changed)) break;
@@ -708,15 +714,20 @@ __global__ __launch_bounds__(1024) void pb_graph_renumber(const int *__restrict_
             for (int i = threadIdx.x; i < nh; i += B) linv[i] = inv[lo + i];
         __syncthreads();
         const int64_t span = 4 * (int64_t)B;
-        for (int64_t jb = e0 + (threadIdx.x & ~63) * 4 + (threadIdx.x & 63); jb - (threadIdx.x & 63) < e1;
-             jb += span) {                        // a wave takes 4 x 64 consecutive segments
-            int sv[4], dv[4];
+        auto load4 = [&](int64_t jb, int *sv, int *dv) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int64_t j = jb + 64 * u;
                 sv[u] = j < e1 ? __builtin_nontemporal_load(src + j) : -1;
                 dv[u] = j < e1 ? __builtin_nontemporal_load(dst + j) : -1;
             }
+        };
+        int sv[4], dv[4];
+        load4(e0 + (threadIdx.x & ~63) * 4 + (threadIdx.x & 63), sv, dv);
+        for (int64_t jb = e0 + (threadIdx.x & ~63) * 4 + (threadIdx.x & 63); jb - (threadIdx.x & 63) < e1;
+             jb += span) {                        // a wave takes 4 x 64 consecutive segments; the next four in flight
+            int sx[4], dx[4];
+            load4(jb + span, sx, dx);
             int sn[4], dn[4], t_out[4], t_in[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -764,6 +775,8 @@ __global__ __launch_bounds__(1024) void pb_graph_renumber(const int *__restrict_
                     }
                 }
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { sv[u] = sx[u]; dv[u] = dx[u]; }
         }
     }
 }
