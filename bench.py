@@ -599,6 +599,10 @@ def run(args):
         warm_runs = []
         for _ in range(3):
             fresh = HitGraphBatch.from_graphs(graphs).to(dev)
+            # (building the host arrays of 256 graphs idles the GPU for ~0.3 s and its clocks fall; a stream of
+            # never-repeated batches keeps it busy - twenty forwards of the resident batch bring the clocks back)
+            for _w in range(20):
+                model(batch)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             fresh.build_plan(D, limits)

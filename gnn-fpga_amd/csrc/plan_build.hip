@@ -806,9 +806,12 @@ __global__ __launch_bounds__(1024) void pb_lists_mode(const TR *__restrict__ tra
 __global__ __launch_bounds__(1024) void pb_tile_lists(const int *__restrict__ src_new, const int *__restrict__ dst_new,
                                                       const TR *__restrict__ trange, const int *__restrict__ tpad_off,
                                                       const I2 *__restrict__ degn, const I2 *__restrict__ ptr, int *sv_in,
-                                                      int *sv_out, const int64_t *__restrict__ hdr)
+                                                      int *sv_out, const int *__restrict__ sbase, int iter_records,
+                                                      int *t_desc, int64_t *hdr)
 {
     if (hdr[H_STATUS] || !hdr[H_LISTMODE]) return;
+    __shared__ int wred[16][2];
+    int m_rec = 0, m_in = 0, m_out = 0, n_lds = 0;      // (thread 0: this workgroup's tiles, as in pb_tile_windows)
     extern __shared__ int lds[];
     I2 *stage = reinterpret_cast<I2 *>(lds);                         // [kTileListEntries]
     int *cur = lds + 2 * kTileListEntries;                           // [kMaxSlicesPerTile * SLICE]
@@ -818,6 +821,7 @@ __global__ __launch_bounds__(1024) void pb_tile_lists(const int *__restrict__ sr
     for (int t = blockIdx.x; t < nt; t += gridDim.x) {
         const int h0 = tpad_off[t], h1 = tpad_off[t + 1], nh = h1 - h0;
         const TR r = trange[t];
+        int wlo[2] = {0x7FFFFFFF, 0x7FFFFFFF}, whi[2] = {-1, -1};    // the tile's windows (pb_tile_windows), thread 0
 #pragma unroll
         for (int dir = 0; dir < 2; ++dir) {
             const int j0 = dir ? r.out_lo : r.in_lo, j1 = dir ? -r.out_nhi : -r.in_nhi;     // inclusive
@@ -851,6 +855,27 @@ __global__ __launch_bounds__(1024) void pb_tile_lists(const int *__restrict__ sr
                     }
             }
             __syncthreads();
+            {   // the window of this direction: min / max new id over all other ends (they are all in `stage` now)
+                int mn = 0x7FFFFFFF, mx = -1;
+                for (int k = threadIdx.x; k < Lt; k += blockDim.x) {
+                    const int v = stage[k].b;
+                    mn = v < mn ? v : mn;
+                    mx = v > mx ? v : mx;
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const int x = __shfl_xor(mn, o, 64), y = __shfl_xor(mx, o, 64);
+                    mn = x < mn ? x : mn;
+                    mx = y > mx ? y : mx;
+                }
+                if ((threadIdx.x & 63) == 0) { wred[threadIdx.x >> 6][0] = mn; wred[threadIdx.x >> 6][1] = mx; }
+                __syncthreads();
+                if (threadIdx.x == 0)
+                    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+                        wlo[dir] = wred[w][0] < wlo[dir] ? wred[w][0] : wlo[dir];
+                        whi[dir] = wred[w][1] > whi[dir] ? wred[w][1] : whi[dir];
+                    }
+            }
             for (int i = grp; i < nh; i += ngrp) {
                 const int p0 = start[i], deg = cur[i] - p0;          // (the cursor stands behind the hit's list now)
                 for (int base = 0; base < deg; base += 16) {
@@ -866,6 +891,27 @@ __global__ __launch_bounds__(1024) void pb_tile_lists(const int *__restrict__ sr
                 }
             }
         }
+        if (threadIdx.x == 0) {                                     // the tile's descriptor, as pb_tile_windows writes it
+            const int icnt = whi[0] >= 0 ? whi[0] - wlo[0] + 1 : 0, ocnt = whi[1] >= 0 ? whi[1] - wlo[1] + 1 : 0;
+            const int mode = (icnt + ocnt + 2) <= iter_records ? 1 : 0;
+            int *d = t_desc + (int64_t)t * 8;
+            d[0] = h0 / SLICE; d[1] = h1 / SLICE;
+            d[2] = icnt > 0 ? wlo[0] : 0; d[3] = icnt;
+            d[4] = ocnt > 0 ? wlo[1] : 0; d[5] = ocnt;
+            d[6] = mode; d[7] = sbase[t];
+            if (mode) {
+                m_rec = icnt + ocnt + 2 > m_rec ? icnt + ocnt + 2 : m_rec;
+                m_in = icnt > m_in ? icnt : m_in;
+                m_out = ocnt > m_out ? ocnt : m_out;
+                ++n_lds;
+            }
+        }
+    }
+    if (threadIdx.x == 0 && n_lds) {
+        hdr_max(hdr, H_LDSREC, m_rec);
+        hdr_max(hdr, H_LDSIN, m_in);
+        hdr_max(hdr, H_LDSOUT, m_out);
+        hdr_add(hdr, H_NLDSTILES, n_lds);
     }
 }
 
@@ -1276,7 +1322,7 @@ __global__ __launch_bounds__(TB) void pb_tile_windows(const int *__restrict__ tp
                                                       const int *__restrict__ sv_in, const int *__restrict__ sv_out,
                                                       int iter_records, int *t_desc, int64_t *hdr)
 {
-    if (hdr[H_STATUS]) return;
+    if (hdr[H_STATUS] || hdr[H_LISTMODE]) return;      // (LISTMODE 1: pb_tile_lists wrote the descriptors)
     const int nt = (int)hdr[H_NTILES];
     __shared__ int red[4][TB / 64];
     int m_rec = 0, m_in = 0, m_out = 0, n_lds = 0;      // (thread 0: this workgroup's tiles; one set of atomics at the end)
@@ -1897,7 +1943,7 @@ static int plan_sizes_impl(const int32_t *src, const int32_t *dst, const int64_t
                    (fs && fs[0] == '1') ? 1 : 0, w.hdr);
         GNN_LAUNCH_SH("pb_tile_lists", pb_tile_lists, 4096, 1024, (size_t)(2 * kTileListEntries + 2 * kMaxSlicesPerTile * SLICE) * 4, s,
                       w.src_new, w.dst_new, reinterpret_cast<const TR *>(w.trange), w.tpad_off, w.degn, w.ptr, w.sv_in, w.sv_out,
-                      w.hdr);
+                      w.sbase, (int)iter_records, w.t_desc, w.hdr);
         if ((size_t)cap * 12 <= (size_t)kGraphLdsBytes)
             GNN_LAUNCH_SH("pb_graph_lists", pb_graph_lists<true>, ggrid, gthreads, (size_t)cap * 12, s, src, dst, hit_ptr, seg_ptr,
                           G, (int)n, cap, w.inv, w.ptr, w.src_new, w.dst_new, w.pin, w.pout, w.hdr);
