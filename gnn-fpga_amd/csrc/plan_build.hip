@@ -400,7 +400,8 @@ __host__ __device__ inline int pow2_ceil(int v) { int p = 2; while (p < v) p <<=
 // [w PW, (w + 1) PW) of a step: for strides j <= PW both words of its pairs lie in its own 2 PW words, and such steps
 // need no workgroup barrier - the wave's LDS operations complete in order (a wave-level fence keeps the compiler from
 // moving them).  Only the strides above PW (10 of the 105 steps at 16 k words and 16 waves) meet at __syncthreads().
-__device__ __forceinline__ void bitonic_sort_lds(unsigned long long *a, int M)
+template <typename W>
+__device__ __forceinline__ void bitonic_sort_lds(W *a, int M)
 {
     const int nw = (int)(blockDim.x >> 6), w = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
     const int PW = (M >> 1) / nw;                       // pairs per wave (0 for tiny M: every step at the barrier)
@@ -413,7 +414,7 @@ __device__ __forceinline__ void bitonic_sort_lds(unsigned long long *a, int M)
             for (int i = i0; i < i1; i += st) {
                 const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo | j;
                 const bool up = (lo & k) == 0;
-                const unsigned long long x = a[lo], y = a[hi];
+                const W x = a[lo], y = a[hi];
                 if ((x > y) == up) { a[lo] = y; a[hi] = x; }
             }
             if (local) {
@@ -440,6 +441,7 @@ __global__ __launch_bounds__(1024) void pb_graph_levels(const int *__restrict__ 
     int *lvl = lds;                                              // [cap]
     unsigned *dio = reinterpret_cast<unsigned *>(lds + cap);     // [cap]  in-degree | out-degree << 16
     __shared__ int red[16];
+    __shared__ int gm[3];                                        // this graph's largest level, in- and out-degree
     const int B = (int)blockDim.x;
     int cnt = 0, bad = 0, miss = 0, lmax = 0;
     for (int64_t g = blockIdx.x; g < G; g += gridDim.x) {
@@ -512,6 +514,9 @@ __global__ __launch_bounds__(1024) void pb_graph_levels(const int *__restrict__ 
             if (over || !__syncthreads_or(changed)) break;
         }
         if (over || round > kMaxLevelIters + 2) { miss = 1; continue; }
+        if (threadIdx.x < 3) gm[threadIdx.x] = 0;
+        __syncthreads();
+        int g_lv = 0, g_di = 0, g_do = 0;
         for (int i = threadIdx.x; i < nh; i += B) {
             const unsigned w = dio[i];
             const int di = (int)(w & 0xFFFFu), dout = (int)(w >> 16);
@@ -519,6 +524,7 @@ __global__ __launch_bounds__(1024) void pb_graph_levels(const int *__restrict__ 
             if (di == 0) { lv = dout > 0 ? lv - 1 : 0; if (lv < 0) lv = 0; }
             if (di > kFastMaxDegree || dout > kFastMaxDegree) miss = 1;
             lmax = lv > lmax ? lv : lmax;
+            g_lv = lv > g_lv ? lv : g_lv; g_di = di > g_di ? di : g_di; g_do = dout > g_do ? dout : g_do;
             const int h = lo + i;
             deg_in[h] = di; deg_out[h] = dout; level[h] = lv; gid[h] = (int)g; iota[h] = h;
             hkey[h] = (int)g * 128 + (lv & 127);
@@ -526,6 +532,12 @@ __global__ __launch_bounds__(1024) void pb_graph_levels(const int *__restrict__ 
                      ((unsigned long long)(0xFFFF - di) << 16) | (unsigned long long)(0xFFFF - dout);
             lvl[i] = lv;
         }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int x = __shfl_xor(g_lv, o, 64), y = __shfl_xor(g_di, o, 64), z = __shfl_xor(g_do, o, 64);
+            g_lv = x > g_lv ? x : g_lv; g_di = y > g_di ? y : g_di; g_do = z > g_do ? z : g_do;
+        }
+        if ((threadIdx.x & 63) == 0) { atomicMax(&gm[0], g_lv); atomicMax(&gm[1], g_di); atomicMax(&gm[2], g_do); }
         __syncthreads();
         // run starts of the (graph, start level) key for the edge chunks (pb_seg_keys + carry scan + pb_run_flags of
         // the global form): segment 0, and every valid segment whose start hit's level differs from that of the
@@ -549,16 +561,43 @@ __global__ __launch_bounds__(1024) void pb_graph_levels(const int *__restrict__ 
         // (graph, level) unit starts where the level changes (pb_unit_flags).
         __syncthreads();
         if (nh > 0) {
-            unsigned long long *a = reinterpret_cast<unsigned long long *>(lds);
             const int M = pow2_ceil(nh);
-            for (int i = threadIdx.x; i < M; i += B)
-                a[i] = i < nh ? ((key[lo + i] & ((1ull << 39) - 1ull)) << 15) | (unsigned long long)i : ~0ull;
-            __syncthreads();
-            bitonic_sort_lds(a, M);
-            for (int r = threadIdx.x; r < nh; r += B) {
-                const unsigned long long e = a[r];
-                base[lo + r] = lo + (int)(e & 0x7FFFull);
-                uflag[lo + r] = (r == 0 || (a[r - 1] >> 47) != (e >> 47)) ? 1 : 0;
+            // bits of this graph's levels, degrees and ids: 32-bit words when they fit (a detector graph: 4 + 5 + 5 +
+            // 14) - the sort is bound by the LDS traffic of its steps, half of it with half the word
+            auto bw = [](int v) { int b = 1; while ((1 << b) <= v) ++b; return b; };
+            const int bi = bw(nh - 1), bo = bw(gm[2]), bd = bw(gm[1]), bl = bw(gm[0]);
+            if (bl + bd + bo + bi <= 32) {                            // (workgroup-uniform)
+                // in place: the key of hit i takes the word of lvl[i]; the padding words reach into the degree table, so
+                // they are written once every key has been made
+                unsigned *a = reinterpret_cast<unsigned *>(lds);
+                const int mdi = gm[1], mdo = gm[2];
+                for (int i = threadIdx.x; i < nh; i += B) {
+                    const unsigned w = dio[i];
+                    a[i] = ((unsigned)lvl[i] << (bd + bo + bi)) | ((unsigned)(mdi - (int)(w & 0xFFFFu)) << (bo + bi)) |
+                           ((unsigned)(mdo - (int)(w >> 16)) << bi) | (unsigned)i;
+                }
+                __syncthreads();
+                for (int i = nh + threadIdx.x; i < M; i += B) a[i] = 0xFFFFFFFFu;
+                __syncthreads();
+                bitonic_sort_lds(a, M);
+                const unsigned idm = (1u << bi) - 1u;
+                const int ls = bd + bo + bi;
+                for (int r = threadIdx.x; r < nh; r += B) {
+                    const unsigned e = a[r];
+                    base[lo + r] = lo + (int)(e & idm);
+                    uflag[lo + r] = (r == 0 || (a[r - 1] >> ls) != (e >> ls)) ? 1 : 0;
+                }
+            } else {
+                unsigned long long *a = reinterpret_cast<unsigned long long *>(lds);
+                for (int i = threadIdx.x; i < M; i += B)
+                    a[i] = i < nh ? ((key[lo + i] & ((1ull << 39) - 1ull)) << 15) | (unsigned long long)i : ~0ull;
+                __syncthreads();
+                bitonic_sort_lds(a, M);
+                for (int r = threadIdx.x; r < nh; r += B) {
+                    const unsigned long long e = a[r];
+                    base[lo + r] = lo + (int)(e & 0x7FFFull);
+                    uflag[lo + r] = (r == 0 || (a[r - 1] >> 47) != (e >> 47)) ? 1 : 0;
+                }
             }
         }
     }
