@@ -1027,7 +1027,7 @@ __global__ __launch_bounds__(TB) void pb_compact(int64_t n, const int *__restric
 // the chunk: the loop-carried chain of the one walking thread is then one 16-byte LDS read per four
 // tiles instead of four dependent 4-byte reads per tile - 0.43 -> 0.1 ms for the 2816 units of c3 x 256.)
 constexpr int kCutChunk = 2048;
-// Up to kParUnits units (8192: 128 KB of LDS) the same cut without the sequential walk: the tile starts are the ORBIT
+// Up to kParUnits units (8192: 96 KB of LDS) the same cut without the sequential walk: the tile starts are the ORBIT
 // of unit 0 under "next tile start" (nxt[i] as below; i + 1 after a unit that is split), and an orbit is marked by
 // pointer doubling - after round r the first 2^r tile starts carry a mark and jump[i] = nxt^(2^r)(i): 13 rounds of
 // two barriers instead of one dependent LDS read per tile by one thread (0.22 -> 0.03 ms for the 2816 units of c3 x
@@ -1041,7 +1041,6 @@ __global__ __launch_bounds__(1024) void pb_cut_tiles_par(const int *__restrict__
     int *st = lds;                                 // [kParUnits + 1]
     int *jump = st + kParUnits + 1;                // [kParUnits]
     int *mark = jump + kParUnits;                  // [kParUnits]
-    int *off = mark + kParUnits;                   // [kParUnits] boundaries a tile start emits, then their exclusive scan
     __shared__ int part[1024];
     const int nu = (int)hdr[H_NUNITS];
     if (nu > kParUnits) return;
@@ -1566,14 +1565,17 @@ __global__ __launch_bounds__(TB) void pb_chunk_windows(const int *__restrict__ c
 {
     if (hdr[H_STATUS]) return;
     const int nc = (int)hdr[H_NCHUNKS];
+    const int npad = (int)hdr[H_NPAD];
     __shared__ int red[4][TB / 64];
     int m_rows = 0, n_lds = 0;                          // (thread 0: this workgroup's chunks)
     for (int c = blockIdx.x; c < nc; c += gridDim.x) {
         const int e0 = cb[c], e1 = cb[c + 1];
         int slo = 0x7FFFFFFF, shi = -1, dlo = 0x7FFFFFFF, dhi = -1;
+        // (a padded segment carries the id behind the last padded hit in both ends: no look at src; four steps in flight)
+#pragma unroll 4
         for (int j = e0 + threadIdx.x; j < e1; j += TB) {
-            if (src[j] >= 0) {
-                const int s = src_new[j], d = dst_new[j];
+            const int s = src_new[j], d = dst_new[j];
+            if (s < npad) {
                 slo = s < slo ? s : slo; shi = s > shi ? s : shi;
                 dlo = d < dlo ? d : dlo; dhi = d > dhi ? d : dhi;
             }
@@ -1696,17 +1698,20 @@ __global__ __launch_bounds__(TB) void pb_fill_lists(int64_t n_pad, const I2 *__r
         const int steps = (IN ? sl.a : sl.b) / SLICE, steps8 = (IN ? sl.c : sl.d) / SLICE;
         int *o32 = nbr + (IN ? of.a : of.b) + i;
         int *o16 = nbr16 + (IN ? of.c : of.d) / 2 + i;
-        for (int k = 0; k < steps8; k += 2) {
-            int v[2];
+        for (int k = 0; k < steps8; k += 8) {            // (steps8 is a multiple of 8: eight list entries in flight)
+            int v[8];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < 8; ++u) v[u] = k + u < deg ? sv[p0 + k + u] : 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
                 const int kk = k + u;
-                int x = null;
-                if (kk < deg) { x = sv[p0 + kk]; if (lds) x -= lo; }
+                const int x = kk < deg ? (lds ? v[u] - lo : v[u]) : null;
                 v[u] = x;
                 if (kk < steps) o32[kk * SLICE] = x;
             }
-            o16[(k >> 1) * SLICE] = (int)(((unsigned)v[0] & 0xFFFFu) | (((unsigned)v[1] & 0xFFFFu) << 16));
+#pragma unroll
+            for (int u = 0; u < 8; u += 2)
+                o16[((k + u) >> 1) * SLICE] = (int)(((unsigned)v[u] & 0xFFFFu) | (((unsigned)v[u + 1] & 0xFFFFu) << 16));
         }
     }
 }
@@ -1950,7 +1955,7 @@ static int plan_sizes_impl(const int32_t *src, const int32_t *dst, const int64_t
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pb_cut_tiles_par),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kGraphLdsBytes);
     }
-    GNN_LAUNCH_SH("pb_cut_tiles_par", pb_cut_tiles_par, 1, 1024, (size_t)(4 * kParUnits + 1) * 4, s, w.ustart, (int)n,
+    GNN_LAUNCH_SH("pb_cut_tiles_par", pb_cut_tiles_par, 1, 1024, (size_t)(3 * kParUnits + 1) * 4, s, w.ustart, (int)n,
                   (int)tile_hits, w.tile_bounds, w.hdr, (int)b.nt_max);
     GNN_LAUNCH("pb_cut_tiles", pb_cut_tiles, 1, 1024, s, w.ustart, (int)n, (int)tile_hits, w.tile_bounds, w.hdr,
                (int)b.nt_max);
