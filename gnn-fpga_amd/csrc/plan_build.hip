@@ -203,7 +203,7 @@ struct OpOr { __device__ int operator()(int a, int b) const { return a | b; } };
 // into and, when it is narrow enough, counts in LDS and flushes only the touched counters - a few
 // thousand global atomics per workgroup instead of 32 k.  Wide ranges (shuffled input) count in global
 // memory as before.
-constexpr int kDegSegs = 16384, kDegRange = 16384;
+constexpr int kDegSegs = 16384, kDegRange = 16384, kDegWindows = 4;
 // The builder does not trust its endpoints: a segment is VALID when both ends lie in [0, n); a padded
 // segment has both ends negative; anything else (an end >= n, one end negative) sets ST_ENDPOINT and
 // is skipped by every kernel that indexes per-hit arrays before the caller reads the status back.
@@ -240,31 +240,44 @@ __global__ __launch_bounds__(1024) void pb_degrees(const int *__restrict__ src, 
             lo = red[2 * w] < lo ? red[2 * w] : lo;
             hi = red[2 * w + 1] > hi ? red[2 * w + 1] : hi;
         }
-        const bool local = hi >= lo && hi - lo < kDegRange;
-        if (local)
-            for (int i = threadIdx.x; i <= hi - lo; i += 1024) cin[i] = cout[i] = 0;
-        __syncthreads();
-        for (int64_t j = b0 + threadIdx.x; j < b1; j += 1024) {
-            const int s = src[j], d = dst[j];
-            if (seg_ok(s, d, n)) {
-                if (local) {
-                    atomicAdd(&cout[s - lo], 1);
-                    atomicAdd(&cin[d - lo], 1);
-                } else {
+        // up to kDegWindows windows of kDegRange hits, one pass over the block's segments (L2-resident by now) per
+        // window: the 50 k-hit graphs of the mu200 shape number their hits in no layer order, so a block's ends span
+        // the whole graph - two global atomics per segment cost 0.31 ms of that batch's 1.7 ms plan
+        const int span = hi >= lo ? hi - lo + 1 : 0;
+        const int nwin = (span + kDegRange - 1) / kDegRange;
+        const bool local = nwin >= 1 && nwin <= kDegWindows;
+        if (!local) {
+            for (int64_t j = b0 + threadIdx.x; j < b1; j += 1024) {
+                const int s = src[j], d = dst[j];
+                if (seg_ok(s, d, n)) {
                     atomicAdd(&deg_out[s], 1);
                     atomicAdd(&deg_in[d], 1);
+                    ++cnt;
                 }
-                ++cnt;
             }
+            __syncthreads();
+            continue;                                      // (workgroup-uniform)
         }
-        __syncthreads();
-        if (local)
-            for (int i = threadIdx.x; i <= hi - lo; i += 1024) {
-                const int a = cin[i], b = cout[i];
-                if (a) atomicAdd(&deg_in[lo + i], a);
-                if (b) atomicAdd(&deg_out[lo + i], b);
+        for (int w = 0; w < nwin; ++w) {
+            const int wlo = lo + w * kDegRange, wn = span - w * kDegRange < kDegRange ? span - w * kDegRange : kDegRange;
+            for (int i = threadIdx.x; i < wn; i += 1024) cin[i] = cout[i] = 0;
+            __syncthreads();
+            for (int64_t j = b0 + threadIdx.x; j < b1; j += 1024) {
+                const int s = src[j], d = dst[j];
+                if (seg_ok(s, d, n)) {
+                    if ((unsigned)(s - wlo) < (unsigned)wn) atomicAdd(&cout[s - wlo], 1);
+                    if ((unsigned)(d - wlo) < (unsigned)wn) atomicAdd(&cin[d - wlo], 1);
+                    if (w == 0) ++cnt;
+                }
             }
-        __syncthreads();
+            __syncthreads();
+            for (int i = threadIdx.x; i < wn; i += 1024) {
+                const int a = cin[i], b = cout[i];
+                if (a) atomicAdd(&deg_in[wlo + i], a);
+                if (b) atomicAdd(&deg_out[wlo + i], b);
+            }
+            __syncthreads();
+        }
     }
     cnt = block_reduce_i(cnt, red, OpAdd());
     bad = block_reduce_i(bad, red, OpOr());
@@ -1200,30 +1213,6 @@ __global__ __launch_bounds__(1024) void pb_cut_tiles(const int *__restrict__ ust
     }
 }
 
-__device__ __forceinline__ int tile_of(const int *__restrict__ bounds, int nt, int p)
-{
-    int lo = 0, hi = nt;                 // last t with bounds[t] <= p
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (bounds[mid] <= p) lo = mid; else hi = mid;
-    }
-    return lo;
-}
-
-__global__ __launch_bounds__(TB) void pb_key2(int64_t n, const int *__restrict__ base, const int *__restrict__ deg_in,
-                                              const int *__restrict__ deg_out, const int *__restrict__ tile_bounds,
-                                              const int64_t *__restrict__ hdr, int *tpos, unsigned long long *key)
-{
-    if (hdr[H_STATUS]) return;             // (base[] may be the sorted image of unwritten ids)
-    const int nt = (int)hdr[H_NTILES];
-    GS_LOOP(p, n) {
-        const int old = base[p];
-        const int t = tile_of(tile_bounds, nt, (int)p);
-        tpos[p] = t;
-        key[p] = ((unsigned long long)(unsigned)t << 32) |
-                 ((unsigned long long)(0xFFFF - ((deg_in[old] + 3) >> 2)) << 16) | (unsigned long long)(0xFFFF - deg_out[old]);
-    }
-}
 
 // The second hit sort of the global form - (tile, -ceil(in / 4), -out), stable in the first sort's order - is local
 // to a tile of at most kMaxSlicesPerTile * SLICE hits: one workgroup per tile sorts (key, position) words in LDS.
@@ -1959,14 +1948,9 @@ static int plan_sizes_impl(const int32_t *src, const int32_t *dst, const int64_t
                   (int)tile_hits, w.tile_bounds, w.hdr, (int)b.nt_max);
     GNN_LAUNCH("pb_cut_tiles", pb_cut_tiles, 1, 1024, s, w.ustart, (int)n, (int)tile_hits, w.tile_bounds, w.hdr,
                (int)b.nt_max);
-    if (fast) {
-        GNN_LAUNCH("pb_tile_sort", pb_tile_sort, 4096, TB, s, n, w.base, w.deg_in, w.deg_out, w.tile_bounds, w.hdr, w.tpos, w.oor);
-    } else {
-        GNN_LAUNCH("pb_key2", pb_key2, gs(n), TB, s, n, w.base, w.deg_in, w.deg_out, w.tile_bounds, w.hdr, w.tpos, w.k64a);
-        tb = w.temp_bytes;
-        HIP_OK(rocprim::radix_sort_pairs(w.temp, tb, (const unsigned long long *)w.k64a, w.k64b, (const int *)w.base, w.oor,
-                                         (size_t)n, 0u, 32u + bit_width((uint64_t)b.nt_max), s, false), "hit sort 2");
-    }
+    // (both forms: the second hit sort is local to a tile - one workgroup sorts it in LDS; the global form ran a
+    // device-wide radix sort of (tile, -ceil(in / 4), -out) keys here until late round 3)
+    GNN_LAUNCH("pb_tile_sort", pb_tile_sort, 4096, TB, s, n, w.base, w.deg_in, w.deg_out, w.tile_bounds, w.hdr, w.tpos, w.oor);
     GNN_LAUNCH("pb_tile_offsets", pb_tile_offsets, 1, 1024, s, w.tile_bounds, w.tpad_off, w.sbase, w.hdr, b.np_max);
     GNN_LAUNCH("pb_new_ids", pb_new_ids, gs(n + 1), TB, s, n, w.oor, w.tpos, w.tile_bounds, w.tpad_off, w.deg_in, w.deg_out,
                w.inv, w.degn, w.slice_tile, w.hdr);
