@@ -48,7 +48,7 @@ inline unsigned gs(int64_t n)
 // device header (int64 slots) - counts that later kernels read and the final sizes are made from
 enum Hdr {
     H_NVALID, H_NUNITS, H_NTILES, H_NPAD, H_TILEMAX, H_NSCHED, H_NRUNS, H_NMARKS, H_NCHUNKS, H_STATUS,
-    H_LDSREC, H_NLDSTILES, H_LDSIN, H_LDSOUT, H_EDGEROWS, H_NLDSCHUNKS, H_MAXSTEPS, H_MAXLEVEL, H_LISTMODE, H_COUNT = 32
+    H_LDSREC, H_NLDSTILES, H_LDSIN, H_LDSOUT, H_EDGEROWS, H_NLDSCHUNKS, H_MAXSTEPS, H_MAXLEVEL, H_LISTMODE, H_SPARSE, H_COUNT = 32
 };
 enum Status { ST_OK = 0, ST_DEGREE = 1, ST_TILES = 2, ST_PAD = 4, ST_CHUNKS = 8, ST_SLICES = 16, ST_I32 = 32,
               ST_ENDPOINT = 64 };   // ST_ENDPOINT: a segment end outside [0, n_hits), or exactly one end negative
@@ -750,12 +750,16 @@ __global__ __launch_bounds__(1024) void pb_graph_renumber(const int *__restrict_
                                                           const int64_t *__restrict__ hit_ptr,
                                                           const int64_t *__restrict__ seg_ptr, int64_t G, int n, int cap,
                                                           const int *__restrict__ inv, const int *__restrict__ slice_tile,
-                                                          int *src_new, int *dst_new, TR *trange,
-                                                          const int64_t *__restrict__ hdr)
+                                                          int *src_new, int *dst_new, TR *trange, int64_t *hdr)
 {
     if (hdr[H_STATUS]) return;
     extern __shared__ int lds[];
     int *linv = lds;
+    // Small tiles (few graphs: plan.py cuts a batch into >= 512 tiles) put a level's hits into many tiles, and a wave's 64
+    // consecutive segments then end in a dozen of them: a dozen rounds of the range loop below per instruction (1 ms
+    // for four detector graphs) for ranges pb_lists_mode would refuse anyway.  A wave that meets more than sixteen tiles
+    // raises H_SPARSE (pb_lists_mode: scattered pairs) and stops keeping ranges.
+    bool ranges = true;
     const int B = (int)blockDim.x;
     const int npad = inv[n];
     for (int64_t g = blockIdx.x; g < G; g += gridDim.x) {
@@ -809,11 +813,18 @@ __global__ __launch_bounds__(1024) void pb_graph_renumber(const int *__restrict_
             for (int u = 0; u < 4; ++u) {
                 const int jj = (int)(jb + 64 * u);
                 const bool ok = sv[u] >= 0;
+                if (!ranges) continue;                                        // (wave-uniform)
 #pragma unroll
                 for (int dir = 0; dir < 2; ++dir) {
                     const int t = dir ? t_out[u] : t_in[u];
                     unsigned long long rem = __ballot(ok);
+                    int trips = 0;
                     while (rem) {                                             // (wave-uniform)
+                        if (++trips > 16) {
+                            if (lane == 0) hdr[H_SPARSE] = 1;
+                            ranges = false;
+                            break;
+                        }
                         const int leader = __ffsll((long long)rem) - 1;
                         const int tl = __shfl(t, leader, 64);
                         const unsigned long long same = __ballot(ok && t == tl);
@@ -852,7 +863,7 @@ __global__ __launch_bounds__(1024) void pb_lists_mode(const TR *__restrict__ tra
     const int tot = block_reduce_i((int)((len + 63) >> 6), red, OpAdd());
     big = block_reduce_i(big, red, OpOr());
     if (threadIdx.x == 0)
-        hdr[H_LISTMODE] = (!force_scatter && !big && (long long)tot * 64 <= 16 * (long long)E + 64ll * nt + 65536) ? 1 : 0;
+        hdr[H_LISTMODE] = (!force_scatter && !big && !hdr[H_SPARSE] && (long long)tot * 64 <= 16 * (long long)E + 64ll * nt + 65536) ? 1 : 0;
 }
 
 __global__ __launch_bounds__(1024) void pb_tile_lists(const int *__restrict__ src_new, const int *__restrict__ dst_new,

@@ -47,8 +47,11 @@ class HipSellPlan(SellPlan):
         # the graph-local stage 1 (one workgroup per graph, LDS tables) when the batch names its graphs' segment
         # ranges and the largest graph fits; the kernels check the layout themselves (status 128 -> the global form)
         local = graph_local if graph_local is not None else os.environ.get("GNN_PLAN_GRAPH_LOCAL", "1") != "0"
-        if graph_local is None and G < 4:
-            local = False       # (one workgroup per graph: 0.70 against 0.60 ms for a single detector graph, 1.2 / 1.4 at 32)
+        if graph_local is None and E < 16 * int(np.diff(sp).max()) and int(np.diff(sp).max()) > 8192:
+            # one workgroup per graph: a graph-local build takes as long as its largest graph does (1 ms for a 100 k-segment
+            # detector graph), the global form as long as all segments together (0.75 ms + 0.02 ms per such graph):
+            # 1.29 / 0.76 ms at 4 detector graphs, 0.98 / 0.86 at 8, 0.92 / 0.92 at 16, 0.95 / 1.07 at 24, 1.03 / 1.41 at 32
+            local = False
         local = bool(local and len(sp) == G + 1 and int(sp[0]) == 0 and int(sp[-1]) == E
                      and int(np.diff(hp).max()) <= _lib.PLAN_GRAPH_CAP_HITS)
         ptrs = torch.from_numpy(np.concatenate([hp, sp]) if local else hp).to(dev)       # one upload

@@ -86,8 +86,9 @@ def test_hip_builder_builds_the_same_plan(hip, case, monkeypatch):
     lim = hip.plan_limits(F, D)
     lim.update(lim_over)
     host = SellPlan(b, lim)
-    # (batches of fewer than four graphs take the global form by default: ask for the graph-local one)
-    dev = HipSellPlan(b.cuda(), lim, debug=True, graph_local=True if len(graphs) < 4 else None)
+    # (a batch of fewer than sixteen graphs the size of its largest takes the global form by default, unless they are
+    # small: ask for the graph-local one)
+    dev = HipSellPlan(b.cuda(), lim, debug=True, graph_local=True)
     assert dev.X.is_cuda
     _same_plan(host, dev)
     # which stage 1 built it: the graph-local form (one workgroup per graph, LDS tables) wherever a batch's graphs
@@ -108,6 +109,21 @@ def test_hip_builder_builds_the_same_plan(hip, case, monkeypatch):
             monkeypatch.delenv("GNN_PLAN_SCATTER_LISTS")
             assert scat.graph_local and scat.list_mode == 0
             _same_plan(host, scat)
+
+
+def test_graph_local_builder_is_chosen_where_it_pays(hip):
+    """One workgroup per graph: the graph-local stage 1 takes as long as its LARGEST graph does, the global form as long
+    as all segments together - the default takes the graph-local form from sixteen graphs of the largest one's size on,
+    and always for small graphs (muon events)."""
+    from gnn_fpga_amd.plan_hip import HipSellPlan
+    lim = hip.plan_limits(3, 8)
+    few = HitGraphBatch.from_graphs([synth.layered_graph(3000, 30000, 3, seed=s) for s in range(5)]).cuda()
+    many = HitGraphBatch.from_graphs([synth.layered_graph(3000, 30000, 3, seed=s) for s in range(16)]).cuda()
+    small = HitGraphBatch.from_graphs([synth.layered_graph(300, 2000, 3, seed=s) for s in range(3)]).cuda()
+    assert not HipSellPlan(few, lim).graph_local
+    assert HipSellPlan(many, lim).graph_local
+    assert HipSellPlan(small, lim).graph_local
+    assert HipSellPlan(few, lim, graph_local=True).graph_local
 
 
 def test_graph_local_builder_checks_the_layout_it_is_told(hip):
