@@ -19,6 +19,12 @@
 //   tile / chunk descriptors, wave schedules (the two-phase greedy of plan.py in float64, one
 //   wavefront per tile), renumbered X, endpoints.              (gnn_plan_build_fill)
 //
+// The recipe above is the GLOBAL form (gnn_plan_build_sizes): it treats a batch as one big graph.  A batch that names its
+// graphs' segment ranges (gnn_plan_build_sizes_graphs, ABI 5) takes the GRAPH-LOCAL form of stage 1 instead - the same
+// arrays, entry for entry, from kernels that keep one graph's (pb_graph_levels, pb_graph_renumber) or one tile's
+// (pb_tile_sort, pb_tile_lists) tables in LDS: no level sweeps over all segments, no device-wide sort; see the block
+// comments at those kernels.  It checks the layout it is told and reports status 128 when it does not hold.
+//
 // Device-wide radix sorts and scans are rocPRIM's (plain library primitives, like a library GEMM);
 // everything else is hand-written.  All kernels are grid-stride on bounded grids (an early-exit
 // sweep costs a launch, not a dispatch of 100 k idle workgroups).  Integer work: bit-exact against
