@@ -658,6 +658,23 @@ def run(args):
                       "kernels_hidden_dim": info and info["hidden_dim"],
                       "ms_per_step_full_width": times[False] * 1e3, "ms_per_step": times[True] * 1e3,
                       "speedup": times[False] / times[True], "value": e_tot_local / times[True]}
+            # the reference's OWN pruned model (gnn/MPNN_Seg_ACTS_maskedlinear.ipynb cell 34: 2 of 8 edge hidden units
+            # dead, nothing else): no narrower width exists for it - on the record as such
+            me2 = [torch.ones(D, 2 * C), torch.ones(1, D)]
+            me2[0][1, :] = 0
+            me2[0][6, :] = 0
+            torch.manual_seed(0)
+            pe = SegmentClassifier(input_dim=F, hidden_dim=D, n_iters=T, masks_e=me2,
+                                   masks_n=[torch.ones(D, 3 * C), torch.ones(D, D)]).to(dev).eval()
+            pe.use_events = False
+            for _ in range(3):
+                pe(fresh)
+            t_eo = time_steps(lambda: pe(fresh), ps, sync_all) / ps
+            einfo = pe.pruned_info()
+            pruned["edge_only"] = {"masks": "2 of 8 edge hidden units dead (the reference's pruned model)",
+                                   "kernels_hidden_dim": (einfo and einfo["hidden_dim"]) or D,
+                                   "ms_per_step": t_eo * 1e3,
+                                   "note": "no specialisation: six live units still occupy a hit's four lanes"}
         del fresh
     if world > 1:
         tmax = torch.tensor([elapsed, exact or 0.0], dtype=torch.float64, device=dev)
