@@ -717,7 +717,7 @@ def plan_build_workspace_bytes(n_hits, n_segments, chunk_segments):
     return int(load().gnn_plan_build_workspace_bytes(n_hits, n_segments, chunk_segments))
 
 
-PLAN_GRAPH_CAP_HITS = 16384      # csrc/plan_build.hip kGraphCapHits: LDS tables and sort keys of the graph-local stage 1
+PLAN_GRAPH_CAP_HITS = 19456      # csrc/plan_build.hip kGraphCapHits: LDS tables and sort keys of the graph-local stage 1
 PLAN_STATUS_FAST_MISS = 128
 
 

@@ -410,7 +410,8 @@ __global__ __launch_bounds__(1024) void pb_levels_small(const int *__restrict__ 
 // global form (every output of this kernel is rewritten there).
 constexpr int ST_FAST_MISS = 128;
 constexpr int kGraphLdsBytes = 152 * 1024;
-constexpr int kGraphCapHits = 16384;                       // hits per graph: 8 bytes of tables, then 8-byte sort keys
+constexpr int kGraphCapHits = kGraphLdsBytes / 8;          // 19456 hits per graph: 8 bytes of tables, then the sort keys
+constexpr int kGraphCapHits64 = 16384;                     // ... 8-byte keys up to here, beyond it only 4-byte ones fit
 __host__ __device__ inline int pow2_ceil(int v) { int p = 2; while (p < v) p <<= 1; return p; }
 
 // bitonic sort of M (a power of two) 64-bit words in LDS, ascending; every thread of the workgroup calls.
@@ -606,6 +607,8 @@ __global__ __launch_bounds__(1024) void pb_graph_levels(const int *__restrict__ 
                     base[lo + r] = lo + (int)(e & idm);
                     uflag[lo + r] = (r == 0 || (a[r - 1] >> ls) != (e >> ls)) ? 1 : 0;
                 }
+            } else if (nh > kGraphCapHits64) {                        // (8-byte keys of > 16 k hits do not fit the LDS)
+                miss = 1;
             } else {
                 unsigned long long *a = reinterpret_cast<unsigned long long *>(lds);
                 for (int i = threadIdx.x; i < M; i += B)
@@ -1905,7 +1908,8 @@ static int plan_sizes_impl(const int32_t *src, const int32_t *dst, const int64_t
         HIP_OK(hipMemsetAsync(w.hdr, 0, (size_t)(reinterpret_cast<char *>(w.deg_in) - reinterpret_cast<char *>(w.hdr)), s),
                "memset");
         HIP_OK(hipMemsetAsync(w.degn, 0, (size_t)(b.np_max + 1) * sizeof(I2), s), "memset");
-        GNN_LAUNCH_SH("pb_graph_levels", pb_graph_levels, ggrid, gthreads, (size_t)pow2_ceil(cap) * 8, s, src, dst, hit_ptr, seg_ptr, G, n,
+        GNN_LAUNCH_SH("pb_graph_levels", pb_graph_levels, ggrid, gthreads,
+                      cap <= kGraphCapHits64 ? (size_t)pow2_ceil(cap) * 8 : (size_t)cap * 8, s, src, dst, hit_ptr, seg_ptr, G, n,
                       E, cap, w.deg_in, w.deg_out, w.gid, level, w.k64a, w.iota, w.hkey, w.mscan, w.base, w.uflag, w.hdr);
     } else {
     // header, sweep flags, degrees and both level buffers start at zero (adjacent in the workspace)

@@ -332,7 +332,7 @@ int gnn_plan_build_sizes(const int32_t *src, const int32_t *dst, const int64_t *
  * lists are then built by one workgroup per graph in LDS instead of device-wide sweeps and sorts (same arrays, entry
  * for entry).  The kernels CHECK the layout they were told: status bit 128 = it does not hold for this batch (an end
  * outside its graph's hit range, ranges that do not tile [0, n_hits) / [0, n_segments), a level above 64, a hit with
- * more than 1024 segments in one direction) - call gnn_plan_build_sizes instead.  max_graph_hits > 16384:
+ * more than 1024 segments in one direction, a graph of more than 16384 hits whose level / degree / id bits exceed a 32-bit sort key) - call gnn_plan_build_sizes instead.  max_graph_hits > 19456:
  * GNN_ERR_UNSUPPORTED. */
 int gnn_plan_build_sizes_graphs(const int32_t *src, const int32_t *dst, const int64_t *hit_ptr, const int64_t *seg_ptr,
                                 int64_t max_graph_hits, int64_t max_graph_segments, int64_t n_hits,

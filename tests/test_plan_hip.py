@@ -22,7 +22,7 @@ def _random_graph(n, e, F, seed):
 
 
 CASES = ["layered", "ragged", "padded", "global", "wide", "one_graph_big_levels", "muon", "cyclic",
-         "shuffled", "big_shuffled", "c3", "many_c3", "leading_pads", "tiny_tiles", "many_muon"]
+         "shuffled", "big_shuffled", "c3", "many_c3", "leading_pads", "tiny_tiles", "many_muon", "mu200_size"]
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -56,6 +56,8 @@ def test_hip_builder_builds_the_same_plan(hip, case, monkeypatch):
     elif case == "many_muon":   # > 8192 (graph, level) units: the sequential tile cut (pb_cut_tiles), not the parallel one
         F = 11
         graphs = [synth.muon_graph(s) for s in range(2600)]
+    elif case == "mu200_size":  # graphs between 16384 and 19456 hits: graph-local with 32-bit sort keys only
+        graphs = [synth.layered_graph(18000, 70000, 3, seed=9), synth.layered_graph(15000, 58000, 3, seed=10)]
     elif case == "cyclic":
         graphs = [_random_graph(400, 3000, 3, 1), _random_graph(37, 90, 3, 2),
                   synth.layered_graph(600, 5000, 3, seed=3), _random_graph(5, 40, 3, 4)]
@@ -102,7 +104,8 @@ def test_hip_builder_builds_the_same_plan(hip, case, monkeypatch):
         # neighbour lists: per tile in LDS when the segments of a tile's lists lie together (the reference's layer-pair
         # order), by scattered pairs + a sort per list otherwise (a graph's segments shuffled) - and on request
         # (one c3 graph: 64-hit tiles cut every level into 16 - its layer-pair block would be read 16 times)
-        assert dev.list_mode == (0 if case in ("shuffled", "c3") else 1), (case, dev.list_mode)
+        # (likewise two mu200-size graphs: 80-hit tiles)
+        assert dev.list_mode == (0 if case in ("shuffled", "c3", "mu200_size") else 1), (case, dev.list_mode)
         if dev.list_mode:
             monkeypatch.setenv("GNN_PLAN_SCATTER_LISTS", "1")
             scat = HipSellPlan(b.cuda(), lim, debug=True, graph_local=True)
