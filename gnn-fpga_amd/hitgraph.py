@@ -91,8 +91,7 @@ class HitGraphBatch:
         if X.ndim != 2 or src.ndim != 1 or src.shape != dst.shape:
             raise ValueError("expected X [N,F], src [E], dst [E]")
         n = X.shape[0]
-        pad = src < 0
-        if np.any(pad != (dst < 0)):
+        if np.any((src ^ dst) < 0):                  # signs differ: exactly one end negative
             raise ValueError("a padded segment must have src = dst = -1")
         if src.size and (src.max(initial=-1) >= n or dst.max(initial=-1) >= n):
             raise ValueError("segment endpoint out of range")
@@ -325,17 +324,26 @@ class HitGraphBatch:
         ys = [getattr(g, "y", None) for g in graphs]
         have_y = not any(v is None for v in ys)
 
-        def cat(field, offset):
-            parts = []
-            for i, g in enumerate(graphs):
-                a = np.asarray(getattr(g, field), dtype=np.int64)
-                a = np.where(a >= 0, a + (hit_ptr[i] if offset else 0), -1)
-                if pad_segments and a.shape[0] < e_max:
-                    a = np.concatenate([a, np.full(e_max - a.shape[0], -1, dtype=np.int64)])
-                parts.append(a)
-            return np.concatenate(parts) if parts else np.zeros(0, np.int64)
+        if int(hit_ptr[-1]) >= 2 ** 31 or int(seg_ptr[-1]) >= 2 ** 31:
+            raise ValueError("batch outside the int32 index range")
 
-        src, dst = cat("src", True), cat("dst", True)
+        def cat(field):
+            # every graph's endpoints + its hit offset, written straight into its slice of ONE int32 array (the
+            # first version went through int64 copies, np.where and a concatenate: 25 ms per million segments, four
+            # times this - more than the GPU needs to plan AND score the batch)
+            out = np.full(int(seg_ptr[-1]), -1, dtype=_I32) if pad_segments else np.empty(int(seg_ptr[-1]), dtype=_I32)
+            for i, g in enumerate(graphs):
+                a = np.asarray(getattr(g, field))
+                e, o = a.shape[0], int(seg_ptr[i])
+                if e == 0:
+                    continue
+                view = out[o:o + e]
+                np.add(a, int(hit_ptr[i]), out=view, casting="unsafe")
+                if int(a.min()) < 0:                     # padded segments of the graph itself stay -1
+                    view[a < 0] = -1
+            return out
+
+        src, dst = cat("src"), cat("dst")
         y = None
         if have_y:
             parts = []
