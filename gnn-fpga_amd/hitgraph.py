@@ -84,17 +84,18 @@ class HitGraphBatch:
     _TENSORS = ("X", "src", "dst", "y")        # (+ the six CSR arrays once they exist)
 
     def __init__(self, X, src, dst, y=None, hit_ptr=None, seg_ptr=None,
-                 dense_shape=None, csr=None):
+                 dense_shape=None, csr=None, _checked=False):
         X = np.ascontiguousarray(X, dtype=np.float32)
         src = np.ascontiguousarray(src, dtype=_I32)
         dst = np.ascontiguousarray(dst, dtype=_I32)
         if X.ndim != 2 or src.ndim != 1 or src.shape != dst.shape:
             raise ValueError("expected X [N,F], src [E], dst [E]")
         n = X.shape[0]
-        if np.any((src ^ dst) < 0):                  # signs differ: exactly one end negative
-            raise ValueError("a padded segment must have src = dst = -1")
-        if src.size and (src.max(initial=-1) >= n or dst.max(initial=-1) >= n):
-            raise ValueError("segment endpoint out of range")
+        if not _checked:                             # (from_graphs checks graph by graph, while a graph is in cache)
+            if np.any((src ^ dst) < 0):              # signs differ: exactly one end negative
+                raise ValueError("a padded segment must have src = dst = -1")
+            if src.size and (src.max(initial=-1) >= n or dst.max(initial=-1) >= n):
+                raise ValueError("segment endpoint out of range")
         self.n_hits, self.n_features = n, X.shape[1]
         self.n_segments = src.shape[0]
         self.hit_ptr = np.asarray([0, n] if hit_ptr is None else hit_ptr, dtype=np.int64)
@@ -327,23 +328,31 @@ class HitGraphBatch:
         if int(hit_ptr[-1]) >= 2 ** 31 or int(seg_ptr[-1]) >= 2 ** 31:
             raise ValueError("batch outside the int32 index range")
 
-        def cat(field):
-            # every graph's endpoints + its hit offset, written straight into its slice of ONE int32 array (the
-            # first version went through int64 copies, np.where and a concatenate: 25 ms per million segments, four
-            # times this - more than the GPU needs to plan AND score the batch)
-            out = np.full(int(seg_ptr[-1]), -1, dtype=_I32) if pad_segments else np.empty(int(seg_ptr[-1]), dtype=_I32)
-            for i, g in enumerate(graphs):
-                a = np.asarray(getattr(g, field))
-                e, o = a.shape[0], int(seg_ptr[i])
-                if e == 0:
-                    continue
-                view = out[o:o + e]
-                np.add(a, int(hit_ptr[i]), out=view, casting="unsafe")
-                if int(a.min()) < 0:                     # padded segments of the graph itself stay -1
-                    view[a < 0] = -1
-            return out
-
-        src, dst = cat("src"), cat("dst")
+        # every graph's endpoints + its hit offset, written straight into its slice of ONE int32 array per end (the
+        # first version went through int64 copies, np.where and a concatenate: 25 ms per million segments - more than
+        # the GPU needs to plan AND score the batch), and checked graph by graph while the graph is in cache (the
+        # constructor's checks are whole-batch passes)
+        E_tot = int(seg_ptr[-1])
+        src = np.full(E_tot, -1, dtype=_I32) if pad_segments else np.empty(E_tot, dtype=_I32)
+        dst = np.full(E_tot, -1, dtype=_I32) if pad_segments else np.empty(E_tot, dtype=_I32)
+        for i, g in enumerate(graphs):
+            a, b = np.asarray(g.src), np.asarray(g.dst)
+            if a.ndim != 1 or a.shape != b.shape:
+                raise ValueError("expected src [E], dst [E]")
+            e, o, off, n_g = a.shape[0], int(seg_ptr[i]), int(hit_ptr[i]), int(g.X.shape[0])
+            if e == 0:
+                continue
+            amin, bmin = int(a.min()), int(b.min())
+            if int(a.max()) >= n_g or int(b.max()) >= n_g:
+                raise ValueError("segment endpoint out of range")
+            np.add(a, off, out=src[o:o + e], casting="unsafe")
+            np.add(b, off, out=dst[o:o + e], casting="unsafe")
+            if amin < 0 or bmin < 0:                     # padded segments of the graph itself stay -1
+                pa = a < 0
+                if np.any(pa != (b < 0)):
+                    raise ValueError("a padded segment must have src = dst = -1")
+                src[o:o + e][pa] = -1
+                dst[o:o + e][pa] = -1
         y = None
         if have_y:
             parts = []
@@ -357,7 +366,7 @@ class HitGraphBatch:
         if pad_segments:
             n_max = max((int(g.X.shape[0]) for g in graphs), default=0)
             dense_shape = (B, n_max, e_max)
-        return cls(X, src, dst, y=y, hit_ptr=hit_ptr, seg_ptr=seg_ptr, dense_shape=dense_shape)
+        return cls(X, src, dst, y=y, hit_ptr=hit_ptr, seg_ptr=seg_ptr, dense_shape=dense_shape, _checked=True)
 
     def to_padded(self, flat, fill=0.0):
         """[E_total] values in this batch's segment order -> [B, E_max] (the reference's target /
