@@ -6,4 +6,4 @@ batch/loader, `synth.py` synthetic inputs, `shard.py` event-batch sharding over 
 """
 from .synth import HitGraph  # noqa: F401
 from .hitgraph import HitGraphBatch  # noqa: F401
-from .batcher import batch_generator, merge_graphs  # noqa: F401,E402
+from .batcher import GraphStore, batch_generator, merge_graphs  # noqa: F401,E402

@@ -15,6 +15,9 @@ Here the same batches come out in the same order as `(HitGraphBatch, y)`:
 * `layout="flat"`: no padding at all; scores and `y` are [E_total]; `HitGraphBatch.to_padded` /
   `from_padded` map between the two.
 
+`GraphStore(graphs, device)` keeps a whole dataset resident on the device and assembles the same batches there;
+`batch_generator` takes one in place of the list.
+
 Graphs may be the reference's `SparseGraph` tuples (fields X, Ri_rows, Ri_cols, Ro_rows, Ro_cols,
 y - what `load_graphs(filenames, SparseGraph)` returns, gnn/graph.py:188-194) or `HitGraph`s.
 """
@@ -57,6 +60,93 @@ def merge_graphs(graphs, layout="padded"):
     return b, (None if b.y is None else b.y.view(b.dense_shape[0], b.dense_shape[2]).clone())
 
 
+class GraphStore:
+    """A DATASET of hit graphs resident where the model runs: every graph's features, endpoints (ids local to the
+    graph) and labels concatenated once into four arrays on `device`, and any run of graphs handed out as a
+    `HitGraphBatch` assembled THERE - slices, one offset add, nothing else; no host pass over the segments, nothing
+    across PCIe per batch.  What the reference does per batch on the host (`graph_from_sparse` densifies, `merge_graphs`
+    zero-pads, `np_to_torch(...).cuda()` uploads: gnn/graph.py:28-35, gnn/trainSegmentClassifier.py:66-111) and what
+    `HitGraphBatch.from_graphs` still does per batch in numpy (23-50 ms per 64 detector graphs + their upload, against
+    the 3.7 ms the GPU needs to plan and score 256 of them) happens once per dataset: a tracking dataset of a few
+    thousand events is tens of GB in index form - it fits the 288 GB of one MI355X many times over.
+
+    `batch(j, batch_size, layout)` = the reference's `graphs[j:j + batch_size]` in list order (`layout` as in
+    `merge_graphs`); endpoints are checked once, graph by graph, when the store is built (works on CPU tensors too:
+    that is how the CPU tests hold it equal to `HitGraphBatch.from_graphs`)."""
+
+    def __init__(self, graphs, device=None):
+        gs = [as_hit_graph(g) for g in graphs]
+        self.n_graphs = len(gs)
+        hp = np.zeros(self.n_graphs + 1, dtype=np.int64)
+        sp = np.zeros(self.n_graphs + 1, dtype=np.int64)
+        for i, g in enumerate(gs):
+            hp[i + 1] = hp[i] + g.X.shape[0]
+            sp[i + 1] = sp[i] + np.asarray(g.src).shape[0]
+        self.hit_ptr, self.seg_ptr = hp, sp
+        src = np.empty(int(sp[-1]), dtype=np.int32)
+        dst = np.empty(int(sp[-1]), dtype=np.int32)
+        for i, g in enumerate(gs):                       # local ids, checked while the graph is in cache
+            a, b = np.asarray(g.src), np.asarray(g.dst)
+            if a.ndim != 1 or a.shape != b.shape:
+                raise ValueError("expected src [E], dst [E]")
+            if a.shape[0] == 0:
+                continue
+            if int(a.max()) >= g.X.shape[0] or int(b.max()) >= g.X.shape[0]:
+                raise ValueError("segment endpoint out of range")
+            if (int(a.min()) < 0 or int(b.min()) < 0) and np.any((a < 0) != (b < 0)):
+                raise ValueError("a padded segment must have src = dst = -1")
+            src[sp[i]:sp[i + 1]] = a
+            dst[sp[i]:sp[i + 1]] = b
+        ys = [getattr(g, "y", None) for g in gs]
+        t = torch.from_numpy
+        dev = torch.device("cpu") if device is None else torch.device(device)
+        self.device = dev
+        self.X = t(np.concatenate([np.asarray(g.X, dtype=np.float32) for g in gs])).to(dev)
+        self.src, self.dst = t(src).to(dev), t(dst).to(dev)
+        self.y = None if any(v is None for v in ys) else \
+            t(np.concatenate([np.asarray(v, dtype=np.float32) for v in ys])).to(dev)
+
+    def batch(self, j, batch_size=1, layout="padded"):
+        """(HitGraphBatch, y) of graphs j ... j + batch_size - 1, like `merge_graphs(graphs[j:j + batch_size], layout)`."""
+        if layout not in ("padded", "flat"):
+            raise ValueError("layout must be 'padded' or 'flat'")
+        j1 = min(j + batch_size, self.n_graphs)
+        B = j1 - j
+        hp = self.hit_ptr[j:j1 + 1] - self.hit_ptr[j]
+        counts = np.diff(self.seg_ptr[j:j1 + 1])
+        e0, e1 = int(self.seg_ptr[j]), int(self.seg_ptr[j1])
+        dev = self.device
+        src, dst = self.src[e0:e1], self.dst[e0:e1]
+        y = None if self.y is None else self.y[e0:e1]
+        cnt_t = torch.from_numpy(counts).to(dev)
+        # the offset of a segment's graph inside the batch, one entry per segment (a few hundred bytes cross over)
+        off = torch.repeat_interleave(torch.from_numpy(hp[:-1].astype(np.int32)).to(dev), cnt_t)
+        src = torch.where(src >= 0, src + off, src)
+        dst = torch.where(dst >= 0, dst + off, dst)
+        dense_shape = None
+        sp = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        if layout == "padded":
+            e_max = int(counts.max(initial=0))
+            n_max = int(np.diff(hp).max(initial=0))
+            if B * e_max != e1 - e0:                     # ragged: every graph's segments into its row of [B, E_max]
+                row = torch.repeat_interleave(torch.arange(B, device=dev), cnt_t)
+                col = torch.arange(e1 - e0, device=dev) - torch.repeat_interleave(
+                    torch.from_numpy(sp[:-1]).to(dev), cnt_t)
+                at = row * e_max + col
+                full = lambda v, fill, dt: torch.full((B * e_max,), fill, dtype=dt, device=dev).index_copy_(0, at, v)  # noqa: E731
+                src, dst = full(src, -1, torch.int32), full(dst, -1, torch.int32)
+                y = None if y is None else full(y, 0.0, torch.float32)
+            sp = np.arange(B + 1, dtype=np.int64) * e_max
+            dense_shape = (B, n_max, e_max)
+        b = HitGraphBatch._from_device_arrays(self.X[int(self.hit_ptr[j]):int(self.hit_ptr[j1])], src.contiguous(),
+                                              dst.contiguous(), y, hp, sp, dense_shape)
+        if y is not None and dense_shape is not None:
+            y = b.y.view(dense_shape[0], dense_shape[2])
+        elif y is not None:
+            y = b.y
+        return b, (None if y is None else y.clone())
+
+
 def _batch_bytes(b, y):
     """Bytes a cached batch pins at most: its own arrays, its two CSRs and the level-ordered twin the
     training path may add (a second copy of all of them), plus the two execution plans (about the size
@@ -84,7 +174,10 @@ def batch_generator(graphs, n_samples=1, batch_size=1, train=True, device=None, 
         for j in idxs:
             item = kept.get(int(j))
             if item is None:
-                b, y = merge_graphs(graphs[j:j + batch_size], layout)
+                if isinstance(graphs, GraphStore):        # assembled where the dataset lives
+                    b, y = graphs.batch(int(j), min(batch_size, n_samples - int(j)), layout)
+                else:
+                    b, y = merge_graphs(graphs[j:j + batch_size], layout)
                 if device is not None:
                     b = b.to(device)
                     y = None if y is None else y.to(device)

@@ -511,6 +511,29 @@ class HitGraphBatch:
         self._event = (_EventLayout(self.hit_ptr, self.seg_ptr, Xt.device),)
         return self
 
+    @classmethod
+    def _from_device_arrays(cls, X, src, dst, y, hit_ptr, seg_ptr, dense_shape=None):
+        """A batch from arrays that already live where they will be used (batcher.GraphStore): torch tensors X
+        [N, F] float32, src / dst [E] int32 in batch numbering (-1 = padded), y [E] or None; hit_ptr / seg_ptr host
+        arrays.  The endpoints were checked when the store was built: block-diagonal by construction."""
+        self = cls.__new__(cls)
+        self.n_hits, self.n_features, self.n_segments = int(X.shape[0]), int(X.shape[1]), int(src.shape[0])
+        self.hit_ptr = np.asarray(hit_ptr, dtype=np.int64)
+        self.seg_ptr = np.asarray(seg_ptr, dtype=np.int64)
+        self.n_graphs = len(self.hit_ptr) - 1
+        self.dense_shape = dense_shape
+        self.X = X.to(torch.float32).contiguous()
+        self.src, self.dst = src.to(torch.int32).contiguous(), dst.to(torch.int32).contiguous()
+        self._csr = None
+        self._src_host = self._dst_host = None
+        self.y = None if y is None else y.to(torch.float32).contiguous()
+        self.plan = None
+        if X.is_cuda:
+            self._event = (_EventLayout(self.hit_ptr, self.seg_ptr, X.device),)
+        else:                        # a CPU batch builds its lists on the host from these
+            self._src_host, self._dst_host = self.src.numpy(), self.dst.numpy()
+        return self
+
     # -- device movement -----------------------------------------------------------------
     def to(self, device):
         for k in self._TENSORS:

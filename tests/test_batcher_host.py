@@ -96,6 +96,42 @@ def test_batch_generator_yields_the_reference_batches(name, layout):
     assert seen[:nb] == seen[nb:]                 # epochs reuse the batches (plans / CSRs with them)
 
 
+@pytest.mark.parametrize("name", ["batchgen_sector_b2", "batchgen_muon_b4"])
+@pytest.mark.parametrize("layout", ["padded", "flat"])
+def test_graph_store_assembles_the_reference_batches(name, layout):
+    """batcher.GraphStore: the dataset concatenated once (here on the CPU), every batch assembled from slices + one
+    offset add where it lives - the same batches, entry for entry, as merge_graphs on the list (and therefore the
+    reference's: the fixtures' targets), also through batch_generator."""
+    from gnn_fpga_amd.batcher import GraphStore, merge_graphs
+    d = _fx(name)
+    graphs = _sparse_graphs(d)
+    n_samples, bs, nb = int(d["n_samples"]), int(d["batch_size"]), int(d["n_batches"])
+    store = GraphStore(graphs)
+    gen = gnn_fpga_amd.batch_generator(store, n_samples=n_samples, batch_size=bs, layout=layout)
+    for b in range(nb):
+        got, y = next(gen)
+        ref, yr = merge_graphs(graphs[b * bs:(b + 1) * bs], layout)
+        for k in ("X", "src", "dst", "y"):
+            assert torch.equal(getattr(got, k), getattr(ref, k)), k
+        assert torch.equal(y, yr) and got.dense_shape == ref.dense_shape
+        assert np.array_equal(got.hit_ptr, ref.hit_ptr) and np.array_equal(got.seg_ptr, ref.seg_ptr)
+        assert (got.n_hits, got.n_segments, got.n_graphs) == (ref.n_hits, ref.n_segments, ref.n_graphs)
+        if layout == "padded":
+            assert np.array_equal(y.numpy(), d["b%d.y" % b])
+        assert all(torch.equal(a, c) for a, c in zip(got._ensure_csr(), ref._ensure_csr()))
+    # ragged graphs, any window, graphs without segments; malformed graphs are refused when the store is built
+    gs = [synth.layered_graph(n, e, 3, n_layers=2, seed=s) for s, (n, e) in enumerate([(5, 9), (40, 0), (2, 1), (33, 80), (7, 7)])]
+    store = GraphStore(gs)
+    for j, k in ((0, 5), (1, 3), (4, 1), (3, 9)):
+        got, y = store.batch(j, k, layout)
+        ref, yr = merge_graphs(gs[j:j + k], layout)
+        assert torch.equal(got.src, ref.src) and torch.equal(got.dst, ref.dst) and torch.equal(y, yr)
+    bad = synth.HitGraph(gs[0].X, gs[0].src.copy(), gs[0].dst.copy(), gs[0].y)
+    bad.dst[2] = 5
+    with pytest.raises(ValueError):
+        GraphStore([gs[3], bad])
+
+
 def test_batch_generator_cache_is_bounded_by_bytes():
     """The generator keeps batches (and what hangs off them: CSRs, plans, level-ordered twins) only
     while their estimated bytes fit `max_cached_bytes`; beyond that, and with cache=False, it holds

@@ -72,6 +72,29 @@ def test_batch_generator_batches_score_like_the_reference(hip, name):
     assert np.abs(out.cpu().numpy() - want).max() < TOL
 
 
+def test_graph_store_on_the_device_scores_like_host_built_batches(hip):
+    """A dataset resident in HBM (batcher.GraphStore on cuda): batches assembled on the device are the arrays
+    HitGraphBatch.from_graphs(...).cuda() holds, so every route gives the same bits - detector-size graphs through
+    first forward (per-module kernels on gnn_csr_build's lists) and planned forward, muon graphs through k_event."""
+    from gnn_fpga_amd.batcher import GraphStore
+    from gnn_fpga_amd.model import SegmentClassifier
+    for F, graphs, bs in ((3, [synth.layered_graph(3000 + 100 * s, 30000, 3, seed=s) for s in range(6)], 3),
+                          (11, [synth.muon_graph(s) for s in range(40)], 16)):
+        store = GraphStore(graphs, device="cuda")
+        torch.manual_seed(0)
+        m = SegmentClassifier(input_dim=F, hidden_dim=8, n_iters=3).cuda().eval()
+        for layout in ("flat", "padded"):
+            for j in range(0, len(graphs), bs):
+                got, y = store.batch(j, bs, layout)
+                ref = HitGraphBatch.from_graphs(graphs[j:j + bs], pad_segments=layout == "padded").cuda()
+                assert got.X.is_cuda and torch.equal(got.src, ref.src) and torch.equal(got.dst, ref.dst)
+                assert torch.equal(got.X, ref.X) and torch.equal(y.reshape(-1), ref.y)
+                with torch.no_grad():
+                    a1, b1 = m(got), m(ref)            # first forward of each
+                    a2, b2 = m(got), m(ref)            # second (planned / event route again)
+                assert torch.equal(a1, b1) and torch.equal(a2, b2)
+
+
 def test_dense_inputs_are_converted_on_the_device(hip):
     """The reference's dense [B,N,E] contract on CUDA tensors: one HIP kernel (gnn_dense_to_index)
     gives the index form the host adapter gives, refuses what it refuses, and - with validation off -
