@@ -106,6 +106,24 @@ class GraphStore:
         self.y = None if any(v is None for v in ys) else \
             t(np.concatenate([np.asarray(v, dtype=np.float32) for v in ys])).to(dev)
 
+    @classmethod
+    def from_npz(cls, filenames, device=None):
+        """The store of the graph files the reference's `save_graph` / `save_graphs` wrote (gnn/graph.py:179-194; the
+        muon writer's `pt` / `eta` are kept in `self.pt` / `self.eta`): what `load_graphs(filenames, SparseGraph)`
+        (gnn/graph.py:188-194) reads per training run, read once and kept on the device."""
+        from collections import namedtuple
+        SG = namedtuple("SparseGraph", ["X", "Ri_rows", "Ri_cols", "Ro_rows", "Ro_cols", "y"])
+        gs, pt, eta = [], [], []
+        for fn in filenames:
+            with np.load(fn) as f:                        # allow_pickle stays False
+                gs.append(SG(f["X"], f["Ri_rows"], f["Ri_cols"], f["Ro_rows"], f["Ro_cols"],
+                             f["y"] if "y" in f.files else None))
+                pt.append(float(f["pt"]) if "pt" in f.files else None)
+                eta.append(float(f["eta"]) if "eta" in f.files else None)
+        store = cls(gs, device)
+        store.pt, store.eta = pt, eta
+        return store
+
     def batch(self, j, batch_size=1, layout="padded"):
         """(HitGraphBatch, y) of graphs j ... j + batch_size - 1, like `merge_graphs(graphs[j:j + batch_size], layout)`."""
         if layout not in ("padded", "flat"):

@@ -132,6 +132,20 @@ def test_graph_store_assembles_the_reference_batches(name, layout):
         GraphStore([gs[3], bad])
 
 
+def test_graph_store_reads_the_files_the_reference_wrote():
+    """GraphStore.from_npz on the two graph files written by the reference's own save_graph (tracking and muon
+    schema): each graph comes back as the batch HitGraphBatch.from_npz makes of its file."""
+    from gnn_fpga_amd.batcher import GraphStore
+    files = [os.path.join(REF_WRITTEN, "graph000000.npz"), os.path.join(REF_WRITTEN, "graph_muon_000000.npz")]
+    for fn in files:                                   # (the two files have different feature counts: one store each)
+        store = GraphStore.from_npz([fn])
+        ref = HitGraphBatch.from_npz(fn)
+        got, y = store.batch(0, 1, "flat")
+        assert torch.equal(got.X, ref.X) and torch.equal(got.src, ref.src) and torch.equal(got.dst, ref.dst)
+        assert torch.equal(y, ref.y) and store.pt[0] == ref.pt and store.eta[0] == ref.eta
+        assert all(torch.equal(a, c) for a, c in zip(got._ensure_csr(), ref._ensure_csr()))
+
+
 def test_batch_generator_cache_is_bounded_by_bytes():
     """The generator keeps batches (and what hangs off them: CSRs, plans, level-ordered twins) only
     while their estimated bytes fit `max_cached_bytes`; beyond that, and with cache=False, it holds
