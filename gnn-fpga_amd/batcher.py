@@ -137,8 +137,9 @@ class GraphStore:
         src, dst = self.src[e0:e1], self.dst[e0:e1]
         y = None if self.y is None else self.y[e0:e1]
         cnt_t = torch.from_numpy(counts).to(dev)
-        # the offset of a segment's graph inside the batch, one entry per segment (a few hundred bytes cross over)
-        off = torch.repeat_interleave(torch.from_numpy(hp[:-1].astype(np.int32)).to(dev), cnt_t)
+        # the offset of a segment's graph inside the batch, one entry per segment (a few hundred bytes cross over;
+        # output_size: no read-back of the total)
+        off = torch.repeat_interleave(torch.from_numpy(hp[:-1].astype(np.int32)).to(dev), cnt_t, output_size=e1 - e0)
         src = torch.where(src >= 0, src + off, src)
         dst = torch.where(dst >= 0, dst + off, dst)
         dense_shape = None
@@ -147,9 +148,9 @@ class GraphStore:
             e_max = int(counts.max(initial=0))
             n_max = int(np.diff(hp).max(initial=0))
             if B * e_max != e1 - e0:                     # ragged: every graph's segments into its row of [B, E_max]
-                row = torch.repeat_interleave(torch.arange(B, device=dev), cnt_t)
+                row = torch.repeat_interleave(torch.arange(B, device=dev), cnt_t, output_size=e1 - e0)
                 col = torch.arange(e1 - e0, device=dev) - torch.repeat_interleave(
-                    torch.from_numpy(sp[:-1]).to(dev), cnt_t)
+                    torch.from_numpy(sp[:-1]).to(dev), cnt_t, output_size=e1 - e0)
                 at = row * e_max + col
                 full = lambda v, fill, dt: torch.full((B * e_max,), fill, dtype=dt, device=dev).index_copy_(0, at, v)  # noqa: E731
                 src, dst = full(src, -1, torch.int32), full(dst, -1, torch.int32)
