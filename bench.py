@@ -614,6 +614,31 @@ def run(args):
             warm_runs.append((t1 - t0) * 1e3)
             if t2 - t0 < t_plan_warm + t_fresh_fwd:
                 t_plan_warm, t_fresh_fwd = t1 - t0, t2 - t1
+        # where a batch is put together: on the host (from_graphs + upload) or on the device from a dataset resident in
+        # HBM (batcher.GraphStore) - outside every timed region above, on the record beside them
+        assembly = None
+        if world == 1:
+            from gnn_fpga_amd.batcher import GraphStore
+            t0 = time.perf_counter()
+            hb = HitGraphBatch.from_graphs(graphs)
+            t1 = time.perf_counter()
+            hb = hb.to(dev)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            del hb
+            store = GraphStore(graphs, device=dev)
+            t_st = float("inf")
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t3 = time.perf_counter()
+                sb, _y = store.batch(0, len(graphs), "flat")
+                torch.cuda.synchronize()
+                t_st = min(t_st, time.perf_counter() - t3)
+            assembly = {"host_from_graphs_ms": (t1 - t0) * 1e3, "upload_ms": (t2 - t1) * 1e3,
+                        "graph_store_on_device_ms": t_st * 1e3,
+                        "note": "one batch of the workload's graphs: HitGraphBatch.from_graphs (numpy) + .to(device), "
+                                "against GraphStore.batch (the dataset resident in HBM, slices + one offset add there)"}
+            del store, sb
         # the same never-seen batch on the model's default first-forward route (no plan: segment lists by
         # gnn_csr_build + the per-module kernels)
         t_first = float("inf")
@@ -790,6 +815,8 @@ def run(args):
             "value_incl_plan_note": "one forward on a never-seen batch: warm plan build + first forward; "
                                     "`value` replays one resident batch (plan amortised)",
         }
+        if assembly is not None:
+            out["batch_assembly_ms"] = assembly
         if exact is not None:
             out["value_exact_exp"] = world * e_tot / exact
             out["ms_per_step_exact_exp"] = exact * 1e3
