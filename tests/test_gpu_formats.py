@@ -95,6 +95,20 @@ def test_graph_store_on_the_device_scores_like_host_built_batches(hip):
                 assert torch.equal(a1, b1) and torch.equal(a2, b2)
 
 
+def test_host_built_batches_can_be_put_together_in_pinned_memory(hip):
+    """from_graphs(pin_memory=True) (the default from 1 M segments on when a GPU is there): the same arrays, in
+    page-locked memory, so that `.cuda()` runs at the link's rate."""
+    graphs = [synth.layered_graph(400 + 10 * s, 3000, 3, seed=s) for s in range(5)]
+    for pad in (False, True):
+        a = HitGraphBatch.from_graphs(graphs, pad_segments=pad, pin_memory=False)
+        b = HitGraphBatch.from_graphs(graphs, pad_segments=pad, pin_memory=True)
+        assert b.src.is_pinned() and b.dst.is_pinned() and b.X.is_pinned() and b.y.is_pinned() and not a.src.is_pinned()
+        for k in ("X", "src", "dst", "y"):
+            assert torch.equal(getattr(a, k), getattr(b, k)), k
+        bc = b.cuda()
+        assert torch.equal(bc.src.cpu(), a.src) and torch.equal(bc.X.cpu(), a.X)
+
+
 def test_dense_inputs_are_converted_on_the_device(hip):
     """The reference's dense [B,N,E] contract on CUDA tensors: one HIP kernel (gnn_dense_to_index)
     gives the index form the host adapter gives, refuses what it refuses, and - with validation off -
