@@ -1,7 +1,8 @@
 """Random batches through the HIP plan builder's three stage-1 forms - graph-local with per-tile lists, graph-local with
 scattered pairs, global - against the numpy specification plan.SellPlan, EVERY array and scalar equal.  What the fixed
 shapes of tests/test_plan_hip.py do not reach: random graph counts and sizes (1 hit ... a few thousand), layer counts,
-skip-layer segments (level = longest walk, not the layer), multi-edges, graphs without segments, shuffled segment
+skip-layer segments (level = longest walk, not the layer), multi-edges, graphs without segments, now and then a graph
+with cycles (the layout check sends the batch to the global form), shuffled segment
 order, padded segments at random places and in blocks, random tile sizes, both kernel shape families.
 usage: python tools/plan_soak.py [trials] [seed]"""
 import os, sys, time
@@ -49,7 +50,10 @@ for t in range(trials):
         e = 0 if rng.random() < 0.1 else int(rng.integers(0, 12 * n + 1))
         if n < 2:
             e = 0
-        gr = random_dag(n, e, F, min(L, max(2, n)), rng, skip=rng.random() < 0.3) if n >= 2 else \
+        cyclic = n >= 2 and e > 0 and rng.random() < 0.05     # any segments at all: cycles, self loops -> status 128
+        gr = synth.HitGraph(rng.uniform(-1, 1, (n, F)).astype(np.float32), rng.integers(0, n, e).astype(np.int32),
+                            rng.integers(0, n, e).astype(np.int32), np.zeros(e, np.float32)) if cyclic else \
+            random_dag(n, e, F, min(L, max(2, n)), rng, skip=rng.random() < 0.3) if n >= 2 else \
             synth.HitGraph(rng.uniform(-1, 1, (n, F)).astype(np.float32), np.zeros(0, np.int32), np.zeros(0, np.int32),
                            np.zeros(0, np.float32))
         if len(gr.src) and rng.random() < 0.15:          # shuffled segment order
